@@ -1,0 +1,121 @@
+"""ctypes binding of libzenv_hip.so (include/zenv.h).  No PyTorch, no CPU fallback.
+
+The library is built in-tree by ``build.py`` (hipcc, gfx950).  Importing this module fails
+loudly when the shared object is missing; every compute call fails with ``ZenvError`` when
+no MI355X is present.
+"""
+import ctypes as C
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libzenv_hip.so")
+
+MAX_ZONES = 32
+OBS_DIM = 8
+
+TASK_TSP, TASK_TIMED_TSP, TASK_COLOUR_MATCH = 0, 1, 2
+POLICY_UNIFORM, POLICY_GREEDY = 0, 1
+KERNEL_LANE_PER_ENV, KERNEL_WAVE_PER_ENV = 0, 1
+
+E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE = -1, -2, -3, -4, -5
+
+(F_OBS, F_ZONE_OBS, F_REWARD, F_DONE, F_GOAL_MET, F_EP_RETURN, F_EP_LEN, F_LAST_RETURN,
+ F_LAST_LEN, F_EPISODES, F_VISIT_COUNT, F_SEED, F_ACTIONS) = range(13)
+
+
+class ZenvError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"zenv error {code}: {message}")
+        self.code = code
+
+
+class Config(C.Structure):
+    """Mirror of ``zenv_config`` (include/zenv.h)."""
+    _fields_ = [
+        ("task", C.c_int32), ("num_zones", C.c_int32), ("num_steps", C.c_int32),
+        ("max_cd", C.c_int32), ("frameskip", C.c_int32), ("kernel", C.c_int32),
+        ("zones_size", C.c_double), ("zones_keepout", C.c_double), ("robot_keepout", C.c_double),
+        ("extent", C.c_double), ("placements_margin", C.c_double),
+        ("time_saved_reward", C.c_double), ("beta_a", C.c_double), ("beta_b", C.c_double),
+        ("timestep", C.c_double), ("mass", C.c_double), ("com_x", C.c_double),
+        ("inertia_zz", C.c_double), ("damping", C.c_double * 3), ("gear", C.c_double),
+        ("forcerange", C.c_double), ("vel_kv", C.c_double),
+    ]
+
+    def copy(self):
+        out = Config()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(Config))
+        return out
+
+
+# every symbol include/zenv.h declares: name -> (restype, argtypes)
+_H = C.c_void_p
+_PROTOTYPES = {
+    "zenv_last_error": (C.c_char_p, []),
+    "zenv_version": (C.c_char_p, []),
+    "zenv_config_for_id": (C.c_int, [C.c_char_p, C.POINTER(Config)]),
+    "zenv_default_config": (C.c_int, [C.c_int, C.c_int, C.POINTER(Config)]),
+    "zenv_zone_feat": (C.c_int, [C.POINTER(Config)]),
+    "zenv_sample_layout": (C.c_int, [C.POINTER(Config), C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.POINTER(C.c_int32)]),
+    "zenv_fixed_seed_sequence": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "zenv_create": (C.c_int, [C.POINTER(Config), C.c_int, C.c_int, C.POINTER(_H)]),
+    "zenv_destroy": (C.c_int, [_H]),
+    "zenv_num_envs": (C.c_int, [_H]),
+    "zenv_get_config": (C.c_int, [_H, C.POINTER(Config)]),
+    "zenv_bank_build": (C.c_int, [_H, C.c_int64, C.c_int, C.c_int]),
+    "zenv_bank_set": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "zenv_bank_size": (C.c_int, [_H]),
+    "zenv_schedule_sequential": (C.c_int, [_H, C.c_void_p, C.c_int32]),
+    "zenv_schedule_fixed_seeds": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int64]),
+    "zenv_reset": (C.c_int, [_H, C.c_void_p]),
+    "zenv_step": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
+    "zenv_policy": (C.c_int, [_H, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "zenv_rollout": (C.c_int, [_H, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
+                               C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "zenv_get": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int]),
+    "zenv_device_ptr": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),
+    "zenv_field_bytes": (C.c_int64, [_H, C.c_int]),
+    "zenv_sync": (C.c_int, [_H]),
+    "zenv_step_count": (C.c_int64, [_H]),
+    "zenv_state_bytes": (C.c_int64, [_H]),
+    "zenv_get_state": (C.c_int, [_H, C.c_void_p, C.c_int64]),
+    "zenv_set_state": (C.c_int, [_H, C.c_void_p, C.c_int64]),
+    "zenv_debug_state": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libzenv_hip.so once.  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # If torch is (or will be) in this process its bundled libamdhip64 must be the one HIP
+    # runtime: make sure it is loaded first so our DT_NEEDED resolves to the same copy.
+    if "torch" in sys.modules:
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL if hasattr(C, "RTLD_GLOBAL") else 0)
+    for name, (restype, argtypes) in _PROTOTYPES.items():
+        fn = getattr(L, name)   # AttributeError if the ABI is incomplete
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().zenv_last_error()
+        raise ZenvError(rc, msg.decode() if msg else "")
+    return rc
+
+
+def exported_symbols():
+    return sorted(_PROTOTYPES)

@@ -1,0 +1,60 @@
+// dev_params.hpp -- POD handed by value to every kernel: model constants + HBM pointers.
+//
+// HBM layout (lane-per-env kernels): everything is struct-of-arrays over the env index so
+// that lane i of a wave touches element i of each array (64 x 8 B = 512 B per wave-load):
+//   dyn      q[3][N], v[3][N]           float64   joint positions / velocities
+//   frame    x0,y0,bq0,bq3 [N]          float64   episode-static robot placement (body quat w,z)
+//   zones    zx[Z][N], zy[Z][N]         float64   zone centres, zone-major
+//   TSP/TTSP vis[N] u32 bitmask; tmax[Z][N] i32 (TimedTSP)
+//   Colour   colpack[N] u64 (2 bits/zone), cooldown[Z][N] u8, goal_dist[N] i32
+//   counters steps[N] i32, done_state[N] u8, ep_return[N] f64, episodes/last_len[N] i32 ...
+// Outputs are row-major exactly as the reference consumer reads them
+// (main/src/utils/format.py:25-29): obs [N][8] f32, zone_obs [N][Z][F] f32.
+#pragma once
+#include <cstdint>
+
+namespace zenvk {
+
+struct DevParams {
+    // sizes / task
+    int32_t task, Z, F, N;
+    int32_t num_steps, max_cd, frameskip, bank_size;
+    int32_t sched_mode, sched_stride;
+    int64_t seed_min, seed_max;
+    // model constants (derived on the host once; see zenv_api.cpp:derive_constants)
+    double h, gear, fmax, kv, mc;
+    double b0, b1, b2;
+    double A22, inv00, inv11;
+    double hit_d2;        // largest d2 with sqrt(d2) <= zones_size
+    double tsr;           // time_saved_reward
+    // state
+    double *q0, *q1, *q2, *v0, *v1, *v2;
+    double *x0, *y0, *bq0, *bq3;
+    double *zx, *zy;
+    uint32_t *vis;
+    int32_t *tmax;
+    uint64_t *colpack;
+    uint8_t *cooldown;
+    int32_t *goal_dist;
+    int32_t *steps;
+    uint8_t *done_state;
+    double *ep_return, *last_return;
+    int32_t *last_len, *episodes, *visit_count;
+    int64_t *seed;
+    // schedule
+    int32_t *slot_first, *episode_idx;
+    uint64_t *pcg;        // [N][4] state_hi,state_lo,inc_hi,inc_lo
+    uint32_t *pcg_buf;    // [N][2] has_u32,u32
+    // bank
+    const double *bank_robot;   // [S][4] x0,y0,bq0,bq3
+    const double *bank_zone;    // [S][Z][2]
+    const int32_t *bank_aux;    // [S][Z]
+    const int64_t *bank_seed;   // [S]
+    // outputs
+    float *obs, *zone_obs, *reward, *actions;
+    uint8_t *done_out, *goal_met;
+};
+
+enum { SCHED_SEQUENTIAL = 0, SCHED_FIXED_SEEDS = 1 };
+
+}  // namespace zenvk

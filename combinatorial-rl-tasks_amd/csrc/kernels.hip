@@ -1,0 +1,602 @@
+// kernels.hip -- gfx950 (CDNA4, wave64) kernels of the batched zone-env hot path.
+//
+// K1  k_step_lane<TASK>   one env.step() for every env (TSP_env.py:45-72, TTSP_env.py:62-71,
+//                         colour_match_env.py:86-123, ZoneEnvBase.py:143-235 + the not-vendored
+//                         Engine.step / mj_step of xmls/point.xml), with the ParallelEnv
+//                         auto-reset of penv.py:8-11 fused in.
+// K2  k_reset_lane<TASK>  masked re-init from the HBM layout bank (Engine.reset).
+// K3  k_policy_lane<TASK> scripted action sources (the build's own).
+//
+// Execution shape (lane-per-env): a 64-thread workgroup = one wave64 owns 64 consecutive
+// envs; lane i holds env i's dynamics in registers and streams the zone-major SoA zone
+// arrays (512 B fully-coalesced loads).  The (N,Z,F) float32 zone_obs rows are built in an
+// LDS tile [64][Z*F] and leave as one contiguous 64*Z*F*4-byte burst of dwordx4 stores.
+// No MFMA: there is no contraction anywhere on this path; the bound is HBM bytes.
+// Build with -ffp-contract=off: the float64 state must match the CPU oracle bit for bit.
+#include <hip/hip_runtime.h>
+
+#include "det_math.hpp"
+#include "dev_params.hpp"
+#include "kernels.hpp"
+
+namespace zenvk {
+
+namespace {
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------- small helpers
+__device__ __forceinline__ int hamming_to_goal(uint64_t colpack, int Z)
+{
+    // colour_match_env.py:38-55 with colours packed 2 bits/zone: 0 Blue, 1 Green, 2 Red
+    const uint64_t lo_bits = 0x5555555555555555ull;
+    const uint64_t used = (Z >= 32) ? ~0ull : ((1ull << (2 * Z)) - 1ull);
+    const uint64_t g = colpack & lo_bits & used;          // bit0 set  -> Green
+    const uint64_t r = (colpack >> 1) & lo_bits & used;   // bit1 set  -> Red
+    const int ng = __popcll(g), nr = __popcll(r), nb = Z - ng - nr;
+    const int to_blue = ng * 2 + nr, to_green = nr * 2 + nb, to_red = nb * 2 + ng;
+    return min(to_blue, min(to_green, to_red));
+}
+
+// PCG64 (numpy default_rng) step/output on device, for the FixedSeedsWrapper schedule
+__device__ __forceinline__ void pcg_step_dev(uint64_t &hi, uint64_t &lo, uint64_t ihi, uint64_t ilo)
+{
+    const uint64_t mh = 2549297995355413924ull, ml = 4865540595714422341ull;
+    const uint64_t plo = lo * ml;
+    const uint64_t phi = __umul64hi(lo, ml) + hi * ml + lo * mh;
+    const uint64_t nlo = plo + ilo;
+    const uint64_t nhi = phi + ihi + (nlo < plo ? 1ull : 0ull);
+    hi = nhi;
+    lo = nlo;
+}
+
+__device__ uint32_t pcg_next32_dev(const DevParams &p, int env)
+{
+    uint32_t *buf = p.pcg_buf + 2 * (size_t)env;
+    if (buf[0]) {
+        buf[0] = 0;
+        return buf[1];
+    }
+    uint64_t *s = p.pcg + 4 * (size_t)env;
+    uint64_t hi = s[0], lo = s[1];
+    pcg_step_dev(hi, lo, s[2], s[3]);
+    s[0] = hi;
+    s[1] = lo;
+    const uint64_t x = hi ^ lo;
+    const unsigned rot = (unsigned)(hi >> 58);
+    const uint64_t out = (x >> rot) | (x << ((0u - rot) & 63u));
+    buf[0] = 1;
+    buf[1] = (uint32_t)(out >> 32);
+    return (uint32_t)out;
+}
+
+__device__ int next_bank_slot(const DevParams &p, int env)
+{
+    const int k = p.episode_idx[env];
+    p.episode_idx[env] = k + 1;
+    if (p.sched_mode == SCHED_SEQUENTIAL) {
+        const long long s = (long long)p.slot_first[env] + (long long)k * (long long)p.sched_stride;
+        return (int)(s % (long long)p.bank_size);
+    }
+    // wrappers.py:20-23: rng.integers(min_seed, max_seed + 1) -- Lemire on 32-bit draws
+    const uint64_t rng = (uint64_t)(p.seed_max - p.seed_min);
+    if (rng == 0) return 0;
+    const uint32_t rng_excl = (uint32_t)rng + 1u;
+    uint64_t m = (uint64_t)pcg_next32_dev(p, env) * rng_excl;
+    uint32_t leftover = (uint32_t)m;
+    if (leftover < rng_excl) {
+        const uint32_t threshold = (0xFFFFFFFFu - (uint32_t)rng) % rng_excl;
+        while (leftover < threshold) {
+            m = (uint64_t)pcg_next32_dev(p, env) * rng_excl;
+            leftover = (uint32_t)m;
+        }
+    }
+    return (int)(m >> 32);
+}
+
+// Per-lane registers of one env
+struct EnvRegs {
+    double q0, q1, q2, v0, v1, v2;
+    double x0, y0, bq0, bq3;
+    uint32_t vis;
+    uint64_t colpack;
+    int32_t goal_dist;
+    int32_t steps;
+};
+
+// World-frame quantities of mj_forward for body "robot" (slides act in the placement frame)
+struct Pose {
+    double px, py, vx, vy, w, xq0, xq3;
+};
+
+__device__ __forceinline__ void world_pos(const EnvRegs &e, double &px, double &py)
+{
+    const double cr = e.bq0 * e.bq0 - e.bq3 * e.bq3;
+    const double sr = 2.0 * (e.bq0 * e.bq3);
+    px = e.x0 + (cr * e.q0 - sr * e.q1);
+    py = e.y0 + (sr * e.q0 + cr * e.q1);
+}
+
+__device__ __forceinline__ Pose forward_pose(const EnvRegs &e)
+{
+    Pose o;
+    const double cr = e.bq0 * e.bq0 - e.bq3 * e.bq3;
+    const double sr = 2.0 * (e.bq0 * e.bq3);
+    o.px = e.x0 + (cr * e.q0 - sr * e.q1);
+    o.py = e.y0 + (sr * e.q0 + cr * e.q1);
+    o.vx = cr * e.v0 - sr * e.v1;
+    o.vy = sr * e.v0 + cr * e.v1;
+    o.w = e.v2;
+    double hs, hc;
+    det_sincos_inl(0.5 * e.q2, hs, hc);
+    o.xq0 = e.bq0 * hc - e.bq3 * hs;
+    o.xq3 = e.bq0 * hs + e.bq3 * hc;
+    return o;
+}
+
+// ZoneEnvBase.py:190-192,217-224 -> the 8-float 'obs' of wrappers.py:136-142
+__device__ __forceinline__ void emit_obs8(const DevParams &p, const EnvRegs &e, float *o)
+{
+    const Pose f = forward_pose(e);
+    o[0] = (float)(1.0 - (double)e.steps / (double)p.num_steps);
+    o[1] = (float)(f.px / 3.0);
+    o[2] = (float)(f.py / 3.0);
+    const double a0 = (double)(float)f.xq0, a3 = (double)(float)f.xq3;
+    o[3] = (float)(a0 * a0 - a3 * a3);
+    o[4] = (float)((2.0 * a0) * a3);
+    o[5] = (float)(f.vx / 1.5);
+    o[6] = (float)(f.vy / 1.5);
+    o[7] = (float)(f.w / 3.0);
+}
+
+__device__ __forceinline__ void store_obs8(const DevParams &p, int env, const float *o)
+{
+    float4 *dst = reinterpret_cast<float4 *>(p.obs + (size_t)env * 8);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+// One zone row of 'zone_obs' (TSP_env.py:31-35, TTSP_env.py:86-92, colour_match_env.py:75-80)
+template <int TASK>
+__device__ __forceinline__ void write_row(const DevParams &p, float *row, double zx, double zy,
+                                          int flag_or_colour, int aux, int k)
+{
+    row[0] = (float)(zx / 3.0);
+    row[1] = (float)(zy / 3.0);
+    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+        row[2] = flag_or_colour == 2 ? 1.f : 0.f;
+        row[3] = flag_or_colour == 1 ? 1.f : 0.f;
+        row[4] = flag_or_colour == 0 ? 1.f : 0.f;
+        row[5] = 0.25f;
+        row[6] = (float)((double)(float)aux / (double)p.max_cd);
+    } else {
+        row[2] = flag_or_colour ? 1.f : 0.f;
+        row[3] = 1.f;
+        row[4] = flag_or_colour ? 0.f : 1.f;
+        row[5] = 0.25f;
+        if (TASK == ZENV_TASK_TIMED_TSP)
+            row[6] = flag_or_colour ? 1.f : (float)((double)(aux - k) / (double)p.num_steps);
+    }
+}
+
+// Engine.reset for one env from bank slot `slot`: writes the SoA zone arrays, the lane's
+// registers and the env's zone_obs rows (rows may point to LDS or to global memory).
+template <int TASK>
+__device__ void reset_env(const DevParams &p, int env, int slot, EnvRegs &e, float *rows)
+{
+    const int Z = p.Z, N = p.N, F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
+    const double *br = p.bank_robot + 4 * (size_t)slot;
+    e.x0 = br[0]; e.y0 = br[1]; e.bq0 = br[2]; e.bq3 = br[3];
+    e.q0 = e.q1 = e.q2 = 0.0;
+    e.v0 = e.v1 = e.v2 = 0.0;
+    e.vis = 0u;
+    e.colpack = 0ull;
+    e.goal_dist = 0;
+    e.steps = 0;
+    const double *bz = p.bank_zone + 2 * (size_t)slot * Z;
+    const int32_t *ba = p.bank_aux + (size_t)slot * Z;
+    for (int z = 0; z < Z; ++z) {
+        const double zx = bz[2 * z], zy = bz[2 * z + 1];
+        const size_t zi = (size_t)z * N + env;
+        p.zx[zi] = zx;
+        p.zy[zi] = zy;
+        int flag = 0, aux = 0;
+        if (TASK == ZENV_TASK_TIMED_TSP) {
+            aux = ba[z];
+            p.tmax[zi] = aux;
+        } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
+            flag = ba[z];
+            e.colpack |= (uint64_t)flag << (2 * z);
+            p.cooldown[zi] = 0;
+        }
+        write_row<TASK>(p, rows + z * F, zx, zy, flag, aux, 0);
+    }
+    if (TASK == ZENV_TASK_COLOUR_MATCH) e.goal_dist = hamming_to_goal(e.colpack, Z);
+    p.seed[env] = p.bank_seed[slot];
+}
+
+__device__ __forceinline__ void load_regs(const DevParams &p, int env, int task, EnvRegs &e)
+{
+    e.q0 = p.q0[env]; e.q1 = p.q1[env]; e.q2 = p.q2[env];
+    e.v0 = p.v0[env]; e.v1 = p.v1[env]; e.v2 = p.v2[env];
+    e.x0 = p.x0[env]; e.y0 = p.y0[env]; e.bq0 = p.bq0[env]; e.bq3 = p.bq3[env];
+    e.steps = p.steps[env];
+    e.vis = 0u; e.colpack = 0ull; e.goal_dist = 0;
+    if (task == ZENV_TASK_COLOUR_MATCH) {
+        e.colpack = p.colpack[env];
+        e.goal_dist = p.goal_dist[env];
+    } else {
+        e.vis = p.vis[env];
+    }
+}
+
+__device__ __forceinline__ void store_regs(const DevParams &p, int env, int task, const EnvRegs &e,
+                                           bool frame_too)
+{
+    p.q0[env] = e.q0; p.q1[env] = e.q1; p.q2[env] = e.q2;
+    p.v0[env] = e.v0; p.v1[env] = e.v1; p.v2[env] = e.v2;
+    if (frame_too) {
+        p.x0[env] = e.x0; p.y0[env] = e.y0; p.bq0[env] = e.bq0; p.bq3[env] = e.bq3;
+    }
+    p.steps[env] = e.steps;
+    if (task == ZENV_TASK_COLOUR_MATCH) {
+        p.colpack[env] = e.colpack;
+        p.goal_dist[env] = e.goal_dist;
+    } else {
+        p.vis[env] = e.vis;
+    }
+}
+
+// MuJoCo mj_step for point.xml: 3 dof (slide x, slide y, hinge z), offset COM, implicit
+// joint damping, no active constraints.  Operation order is the
+// oracle's, token for token.
+__device__ __forceinline__ void mj_substep(const DevParams &p, EnvRegs &e, double c0, double c1)
+{
+    double s, k;
+    det_sincos_inl(e.q2, s, k);
+    const double mcs = p.mc * s, mck = p.mc * k;
+    const double w2 = e.v2 * e.v2;
+    const double f0 = det_clamp(c0, -p.fmax, p.fmax);
+    const double f1 = det_clamp(p.kv * c1 - p.kv * (p.gear * e.v2), -p.fmax, p.fmax);
+    const double gf0 = p.gear * f0;
+    const double rhs0 = (gf0 * k + mck * w2) - p.b0 * e.v0;
+    const double rhs1 = (gf0 * s + mcs * w2) - p.b1 * e.v1;
+    const double rhs2 = p.gear * f1 - p.b2 * e.v2;
+    const double t0 = rhs0 * p.inv00, t1 = rhs1 * p.inv11;
+    const double den = (p.A22 - (mcs * mcs) * p.inv00) - (mck * mck) * p.inv11;
+    const double num = (rhs2 + mcs * t0) - mck * t1;
+    const double a2 = num / den;
+    const double a0 = (rhs0 + mcs * a2) * p.inv00;
+    const double a1 = (rhs1 - mck * a2) * p.inv11;
+    e.v0 = e.v0 + p.h * a0;
+    e.v1 = e.v1 + p.h * a1;
+    e.v2 = e.v2 + p.h * a2;
+    e.q0 = e.q0 + p.h * e.v0;
+    e.q1 = e.q1 + p.h * e.v1;
+    e.q2 = e.q2 + p.h * e.v2;
+}
+
+// Contiguous LDS tile -> HBM burst: [n_env_blk][ZF] floats, 16 B per lane per store
+__device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_floats, int lane)
+{
+    const int n4 = n_floats >> 2;
+    const float4 *s4 = reinterpret_cast<const float4 *>(tile);
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    for (int i = lane; i < n4; i += kWave) d4[i] = s4[i];
+    for (int i = (n4 << 2) + lane; i < n_floats; i += kWave) dst[i] = tile[i];
+}
+
+// =========================================================================== K1: step
+template <int TASK>
+__global__ __launch_bounds__(kWave) void k_step_lane(DevParams p, const float *__restrict__ actions,
+                                                     int auto_reset)
+{
+    extern __shared__ __align__(16) float tile[];
+    constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
+    const int lane = threadIdx.x;
+    const int env0 = blockIdx.x * kWave;
+    const int env = env0 + lane;
+    const int N = p.N, Z = p.Z, ZF = Z * F;
+    float *rows = tile + lane * ZF;
+
+    if (env < N) {
+        float o[8];
+        float rew_out = 0.f;
+        uint8_t done_out = 1, goal_out = 0;
+        if (p.done_state[env]) {
+            // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
+            for (int i = 0; i < ZF; ++i) rows[i] = 0.f;
+            for (int i = 0; i < 8; ++i) o[i] = 0.f;
+        } else {
+            EnvRegs e;
+            load_regs(p, env, TASK, e);
+            const float2 act = reinterpret_cast<const float2 *>(actions)[env];
+            // Engine.step: ctrl = clip(action, ctrlrange)
+            const double c0 = det_clamp((double)act.x, -1.0, 1.0);
+            const double c1 = det_clamp((double)act.y, -1.0, 1.0);
+            const int k = e.steps + 1;   // step index after this call
+
+            // ---- zone pass: set_mocaps() of the first substep, with the pre-physics pose
+            double rx, ry;
+            world_pos(e, rx, ry);
+            int first = -1;
+            bool timed_out = false;
+            for (int z = 0; z < Z; ++z) {
+                const size_t zi = (size_t)z * N + env;
+                const double zx = p.zx[zi], zy = p.zy[zi];
+                const double dx = zx - rx, dy = zy - ry;
+                const double d2 = dx * dx + dy * dy;
+                const bool inside = d2 <= p.hit_d2;
+                if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                    int cd = p.cooldown[zi];
+                    if (cd > 0) cd -= 1;                       // colour_match_env.py:98-100
+                    int col = (int)((e.colpack >> (2 * z)) & 3ull);
+                    if (first < 0 && cd == 0 && inside) {       // :106-120, lowest index wins
+                        first = z;
+                        col = (col == 2) ? 0 : col + 1;         // Blue->Green->Red->Blue
+                        e.colpack = (e.colpack & ~(3ull << (2 * z))) | ((uint64_t)col << (2 * z));
+                        cd = p.max_cd;
+                    }
+                    p.cooldown[zi] = (uint8_t)cd;
+                    write_row<TASK>(p, rows + z * F, zx, zy, col, cd, k);
+                } else {
+                    bool vis = (e.vis >> z) & 1u;
+                    if (first < 0 && !vis && inside) {          // TSP_env.py:54-69
+                        first = z;
+                        vis = true;
+                        e.vis |= 1u << z;
+                    }
+                    int tm = 0;
+                    if (TASK == ZENV_TASK_TIMED_TSP) {
+                        tm = p.tmax[zi];
+                        if (!vis && (tm - k) <= 0) timed_out = true;   // TTSP_env.py:67
+                    }
+                    write_row<TASK>(p, rows + z * F, zx, zy, vis ? 1 : 0, tm, k);
+                }
+            }
+
+            // ---- physics: frameskip x mj_step
+            for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
+
+            // ---- reward / goal / termination (Engine.step order)
+            double r = 0.0;
+            bool goal;
+            if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                if (first >= 0) {
+                    const int nd = hamming_to_goal(e.colpack, Z);
+                    r = (double)(e.goal_dist - nd);
+                    e.goal_dist = nd;
+                }
+                goal = e.goal_dist == 0;
+            } else {
+                r = first >= 0 ? 1.0 : 0.0;
+                const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
+                goal = e.vis == full;
+            }
+            bool done = false;
+            if (goal) {
+                r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
+                done = true;
+                goal_out = 1;
+            }
+            e.steps = k;
+            if (k >= p.num_steps) done = true;
+            if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
+
+            double ep_ret = p.ep_return[env] + r;
+            rew_out = (float)r;
+            done_out = done ? 1 : 0;
+            p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
+
+            bool frame_changed = false;
+            if (done) {
+                p.last_return[env] = ep_ret;
+                p.last_len[env] = k;
+                p.episodes[env] += 1;
+                if (auto_reset) {
+                    // penv.py:8-11: the returned obs is the first obs of the next episode
+                    const int slot = next_bank_slot(p, env);
+                    reset_env<TASK>(p, env, slot, e, rows);
+                    ep_ret = 0.0;
+                    frame_changed = true;
+                } else {
+                    p.done_state[env] = 1;
+                }
+            }
+            p.ep_return[env] = ep_ret;
+            store_regs(p, env, TASK, e, frame_changed);
+            emit_obs8(p, e, o);
+        }
+        store_obs8(p, env, o);
+        p.reward[env] = rew_out;
+        p.done_out[env] = done_out;
+        p.goal_met[env] = goal_out;
+    }
+    __syncthreads();
+    const int n_blk = min(kWave, N - env0);
+    flush_tile(tile, p.zone_obs + (size_t)env0 * ZF, n_blk * ZF, lane);
+}
+
+// =========================================================================== K2: reset
+template <int TASK>
+__global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t *__restrict__ mask)
+{
+    constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
+    const int env = blockIdx.x * kWave + threadIdx.x;
+    if (env >= p.N) return;
+    if (mask && !mask[env]) return;
+    EnvRegs e;
+    const int slot = next_bank_slot(p, env);
+    reset_env<TASK>(p, env, slot, e, p.zone_obs + (size_t)env * p.Z * F);
+    store_regs(p, env, TASK, e, true);
+    p.done_state[env] = 0;
+    p.ep_return[env] = 0.0;
+    p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : 0;
+    float o[8];
+    emit_obs8(p, e, o);
+    store_obs8(p, env, o);
+    p.reward[env] = 0.f;
+    p.done_out[env] = 0;
+    p.goal_met[env] = 0;
+}
+
+// =========================================================================== K3: policies
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+template <int TASK>
+__global__ __launch_bounds__(kWave) void k_policy_lane(DevParams p, int policy, uint64_t policy_seed,
+                                                       uint64_t env_index0, uint32_t step_index,
+                                                       float *__restrict__ out)
+{
+    extern __shared__ __align__(16) float tile[];
+    constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
+    const int lane = threadIdx.x;
+    const int env0 = blockIdx.x * kWave;
+    const int env = env0 + lane;
+    const int N = p.N, Z = p.Z, ZF = Z * F;
+
+    if (policy == ZENV_POLICY_UNIFORM) {
+        if (env < N) {
+            const uint64_t gi = env_index0 + (uint64_t)env;
+            uint32_t c[4] = { (uint32_t)gi, (uint32_t)(gi >> 32), step_index, 0u };
+            philox4x32_10(c, (uint32_t)policy_seed, (uint32_t)(policy_seed >> 32));
+            float2 a;
+            a.x = 2.0f * ((float)(c[0] >> 8) * 5.9604644775390625e-08f) - 1.0f;
+            a.y = 2.0f * ((float)(c[1] >> 8) * 5.9604644775390625e-08f) - 1.0f;
+            reinterpret_cast<float2 *>(out)[env] = a;
+        }
+        return;
+    }
+
+    // greedy: stage the wave's zone_obs rows through LDS (coalesced 16 B/lane loads)
+    {
+        const int n_blk = min(kWave, N - env0);
+        const int n_floats = n_blk * ZF, n4 = n_floats >> 2;
+        const float *src = p.zone_obs + (size_t)env0 * ZF;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *t4 = reinterpret_cast<float4 *>(tile);
+        for (int i = lane; i < n4; i += kWave) t4[i] = s4[i];
+        for (int i = (n4 << 2) + lane; i < n_floats; i += kWave) tile[i] = src[i];
+    }
+    __syncthreads();
+    if (env >= N) return;
+    const float *rows = tile + lane * ZF;
+    const float4 *ob = reinterpret_cast<const float4 *>(p.obs + (size_t)env * 8);
+    const float4 oa = ob[0], obb = ob[1];
+    const double px = 3.0 * (double)oa.y, py = 3.0 * (double)oa.z;
+    const double hx = (double)oa.w, hy = (double)obb.x;
+
+    int target_colour = -1;
+    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+        int cb = 0, cg = 0, cr = 0;
+        for (int z = 0; z < Z; ++z) {
+            const float *row = rows + z * F;
+            const int col = row[4] != 0.f ? 0 : (row[3] != 0.f ? 1 : 2);
+            cb += col == 0; cg += col == 1; cr += col == 2;
+        }
+        target_colour = 0;
+        int best_cnt = cb;
+        if (cg > best_cnt) { target_colour = 1; best_cnt = cg; }
+        if (cr > best_cnt) { target_colour = 2; }
+    }
+    int best = -1;
+    double bd2 = 0.0, bdx = 0.0, bdy = 0.0;
+    for (int z = 0; z < Z; ++z) {
+        const float *row = rows + z * F;
+        bool eligible;
+        if (TASK == ZENV_TASK_COLOUR_MATCH) {
+            const int col = row[4] != 0.f ? 0 : (row[3] != 0.f ? 1 : 2);
+            eligible = (row[6] == 0.f) && (col != target_colour);
+        } else {
+            eligible = row[2] == 0.f;
+        }
+        const double dx = 3.0 * (double)row[0] - px, dy = 3.0 * (double)row[1] - py;
+        const double d2 = dx * dx + dy * dy;
+        if (eligible && (best < 0 || d2 < bd2)) { best = z; bd2 = d2; bdx = dx; bdy = dy; }
+    }
+    float2 a = make_float2(0.f, 0.f);
+    if (best >= 0 && bd2 > 1e-18) {
+        const double n = sqrt(bd2);
+        const double cs = (hx * bdx + hy * bdy) / n;
+        const double sn = (hx * bdy - hy * bdx) / n;
+        if (cs < 0.0) a.y = sn >= 0.0 ? 1.f : -1.f;
+        else a.y = (float)det_clamp(4.0 * sn, -1.0, 1.0);
+        a.x = cs > 0.8 ? 1.f : 0.f;
+    }
+    reinterpret_cast<float2 *>(out)[env] = a;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- launchers
+static inline int n_blocks(int n) { return (n + kWave - 1) / kWave; }
+static inline size_t tile_bytes(const DevParams &p) { return (size_t)kWave * p.Z * p.F * sizeof(float); }
+
+hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset, hipStream_t s)
+{
+    const dim3 grid(n_blocks(p.N)), block(kWave);
+    const size_t lds = tile_bytes(p);
+    switch (p.task) {
+    case ZENV_TASK_TSP:
+        hipLaunchKernelGGL(k_step_lane<ZENV_TASK_TSP>, grid, block, lds, s, p, actions, auto_reset);
+        break;
+    case ZENV_TASK_TIMED_TSP:
+        hipLaunchKernelGGL(k_step_lane<ZENV_TASK_TIMED_TSP>, grid, block, lds, s, p, actions, auto_reset);
+        break;
+    default:
+        hipLaunchKernelGGL(k_step_lane<ZENV_TASK_COLOUR_MATCH>, grid, block, lds, s, p, actions, auto_reset);
+        break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_reset(const DevParams &p, const uint8_t *mask, hipStream_t s)
+{
+    const dim3 grid(n_blocks(p.N)), block(kWave);
+    switch (p.task) {
+    case ZENV_TASK_TSP:
+        hipLaunchKernelGGL(k_reset_lane<ZENV_TASK_TSP>, grid, block, 0, s, p, mask);
+        break;
+    case ZENV_TASK_TIMED_TSP:
+        hipLaunchKernelGGL(k_reset_lane<ZENV_TASK_TIMED_TSP>, grid, block, 0, s, p, mask);
+        break;
+    default:
+        hipLaunchKernelGGL(k_reset_lane<ZENV_TASK_COLOUR_MATCH>, grid, block, 0, s, p, mask);
+        break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_policy(const DevParams &p, int policy, uint64_t policy_seed, uint64_t env_index0,
+                         uint32_t step_index, float *out, hipStream_t s)
+{
+    const dim3 grid(n_blocks(p.N)), block(kWave);
+    const size_t lds = policy == ZENV_POLICY_GREEDY ? tile_bytes(p) : 0;
+    switch (p.task) {
+    case ZENV_TASK_TSP:
+        hipLaunchKernelGGL(k_policy_lane<ZENV_TASK_TSP>, grid, block, lds, s, p, policy, policy_seed,
+                           env_index0, step_index, out);
+        break;
+    case ZENV_TASK_TIMED_TSP:
+        hipLaunchKernelGGL(k_policy_lane<ZENV_TASK_TIMED_TSP>, grid, block, lds, s, p, policy,
+                           policy_seed, env_index0, step_index, out);
+        break;
+    default:
+        hipLaunchKernelGGL(k_policy_lane<ZENV_TASK_COLOUR_MATCH>, grid, block, lds, s, p, policy,
+                           policy_seed, env_index0, step_index, out);
+        break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace zenvk

@@ -1,0 +1,737 @@
+// zenv_api.cpp -- the C ABI of include/zenv.h over the gfx950 kernels.
+// Host-side plumbing only: device memory, the layout bank, launches, copies.  There is no
+// CPU compute path here: without a usable HIP device every compute entry point fails.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/zenv.h"
+#include "dev_params.hpp"
+#include "host_sampler.hpp"
+#include "kernels.hpp"
+
+using namespace zenvk;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(ZENV_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+struct Alloc {
+    void **slot;
+    size_t bytes;
+    bool is_state;   // part of zenv_get_state/zenv_set_state
+};
+
+}  // namespace
+
+struct zenv {
+    zenv_config cfg{};
+    int n_env = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevParams p{};
+    std::vector<Alloc> allocs;
+    void *bank_mem[4] = { nullptr, nullptr, nullptr, nullptr };
+    uint8_t *d_mask = nullptr;
+    bool bank_ready = false;
+    bool sched_ready = false;
+    bool was_reset = false;
+    int64_t step_count = 0;
+    std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+int validate_config(const zenv_config &c)
+{
+    if (c.task < ZENV_TASK_TSP || c.task > ZENV_TASK_COLOUR_MATCH) return fail(ZENV_E_ARG, "unknown task %d", c.task);
+    if (c.num_zones < 1 || c.num_zones > ZENV_MAX_ZONES)
+        return fail(ZENV_E_ARG, "num_zones %d outside [1,%d]", c.num_zones, ZENV_MAX_ZONES);
+    if (c.num_steps < 1) return fail(ZENV_E_ARG, "num_steps must be positive");
+    if (c.max_cd < 0 || c.max_cd > 255) return fail(ZENV_E_ARG, "max_cd %d outside [0,255]", c.max_cd);
+    if (c.frameskip < 1 || c.frameskip > 1000) return fail(ZENV_E_ARG, "bad frameskip %d", c.frameskip);
+    if (!(c.mass > 0) || !(c.inertia_zz > 0) || !(c.timestep > 0)) return fail(ZENV_E_ARG, "bad model constants");
+    if (c.kernel != ZENV_KERNEL_LANE_PER_ENV)
+        return fail(ZENV_E_ARG, "kernel layout %d not available in this build", c.kernel);
+    return ZENV_OK;
+}
+
+void derive_constants(const zenv_config &c, DevParams &p)
+{
+    p.task = c.task;
+    p.Z = c.num_zones;
+    p.F = zenv_zone_feat(&c);
+    p.num_steps = c.num_steps;
+    p.max_cd = c.max_cd;
+    p.frameskip = c.frameskip;
+    p.h = c.timestep;
+    p.gear = c.gear;
+    p.fmax = c.forcerange;
+    p.kv = c.vel_kv;
+    p.mc = c.mass * c.com_x;
+    p.b0 = c.damping[0];
+    p.b1 = c.damping[1];
+    p.b2 = c.damping[2];
+    const double A00 = c.mass + c.timestep * c.damping[0];
+    const double A11 = c.mass + c.timestep * c.damping[1];
+    p.A22 = c.inertia_zz + c.timestep * c.damping[2];
+    p.inv00 = 1.0 / A00;
+    p.inv11 = 1.0 / A11;
+    p.hit_d2 = sqrt_threshold(c.zones_size);
+    p.tsr = c.time_saved_reward;
+}
+
+template <typename T>
+void want(zenv *h, T *&slot, size_t count, bool is_state)
+{
+    h->allocs.push_back({ reinterpret_cast<void **>(&slot), count * sizeof(T), is_state });
+}
+
+int use_device(const zenv *h)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    return ZENV_OK;
+}
+
+struct FieldInfo {
+    void *ptr;
+    int64_t bytes;
+};
+
+FieldInfo field_info(const zenv *h, int field)
+{
+    const DevParams &p = h->p;
+    const int64_t N = h->n_env;
+    switch (field) {
+    case ZENV_F_OBS: return { p.obs, N * 8 * 4 };
+    case ZENV_F_ZONE_OBS: return { p.zone_obs, N * p.Z * p.F * 4 };
+    case ZENV_F_REWARD: return { p.reward, N * 4 };
+    case ZENV_F_DONE: return { p.done_out, N };
+    case ZENV_F_GOAL_MET: return { p.goal_met, N };
+    case ZENV_F_EP_RETURN: return { p.ep_return, N * 8 };
+    case ZENV_F_EP_LEN: return { p.steps, N * 4 };
+    case ZENV_F_LAST_RETURN: return { p.last_return, N * 8 };
+    case ZENV_F_LAST_LEN: return { p.last_len, N * 4 };
+    case ZENV_F_EPISODES: return { p.episodes, N * 4 };
+    case ZENV_F_VISIT_COUNT: return { p.visit_count, N * 4 };
+    case ZENV_F_SEED: return { p.seed, N * 8 };
+    case ZENV_F_ACTIONS: return { p.actions, N * 2 * 4 };
+    default: return { nullptr, 0 };
+    }
+}
+
+}  // namespace
+
+// ============================================================================ host-only API
+extern "C" const char *zenv_last_error(void) { return g_err.c_str(); }
+
+extern "C" const char *zenv_version(void) { return "zenv-hip 0.1 (gfx950)"; }
+
+extern "C" int zenv_zone_feat(const zenv_config *cfg)
+{
+    if (!cfg) return 0;
+    return cfg->task == ZENV_TASK_TSP ? 6 : 7;   // TSP_env.py:27-29, TTSP_env.py:78-84, colour_match_env.py:70-73
+}
+
+extern "C" int zenv_default_config(int task, int num_zones, zenv_config *c)
+{
+    if (!c) return fail(ZENV_E_ARG, "null config");
+    std::memset(c, 0, sizeof(*c));
+    c->task = task;
+    c->num_zones = num_zones;
+    c->num_steps = 2000;
+    c->max_cd = 150;
+    c->frameskip = 10;
+    c->kernel = ZENV_KERNEL_LANE_PER_ENV;
+    c->zones_size = 0.2;
+    c->zones_keepout = 0.55;
+    c->robot_keepout = 0.4;
+    c->extent = 3.0;
+    c->placements_margin = 0.0;
+    c->time_saved_reward = 0.01;
+    c->beta_a = 3.0;
+    c->beta_b = 1.5;
+    // xmls/point.xml: sphere r=0.1 at the body origin + box half-size 0.05 at (0.1,0,0), density 1
+    const double pi = 3.14159265358979323846, density = 1.0;
+    const double m_sphere = density * (4.0 / 3.0 * pi * 0.1 * 0.1 * 0.1);
+    const double m_box = density * (8.0 * 0.05 * 0.05 * 0.05);
+    c->timestep = 0.002;
+    c->mass = m_sphere + m_box;
+    c->com_x = 0.1 * m_box / c->mass;
+    c->inertia_zz = 0.4 * m_sphere * (0.1 * 0.1) + m_box * (0.05 * 0.05 + 0.05 * 0.05) / 3.0 + m_box * (0.1 * 0.1);
+    c->damping[0] = 0.01;
+    c->damping[1] = 0.01;
+    c->damping[2] = 0.005;
+    c->gear = 0.3;
+    c->forcerange = 0.05;
+    c->vel_kv = 1.0;
+    return validate_config(*c);
+}
+
+extern "C" int zenv_config_for_id(const char *env_id, zenv_config *out)
+{
+    if (!env_id || !out) return fail(ZENV_E_ARG, "null argument");
+    struct Entry {
+        const char *id;
+        int task, zones, steps;
+    };
+    // envs/__init__.py:88-141 with config_point / config_point_easy / config_point_colour
+    static const Entry table[] = {
+        { "PointTSP-v0", ZENV_TASK_TSP, 15, 2000 },        { "PointTSP-v1", ZENV_TASK_TSP, 5, 1000 },
+        { "PointTTSP-v0", ZENV_TASK_TIMED_TSP, 15, 2000 }, { "PointTTSP-v1", ZENV_TASK_TIMED_TSP, 5, 1000 },
+        { "ColourMatch-v0", ZENV_TASK_COLOUR_MATCH, 6, 2000 },
+    };
+    for (const Entry &e : table) {
+        if (std::strcmp(e.id, env_id) == 0) {
+            int rc = zenv_default_config(e.task, e.zones, out);
+            if (rc) return rc;
+            out->num_steps = e.steps;
+            return ZENV_OK;
+        }
+    }
+    return fail(ZENV_E_ARG, "Unknown environment: %s", env_id);
+}
+
+extern "C" int zenv_sample_layout(const zenv_config *cfg, int64_t seed, double *robot_xyrot,
+                                  double *zone_xy, int32_t *aux, int32_t *restarts)
+{
+    if (!cfg) return fail(ZENV_E_ARG, "null config");
+    int rc = validate_config(*cfg);
+    if (rc) return rc;
+    if (seed < 0 || seed + 1 > 0xFFFFFFFFll) return fail(ZENV_E_ARG, "Seed must be between 0 and 2**32 - 1");
+    Layout L;
+    rc = sample_layout(*cfg, seed, L);
+    if (rc) return fail(rc, "Failed to sample layout of objects (seed %lld)", (long long)seed);
+    if (robot_xyrot) {
+        robot_xyrot[0] = L.robot_x;
+        robot_xyrot[1] = L.robot_y;
+        robot_xyrot[2] = L.robot_rot;
+    }
+    for (int z = 0; z < cfg->num_zones; ++z) {
+        if (zone_xy) {
+            zone_xy[2 * z] = L.zone_xy[z][0];
+            zone_xy[2 * z + 1] = L.zone_xy[z][1];
+        }
+        if (aux) aux[z] = L.aux[z];
+    }
+    if (restarts) *restarts = L.restarts;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_fixed_seed_sequence(uint64_t rng_seed, int64_t min_seed, int64_t max_seed, int count,
+                                        int64_t *out)
+{
+    if (!out || count < 0 || max_seed < min_seed) return fail(ZENV_E_ARG, "bad argument");
+    if ((uint64_t)(max_seed - min_seed) >= 0xFFFFFFFFull) return fail(ZENV_E_ARG, "seed range too wide");
+    Pcg64State s = pcg64_from_seed(rng_seed);
+    for (int i = 0; i < count; ++i) out[i] = pcg64_integers(s, min_seed, max_seed + 1);
+    return ZENV_OK;
+}
+
+// ============================================================================ lifecycle
+extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t **out)
+{
+    if (!cfg || !out) return fail(ZENV_E_ARG, "null argument");
+    *out = nullptr;
+    int rc = validate_config(*cfg);
+    if (rc) return rc;
+    if (n_env < 1) return fail(ZENV_E_ARG, "n_env must be >= 1");
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev < 1)
+        return fail(ZENV_E_HIP, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n_dev) return fail(ZENV_E_ARG, "device %d outside [0,%d)", device, n_dev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ZENV_E_HIP, "device %d is %s; this library ships gfx950 code only", device, prop.gcnArchName);
+
+    zenv *h = new zenv();
+    h->cfg = *cfg;
+    h->n_env = n_env;
+    h->device = device;
+    derive_constants(*cfg, h->p);
+    DevParams &p = h->p;
+    p.N = n_env;
+    p.sched_mode = SCHED_SEQUENTIAL;
+    p.sched_stride = 0;
+    const size_t N = n_env, Z = cfg->num_zones, F = p.F;
+
+    want(h, p.q0, N, true); want(h, p.q1, N, true); want(h, p.q2, N, true);
+    want(h, p.v0, N, true); want(h, p.v1, N, true); want(h, p.v2, N, true);
+    want(h, p.x0, N, true); want(h, p.y0, N, true); want(h, p.bq0, N, true); want(h, p.bq3, N, true);
+    want(h, p.zx, Z * N, true); want(h, p.zy, Z * N, true);
+    want(h, p.vis, N, true);
+    want(h, p.tmax, Z * N, true);
+    want(h, p.colpack, N, true);
+    want(h, p.cooldown, Z * N, true);
+    want(h, p.goal_dist, N, true);
+    want(h, p.steps, N, true);
+    want(h, p.done_state, N, true);
+    want(h, p.ep_return, N, true); want(h, p.last_return, N, true);
+    want(h, p.last_len, N, true); want(h, p.episodes, N, true); want(h, p.visit_count, N, true);
+    want(h, p.seed, N, true);
+    want(h, p.slot_first, N, true); want(h, p.episode_idx, N, true);
+    want(h, p.pcg, 4 * N, true); want(h, p.pcg_buf, 2 * N, true);
+    want(h, p.obs, 8 * N, true); want(h, p.zone_obs, Z * F * N, true);
+    want(h, p.reward, N, true); want(h, p.actions, 2 * N, true);
+    want(h, p.done_out, N, true); want(h, p.goal_met, N, true);
+
+    hipError_t err = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (err != hipSuccess) {
+        delete h;
+        return fail(ZENV_E_HIP, "hipStreamCreate: %s", hipGetErrorString(err));
+    }
+    for (Alloc &a : h->allocs) {
+        err = hipMalloc(a.slot, a.bytes);
+        if (err == hipSuccess) err = hipMemsetAsync(*a.slot, 0, a.bytes, h->stream);
+        if (err != hipSuccess) {
+            zenv_destroy(h);
+            return fail(ZENV_E_HIP, "hipMalloc(%zu): %s", a.bytes, hipGetErrorString(err));
+        }
+    }
+    err = hipMalloc(reinterpret_cast<void **>(&h->d_mask), N);
+    if (err == hipSuccess) err = hipStreamSynchronize(h->stream);
+    if (err != hipSuccess) {
+        zenv_destroy(h);
+        return fail(ZENV_E_HIP, "init: %s", hipGetErrorString(err));
+    }
+    *out = h;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_destroy(zenv_t *h)
+{
+    if (!h) return ZENV_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (Alloc &a : h->allocs)
+        if (*a.slot) (void)hipFree(*a.slot);
+    for (void *m : h->bank_mem)
+        if (m) (void)hipFree(m);
+    if (h->d_mask) (void)hipFree(h->d_mask);
+    for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_num_envs(const zenv_t *h) { return h ? h->n_env : 0; }
+
+extern "C" int zenv_get_config(const zenv_t *h, zenv_config *out)
+{
+    if (!h || !out) return fail(ZENV_E_ARG, "null argument");
+    *out = h->cfg;
+    return ZENV_OK;
+}
+
+// ============================================================================ layout bank
+static int upload_bank(zenv *h, const std::vector<double> &robot4, const std::vector<double> &zone,
+                       const std::vector<int32_t> &aux, const std::vector<int64_t> &seeds)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (void *&m : h->bank_mem) {
+        if (m) HIP_TRY(hipFree(m));
+        m = nullptr;
+    }
+    const size_t S = seeds.size();
+    HIP_TRY(hipMalloc(&h->bank_mem[0], robot4.size() * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->bank_mem[1], zone.size() * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->bank_mem[2], aux.size() * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&h->bank_mem[3], S * sizeof(int64_t)));
+    HIP_TRY(hipMemcpy(h->bank_mem[0], robot4.data(), robot4.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->bank_mem[1], zone.data(), zone.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->bank_mem[2], aux.data(), aux.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->bank_mem[3], seeds.data(), S * sizeof(int64_t), hipMemcpyHostToDevice));
+    h->p.bank_robot = static_cast<const double *>(h->bank_mem[0]);
+    h->p.bank_zone = static_cast<const double *>(h->bank_mem[1]);
+    h->p.bank_aux = static_cast<const int32_t *>(h->bank_mem[2]);
+    h->p.bank_seed = static_cast<const int64_t *>(h->bank_mem[3]);
+    h->p.bank_size = static_cast<int32_t>(S);
+    h->bank_ready = true;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_bank_build(zenv_t *h, int64_t seed_first, int count, int n_threads)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (count < 1) return fail(ZENV_E_ARG, "count must be >= 1");
+    if (seed_first < 0 || seed_first + count > 0xFFFFFFFFll)
+        return fail(ZENV_E_ARG, "Seed must be between 0 and 2**32 - 1");
+    const int Z = h->cfg.num_zones;
+    const size_t S = count;
+    std::vector<double> robot4(S * 4), zone(S * Z * 2);
+    std::vector<int32_t> aux(S * Z);
+    std::vector<int64_t> seeds(S);
+    std::vector<int> status(S, 0);
+    n_threads = std::max(1, std::min(n_threads, 256));
+    auto work = [&](int tid) {
+        for (size_t i = tid; i < S; i += n_threads) {
+            Layout L;
+            status[i] = sample_layout(h->cfg, seed_first + (int64_t)i, L);
+            double s, c;
+            det_sincos(L.robot_rot / 2, s, c);   // world.py rot2quat: [cos(rot/2), 0, 0, sin(rot/2)]
+            robot4[4 * i + 0] = L.robot_x;
+            robot4[4 * i + 1] = L.robot_y;
+            robot4[4 * i + 2] = c;
+            robot4[4 * i + 3] = s;
+            for (int z = 0; z < Z; ++z) {
+                zone[(i * Z + z) * 2 + 0] = L.zone_xy[z][0];
+                zone[(i * Z + z) * 2 + 1] = L.zone_xy[z][1];
+                aux[i * Z + z] = L.aux[z];
+            }
+            seeds[i] = seed_first + (int64_t)i;
+        }
+    };
+    if (n_threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work, t);
+        for (std::thread &t : pool) t.join();
+    }
+    for (size_t i = 0; i < S; ++i)
+        if (status[i])
+            return fail(ZENV_E_LAYOUT, "Failed to sample layout of objects (seed %lld)",
+                        (long long)(seed_first + (int64_t)i));
+    return upload_bank(h, robot4, zone, aux, seeds);
+}
+
+extern "C" int zenv_bank_set(zenv_t *h, const double *robot_xyrot, const double *zone_xy, const int32_t *aux_in,
+                             const int64_t *seeds_in, int count)
+{
+    if (!h || !robot_xyrot || !zone_xy) return fail(ZENV_E_ARG, "null argument");
+    if (count < 1) return fail(ZENV_E_ARG, "count must be >= 1");
+    if (!aux_in && h->cfg.task != ZENV_TASK_TSP) return fail(ZENV_E_ARG, "aux required for this task");
+    const int Z = h->cfg.num_zones;
+    const size_t S = count;
+    std::vector<double> robot4(S * 4), zone(zone_xy, zone_xy + S * Z * 2);
+    std::vector<int32_t> aux(S * Z, 0);
+    std::vector<int64_t> seeds(S, 0);
+    for (size_t i = 0; i < S; ++i) {
+        double s, c;
+        det_sincos(robot_xyrot[3 * i + 2] / 2, s, c);
+        robot4[4 * i + 0] = robot_xyrot[3 * i + 0];
+        robot4[4 * i + 1] = robot_xyrot[3 * i + 1];
+        robot4[4 * i + 2] = c;
+        robot4[4 * i + 3] = s;
+        if (seeds_in) seeds[i] = seeds_in[i];
+    }
+    if (aux_in) {
+        for (size_t i = 0; i < S * Z; ++i) {
+            if (h->cfg.task == ZENV_TASK_COLOUR_MATCH && (aux_in[i] < 0 || aux_in[i] > 2))
+                return fail(ZENV_E_ARG, "colour %d outside 0..2", aux_in[i]);
+            aux[i] = aux_in[i];
+        }
+    }
+    return upload_bank(h, robot4, zone, aux, seeds);
+}
+
+extern "C" int zenv_bank_size(const zenv_t *h) { return h ? h->p.bank_size : 0; }
+
+// ============================================================================ schedule
+extern "C" int zenv_schedule_sequential(zenv_t *h, const int32_t *first, int32_t stride)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (!h->bank_ready) return fail(ZENV_E_STATE, "build or set the layout bank first");
+    if (stride < 0) return fail(ZENV_E_ARG, "stride must be >= 0");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int S = h->p.bank_size;
+    std::vector<int32_t> f(h->n_env);
+    for (int i = 0; i < h->n_env; ++i) {
+        const int32_t v = first ? first[i] : (i % S);
+        if (v < 0 || v >= S) return fail(ZENV_E_ARG, "first[%d] = %d outside the bank [0,%d)", i, v, S);
+        f[i] = v;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->p.slot_first, f.data(), f.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->p.episode_idx, 0, h->n_env * sizeof(int32_t)));
+    h->p.sched_mode = SCHED_SEQUENTIAL;
+    h->p.sched_stride = stride % S;
+    h->sched_ready = true;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_schedule_fixed_seeds(zenv_t *h, const uint64_t *rng_seeds, int64_t min_seed, int64_t max_seed)
+{
+    if (!h || !rng_seeds) return fail(ZENV_E_ARG, "null argument");
+    if (!h->bank_ready) return fail(ZENV_E_STATE, "build or set the layout bank first");
+    if (max_seed < min_seed || max_seed - min_seed + 1 != h->p.bank_size)
+        return fail(ZENV_E_ARG, "bank must hold exactly the seeds min_seed..max_seed (%d layouts)", h->p.bank_size);
+    int rc = use_device(h);
+    if (rc) return rc;
+    std::vector<uint64_t> st(4 * (size_t)h->n_env);
+    for (int i = 0; i < h->n_env; ++i) {
+        const Pcg64State s = pcg64_from_seed(rng_seeds[i]);
+        st[4 * (size_t)i + 0] = s.state_hi;
+        st[4 * (size_t)i + 1] = s.state_lo;
+        st[4 * (size_t)i + 2] = s.inc_hi;
+        st[4 * (size_t)i + 3] = s.inc_lo;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->p.pcg, st.data(), st.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->p.pcg_buf, 0, 2 * (size_t)h->n_env * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(h->p.episode_idx, 0, h->n_env * sizeof(int32_t)));
+    h->p.sched_mode = SCHED_FIXED_SEEDS;
+    h->p.seed_min = min_seed;
+    h->p.seed_max = max_seed;
+    h->sched_ready = true;
+    return ZENV_OK;
+}
+
+// ============================================================================ hot path
+extern "C" int zenv_reset(zenv_t *h, const uint8_t *mask)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (!h->bank_ready) return fail(ZENV_E_STATE, "build or set the layout bank first");
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->sched_ready) {
+        rc = zenv_schedule_sequential(h, nullptr, 0);
+        if (rc) return rc;
+    }
+    if (mask && !h->was_reset) return fail(ZENV_E_STATE, "the first reset must cover every env (mask == NULL)");
+    const uint8_t *dmask = nullptr;
+    if (mask) {
+        HIP_TRY(hipMemcpyAsync(h->d_mask, mask, h->n_env, hipMemcpyHostToDevice, h->stream));
+        dmask = h->d_mask;
+    }
+    HIP_TRY(launch_reset(h->p, dmask, h->stream));
+    h->was_reset = true;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_step(zenv_t *h, const float *actions, int actions_on_device, int auto_reset)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (!h->was_reset) return fail(ZENV_E_STATE, "Environment must be reset before stepping");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const float *d_act = h->p.actions;
+    if (actions) {
+        if (actions_on_device) {
+            d_act = actions;
+        } else {
+            HIP_TRY(hipMemcpyAsync(h->p.actions, actions, sizeof(float) * 2 * (size_t)h->n_env,
+                                   hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    HIP_TRY(launch_step(h->p, d_act, auto_reset, h->stream));
+    h->step_count += 1;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0, float *dst_device)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (!h->was_reset) return fail(ZENV_E_STATE, "reset before asking for actions");
+    if (policy != ZENV_POLICY_UNIFORM && policy != ZENV_POLICY_GREEDY) return fail(ZENV_E_ARG, "unknown policy %d", policy);
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(launch_policy(h->p, policy, policy_seed, env_index0, (uint32_t)h->step_count,
+                          dst_device ? dst_device : h->p.actions, h->stream));
+    return ZENV_OK;
+}
+
+extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
+                            int auto_reset, float *ms_total, float *ms_step_kernel)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (!h->was_reset) return fail(ZENV_E_STATE, "Environment must be reset before stepping");
+    if (steps < 0) return fail(ZENV_E_ARG, "steps must be >= 0");
+    if (policy != ZENV_POLICY_UNIFORM && policy != ZENV_POLICY_GREEDY) return fail(ZENV_E_ARG, "unknown policy %d", policy);
+    int rc = use_device(h);
+    if (rc) return rc;
+    const bool per_kernel = ms_step_kernel != nullptr;
+    const size_t need = 2 + (per_kernel ? 2 * (size_t)steps : 0);
+    while (h->events.size() < need) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        h->events.push_back(ev);
+    }
+    HIP_TRY(hipEventRecord(h->events[0], h->stream));
+    for (int t = 0; t < steps; ++t) {
+        HIP_TRY(launch_policy(h->p, policy, policy_seed, env_index0, (uint32_t)h->step_count, h->p.actions, h->stream));
+        if (per_kernel) HIP_TRY(hipEventRecord(h->events[2 + 2 * t], h->stream));
+        HIP_TRY(launch_step(h->p, h->p.actions, auto_reset, h->stream));
+        if (per_kernel) HIP_TRY(hipEventRecord(h->events[3 + 2 * t], h->stream));
+        h->step_count += 1;
+    }
+    HIP_TRY(hipEventRecord(h->events[1], h->stream));
+    HIP_TRY(hipEventSynchronize(h->events[1]));
+    if (ms_total) HIP_TRY(hipEventElapsedTime(ms_total, h->events[0], h->events[1]));
+    if (per_kernel) {
+        double sum = 0.0;
+        for (int t = 0; t < steps; ++t) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, h->events[2 + 2 * t], h->events[3 + 2 * t]));
+            sum += ms;
+        }
+        *ms_step_kernel = (float)sum;
+    }
+    return ZENV_OK;
+}
+
+// ============================================================================ results
+extern "C" int64_t zenv_field_bytes(const zenv_t *h, int field) { return h ? field_info(h, field).bytes : 0; }
+
+extern "C" int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device)
+{
+    if (!h || !dst) return fail(ZENV_E_ARG, "null argument");
+    const FieldInfo f = field_info(h, field);
+    if (!f.ptr) return fail(ZENV_E_ARG, "unknown field %d", field);
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, f.ptr, f.bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                           h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ZENV_OK;
+}
+
+extern "C" int zenv_device_ptr(zenv_t *h, int field, void **ptr)
+{
+    if (!h || !ptr) return fail(ZENV_E_ARG, "null argument");
+    const FieldInfo f = field_info(h, field);
+    if (!f.ptr) return fail(ZENV_E_ARG, "unknown field %d", field);
+    *ptr = f.ptr;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_sync(zenv_t *h)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ZENV_OK;
+}
+
+extern "C" int64_t zenv_step_count(const zenv_t *h) { return h ? h->step_count : 0; }
+
+// ============================================================================ snapshots
+extern "C" int64_t zenv_state_bytes(const zenv_t *h)
+{
+    if (!h) return 0;
+    int64_t total = 16;   // step_count + flags
+    for (const Alloc &a : h->allocs)
+        if (a.is_state) total += (int64_t)a.bytes;
+    return total;
+}
+
+extern "C" int zenv_get_state(zenv_t *h, void *dst, int64_t bytes)
+{
+    if (!h || !dst) return fail(ZENV_E_ARG, "null argument");
+    if (bytes != zenv_state_bytes(h)) return fail(ZENV_E_ARG, "state blob is %lld bytes", (long long)zenv_state_bytes(h));
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    char *out = static_cast<char *>(dst);
+    int64_t head[2] = { h->step_count, (int64_t)h->p.sched_mode | ((int64_t)h->was_reset << 8) };
+    std::memcpy(out, head, 16);
+    out += 16;
+    for (const Alloc &a : h->allocs) {
+        if (!a.is_state) continue;
+        HIP_TRY(hipMemcpy(out, *a.slot, a.bytes, hipMemcpyDeviceToHost));
+        out += a.bytes;
+    }
+    return ZENV_OK;
+}
+
+extern "C" int zenv_set_state(zenv_t *h, const void *src, int64_t bytes)
+{
+    if (!h || !src) return fail(ZENV_E_ARG, "null argument");
+    if (bytes != zenv_state_bytes(h)) return fail(ZENV_E_ARG, "state blob is %lld bytes", (long long)zenv_state_bytes(h));
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const char *in = static_cast<const char *>(src);
+    int64_t head[2];
+    std::memcpy(head, in, 16);
+    in += 16;
+    for (const Alloc &a : h->allocs) {
+        if (!a.is_state) continue;
+        HIP_TRY(hipMemcpy(*a.slot, in, a.bytes, hipMemcpyHostToDevice));
+        in += a.bytes;
+    }
+    h->step_count = head[0];
+    h->was_reset = ((head[1] >> 8) & 1) != 0;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_debug_state(zenv_t *h, double *qpos, double *qvel, int32_t *zone_state, int32_t *cooldown,
+                                int32_t *steps)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t N = h->n_env, Z = h->cfg.num_zones;
+    const DevParams &p = h->p;
+    std::vector<double> tmp(N);
+    if (qpos) {
+        const double *src[3] = { p.q0, p.q1, p.q2 };
+        for (int k = 0; k < 3; ++k) {
+            HIP_TRY(hipMemcpy(tmp.data(), src[k], N * 8, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < N; ++i) qpos[3 * i + k] = tmp[i];
+        }
+    }
+    if (qvel) {
+        const double *src[3] = { p.v0, p.v1, p.v2 };
+        for (int k = 0; k < 3; ++k) {
+            HIP_TRY(hipMemcpy(tmp.data(), src[k], N * 8, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < N; ++i) qvel[3 * i + k] = tmp[i];
+        }
+    }
+    if (zone_state) {
+        if (h->cfg.task == ZENV_TASK_COLOUR_MATCH) {
+            std::vector<uint64_t> cp(N);
+            HIP_TRY(hipMemcpy(cp.data(), p.colpack, N * 8, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < N; ++i)
+                for (size_t z = 0; z < Z; ++z) zone_state[i * Z + z] = (int32_t)((cp[i] >> (2 * z)) & 3ull);
+        } else {
+            std::vector<uint32_t> v(N);
+            HIP_TRY(hipMemcpy(v.data(), p.vis, N * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < N; ++i)
+                for (size_t z = 0; z < Z; ++z) zone_state[i * Z + z] = (int32_t)((v[i] >> z) & 1u);
+        }
+    }
+    if (cooldown) {
+        std::vector<uint8_t> cd(N * Z);
+        HIP_TRY(hipMemcpy(cd.data(), p.cooldown, N * Z, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; ++i)
+            for (size_t z = 0; z < Z; ++z) cooldown[i * Z + z] = cd[z * N + i];
+    }
+    if (steps) HIP_TRY(hipMemcpy(steps, p.steps, N * 4, hipMemcpyDeviceToHost));
+    return ZENV_OK;
+}

@@ -1,0 +1,250 @@
+"""ZoneVecEnv -- the batched, device-resident surface of the zone-env hot path.
+
+One object = N independent PointTSP / TimedTSP / ColourMatch environments stepped by one
+HIP kernel launch on one MI355X.  This is the thing that replaces the reference's
+``ParallelEnv`` process pool (main/src/torch_ac/torch_utils/penv.py:26-66): ``step`` takes a
+(N, 2) float32 action array and returns struct-of-arrays results; finished envs are
+re-reset inside the same launch and report the next episode's first observation with the
+terminal reward/done, exactly like ``worker`` (penv.py:7-11).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+from ._native import Config, ZenvError, check, lib
+
+_FIELD_DTYPES = {
+    nat.F_OBS: np.float32, nat.F_ZONE_OBS: np.float32, nat.F_REWARD: np.float32,
+    nat.F_DONE: np.uint8, nat.F_GOAL_MET: np.uint8, nat.F_EP_RETURN: np.float64,
+    nat.F_EP_LEN: np.int32, nat.F_LAST_RETURN: np.float64, nat.F_LAST_LEN: np.int32,
+    nat.F_EPISODES: np.int32, nat.F_VISIT_COUNT: np.int32, nat.F_SEED: np.int64,
+    nat.F_ACTIONS: np.float32,
+}
+
+
+def config_for_id(env_id, **overrides):
+    """Config of a registry id (envs/__init__.py:88-141); unknown id -> RuntimeError."""
+    cfg = Config()
+    rc = lib().zenv_config_for_id(env_id.encode(), C.byref(cfg))
+    if rc != 0:
+        raise RuntimeError("Unknown environment")   # make_env.py:18,34,51
+    return apply_overrides(cfg, overrides)
+
+
+def default_config(task, num_zones, **overrides):
+    cfg = Config()
+    check(lib().zenv_default_config(int(task), int(num_zones), C.byref(cfg)))
+    return apply_overrides(cfg, overrides)
+
+
+def apply_overrides(cfg, overrides):
+    for k, v in overrides.items():
+        if k == "damping":
+            for i in range(3):
+                cfg.damping[i] = float(v[i])
+        elif not hasattr(cfg, k):
+            raise KeyError(f"unknown config key {k!r}")
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+def zone_feat(cfg):
+    return lib().zenv_zone_feat(C.byref(cfg))
+
+
+def sample_layout(cfg, seed):
+    """Host half of reset() for ``env.seed(seed); env.reset()``.
+
+    Returns (robot_xyrot[3], zone_xy[Z,2], aux[Z], restarts)."""
+    Z = cfg.num_zones
+    robot = np.zeros(3, np.float64)
+    zones = np.zeros((Z, 2), np.float64)
+    aux = np.zeros(Z, np.int32)
+    restarts = C.c_int32(0)
+    check(lib().zenv_sample_layout(C.byref(cfg), int(seed), robot.ctypes.data, zones.ctypes.data,
+                                   aux.ctypes.data, C.byref(restarts)))
+    return robot, zones, aux, restarts.value
+
+
+def fixed_seed_sequence(rng_seed, min_seed, max_seed, count):
+    """Seeds FixedSeedsWrapper.reset (wrappers.py:20-23) would draw, without numpy's Generator."""
+    out = np.zeros(count, np.int64)
+    check(lib().zenv_fixed_seed_sequence(int(rng_seed), int(min_seed), int(max_seed), int(count),
+                                         out.ctypes.data))
+    return out
+
+
+class ZoneVecEnv:
+    """N device-resident zone envs.
+
+    Parameters
+    ----------
+    cfg : Config or registry id (str)
+    num_envs : N
+    device : HIP device ordinal
+    """
+
+    def __init__(self, cfg, num_envs, device=0, **overrides):
+        if isinstance(cfg, str):
+            cfg = config_for_id(cfg, **overrides)
+        elif overrides:
+            cfg = apply_overrides(cfg.copy(), overrides)
+        self.cfg = cfg
+        self.num_envs = int(num_envs)
+        self.num_zones = cfg.num_zones
+        self.zone_feat = zone_feat(cfg)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        check(lib().zenv_create(C.byref(cfg), self.num_envs, self.device, C.byref(self._h)))
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().zenv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ bank / schedule
+    def build_bank(self, seed_first, count, n_threads=8):
+        check(lib().zenv_bank_build(self._h, int(seed_first), int(count), int(n_threads)))
+
+    def set_bank(self, robot_xyrot, zone_xy, aux=None, seeds=None):
+        robot = np.ascontiguousarray(robot_xyrot, np.float64).reshape(-1, 3)
+        S = robot.shape[0]
+        zones = np.ascontiguousarray(zone_xy, np.float64).reshape(S, self.num_zones, 2)
+        aux_a = None if aux is None else np.ascontiguousarray(aux, np.int32).reshape(S, self.num_zones)
+        seeds_a = None if seeds is None else np.ascontiguousarray(seeds, np.int64).reshape(S)
+        check(lib().zenv_bank_set(self._h, robot.ctypes.data, zones.ctypes.data,
+                                  None if aux_a is None else aux_a.ctypes.data,
+                                  None if seeds_a is None else seeds_a.ctypes.data, S))
+
+    @property
+    def bank_size(self):
+        return lib().zenv_bank_size(self._h)
+
+    def schedule_sequential(self, first=None, stride=0):
+        f = None if first is None else np.ascontiguousarray(first, np.int32)
+        if f is not None and f.shape != (self.num_envs,):
+            raise ValueError("first must have shape (num_envs,)")
+        check(lib().zenv_schedule_sequential(self._h, None if f is None else f.ctypes.data, int(stride)))
+
+    def schedule_fixed_seeds(self, rng_seeds, min_seed, max_seed):
+        s = np.ascontiguousarray(rng_seeds, np.uint64)
+        if s.shape != (self.num_envs,):
+            raise ValueError("rng_seeds must have shape (num_envs,)")
+        check(lib().zenv_schedule_fixed_seeds(self._h, s.ctypes.data, int(min_seed), int(max_seed)))
+
+    # ------------------------------------------------------------------ hot path
+    def reset(self, mask=None):
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, np.uint8)
+            if m.shape != (self.num_envs,):
+                raise ValueError("mask must have shape (num_envs,)")
+        check(lib().zenv_reset(self._h, None if m is None else m.ctypes.data))
+
+    def step(self, actions=None, auto_reset=True):
+        """actions: (N,2) float32 ndarray (host), or None to use the device action buffer."""
+        if actions is None:
+            check(lib().zenv_step(self._h, None, 0, int(bool(auto_reset))))
+            return
+        a = np.ascontiguousarray(actions, np.float32)
+        if a.shape != (self.num_envs, 2):
+            raise ValueError(f"actions must have shape ({self.num_envs}, 2)")
+        check(lib().zenv_step(self._h, a.ctypes.data, 0, int(bool(auto_reset))))
+
+    def step_device(self, actions_ptr, auto_reset=True):
+        """actions_ptr: integer device address of a float32 [N,2] buffer (zero-copy policies)."""
+        check(lib().zenv_step(self._h, C.c_void_p(int(actions_ptr)), 1, int(bool(auto_reset))))
+
+    def policy(self, policy, policy_seed=0x5EED, env_index0=0, dst_ptr=None):
+        check(lib().zenv_policy(self._h, int(policy), int(policy_seed), int(env_index0),
+                                None if dst_ptr is None else C.c_void_p(int(dst_ptr))))
+
+    def rollout(self, steps, policy, policy_seed=0x5EED, env_index0=0, auto_reset=True,
+                time_step_kernel=False):
+        """K closed-loop {policy; step} iterations on the handle's stream.
+
+        Returns (ms_total, ms_step_kernel or None), both from HIP events on that stream."""
+        total = C.c_float(0)
+        kern = C.c_float(0)
+        check(lib().zenv_rollout(self._h, int(steps), int(policy), int(policy_seed),
+                                 int(env_index0), int(bool(auto_reset)), C.byref(total),
+                                 C.byref(kern) if time_step_kernel else None))
+        return total.value, (kern.value if time_step_kernel else None)
+
+    def sync(self):
+        check(lib().zenv_sync(self._h))
+
+    @property
+    def step_count(self):
+        return lib().zenv_step_count(self._h)
+
+    # ------------------------------------------------------------------ results
+    def _shape(self, field):
+        N = self.num_envs
+        if field == nat.F_OBS:
+            return (N, nat.OBS_DIM)
+        if field == nat.F_ZONE_OBS:
+            return (N, self.num_zones, self.zone_feat)
+        if field == nat.F_ACTIONS:
+            return (N, 2)
+        return (N,)
+
+    def get(self, field, out=None):
+        if out is None:
+            out = np.empty(self._shape(field), _FIELD_DTYPES[field])
+        assert out.nbytes == lib().zenv_field_bytes(self._h, field)
+        check(lib().zenv_get(self._h, field, out.ctypes.data, 0))
+        return out
+
+    def get_into_device(self, field, dst_ptr):
+        check(lib().zenv_get(self._h, field, C.c_void_p(int(dst_ptr)), 1))
+
+    def device_ptr(self, field):
+        p = C.c_void_p()
+        check(lib().zenv_device_ptr(self._h, field, C.byref(p)))
+        return p.value
+
+    def field_bytes(self, field):
+        return lib().zenv_field_bytes(self._h, field)
+
+    def observations(self):
+        return self.get(nat.F_OBS), self.get(nat.F_ZONE_OBS)
+
+    def results(self):
+        """(obs, zone_obs, reward, done, goal_met) of the last step, as host arrays."""
+        return (self.get(nat.F_OBS), self.get(nat.F_ZONE_OBS), self.get(nat.F_REWARD),
+                self.get(nat.F_DONE).astype(bool), self.get(nat.F_GOAL_MET).astype(bool))
+
+    # ------------------------------------------------------------------ snapshots / debug
+    def get_state(self):
+        n = lib().zenv_state_bytes(self._h)
+        buf = np.empty(n, np.uint8)
+        check(lib().zenv_get_state(self._h, buf.ctypes.data, n))
+        return buf
+
+    def set_state(self, blob):
+        b = np.ascontiguousarray(blob, np.uint8)
+        check(lib().zenv_set_state(self._h, b.ctypes.data, b.nbytes))
+
+    def debug_state(self):
+        N, Z = self.num_envs, self.num_zones
+        out = dict(qpos=np.empty((N, 3)), qvel=np.empty((N, 3)),
+                   zone_state=np.empty((N, Z), np.int32), cooldown=np.empty((N, Z), np.int32),
+                   steps=np.empty(N, np.int32))
+        check(lib().zenv_debug_state(self._h, out["qpos"].ctypes.data, out["qvel"].ctypes.data,
+                                     out["zone_state"].ctypes.data, out["cooldown"].ctypes.data,
+                                     out["steps"].ctypes.data))
+        return out
+
+
+__all__ = ["ZoneVecEnv", "Config", "ZenvError", "config_for_id", "default_config",
+           "sample_layout", "fixed_seed_sequence", "zone_feat"]

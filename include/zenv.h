@@ -1,0 +1,177 @@
+/*
+ * zenv.h -- C ABI of the MI355X-native batched zone-env step path.
+ *
+ * Drop-in boundary for the env.step()/reset() hot path of
+ * andrewli77/combinatorial-rl-tasks (paths below are relative to the reference root):
+ *   main/envs/TSP_env.py, main/envs/TTSP_env.py, main/envs/colour_match_env.py,
+ *   main/envs/zone_envs/ZoneEnvBase.py, main/envs/wrappers.py (FixedSeedsWrapper,
+ *   ZoneWrapper), main/src/torch_ac/torch_utils/penv.py (ParallelEnv) and, beneath them,
+ *   safety_gym Engine.step/reset + MuJoCo mj_step for xmls/point.xml (not vendored).
+ *
+ * Conventions: every entry point is extern "C", takes plain pointers and sizes, returns
+ * 0 on success or a negative ZENV_E_* code (text from zenv_last_error()); no exception
+ * crosses the boundary.  The caller owns every buffer it passes; the library owns the
+ * handle and its device memory until zenv_destroy().  A handle is bound to one device and
+ * one HIP stream and is not thread-safe.  zenv_step()/zenv_reset()/zenv_policy() are
+ * asynchronous on the handle's stream; zenv_get() and zenv_sync() synchronise.
+ *
+ * There is no CPU fallback: every compute entry point fails with ZENV_E_HIP when no
+ * gfx950 device is usable.
+ */
+#ifndef ZENV_H
+#define ZENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZENV_MAX_ZONES 32
+#define ZENV_OBS_DIM 8
+
+/* tasks: envs/__init__.py:88-141 registry ids PointTSP-v0/v1, PointTTSP-v0/v1, ColourMatch-v0 */
+enum { ZENV_TASK_TSP = 0, ZENV_TASK_TIMED_TSP = 1, ZENV_TASK_COLOUR_MATCH = 2 };
+
+/* error codes */
+enum {
+    ZENV_OK = 0,
+    ZENV_E_ARG = -1,        /* bad argument */
+    ZENV_E_HIP = -2,        /* HIP runtime / no device */
+    ZENV_E_STATE = -3,      /* call order (e.g. step before bank/reset) */
+    ZENV_E_LAYOUT = -4,     /* ResamplingError: no layout in 10000 tries */
+    ZENV_E_DONE = -5        /* single-env semantics: 'Environment must be reset before stepping' */
+};
+
+/* zenv_get()/zenv_device_ptr() selectors */
+enum {
+    ZENV_F_OBS = 0,         /* float32 [N,8]   wrappers.py:136-142 'obs' = remaining,pos,dir,velp,velr */
+    ZENV_F_ZONE_OBS = 1,    /* float32 [N,Z,F] wrappers.py:137 'zone_obs' */
+    ZENV_F_REWARD = 2,      /* float32 [N] */
+    ZENV_F_DONE = 3,        /* uint8   [N]     done flag returned by the last step */
+    ZENV_F_GOAL_MET = 4,    /* uint8   [N]     info['goal_met'] (evaluate.py:65) */
+    ZENV_F_EP_RETURN = 5,   /* float64 [N]     undiscounted return of the running episode */
+    ZENV_F_EP_LEN = 6,      /* int32   [N]     steps of the running episode */
+    ZENV_F_LAST_RETURN = 7, /* float64 [N]     return of the last finished episode (evaluate.py:62-72) */
+    ZENV_F_LAST_LEN = 8,    /* int32   [N] */
+    ZENV_F_EPISODES = 9,    /* int32   [N]     episodes finished so far */
+    ZENV_F_VISIT_COUNT = 10,/* int32   [N]     visited zones (TSP/Timed) or goal_dist (ColourMatch) */
+    ZENV_F_SEED = 11,       /* int64   [N]     env seed of the running episode */
+    ZENV_F_ACTIONS = 12,    /* float32 [N,2]   internal action buffer (zenv_policy target) */
+    ZENV_F_COUNT = 13
+};
+
+/* scripted on-device action sources (the build's own; used by bench/tests) */
+enum { ZENV_POLICY_UNIFORM = 0, ZENV_POLICY_GREEDY = 1 };
+
+/* kernel layouts */
+enum {
+    ZENV_KERNEL_LANE_PER_ENV = 0,  /* SoA state, one lane per env, LDS-transposed obs tile */
+    ZENV_KERNEL_WAVE_PER_ENV = 1   /* one wave64 per env, lane z owns zone z (north-star layout) */
+};
+
+/* Replaces the config dicts of envs/__init__.py:7-50 merged into Engine.DEFAULT
+ * (ZoneEnvBase.py:42-53) and the model constants of xmls/point.xml. */
+typedef struct zenv_config {
+    int32_t task;              /* ZENV_TASK_* */
+    int32_t num_zones;         /* 'num_cities' */
+    int32_t num_steps;         /* 'num_steps' */
+    int32_t max_cd;            /* colour_match_env.py:16 */
+    int32_t frameskip;         /* Engine frameskip_binom_n (p = 1.0) */
+    int32_t kernel;            /* ZENV_KERNEL_* */
+    double zones_size;         /* ZoneEnvBase.py:51 */
+    double zones_keepout;      /* ZoneEnvBase.py:50 */
+    double robot_keepout;
+    double extent;             /* ZoneEnvBase.py:41 */
+    double placements_margin;
+    double time_saved_reward;  /* TSP_env.py:15 */
+    double beta_a, beta_b;     /* TTSP_env.py:13 */
+    double timestep;           /* point.xml <option timestep> */
+    double mass, com_x, inertia_zz;
+    double damping[3];
+    double gear, forcerange, vel_kv;
+} zenv_config;
+
+typedef struct zenv zenv_t;
+
+/* ---- configuration / introspection (host only; usable without a GPU) ---- */
+const char *zenv_last_error(void);
+const char *zenv_version(void);
+/* env_id: "PointTSP-v0", "PointTSP-v1", "PointTTSP-v0", "PointTTSP-v1", "ColourMatch-v0"
+ * (envs/__init__.py:88-141); unknown id -> ZENV_E_ARG (make_env.py:18 RuntimeError). */
+int zenv_config_for_id(const char *env_id, zenv_config *out);
+int zenv_default_config(int task, int num_zones, zenv_config *out);
+int zenv_zone_feat(const zenv_config *cfg);   /* F: 6 (TSP) or 7 */
+
+/* Host layout sampler = Engine.reset()'s random half for env.seed(seed); reset():
+ * aux from RandomState(seed) (TTSP_env.py:19-21 tmax / colour_match_env.py:57-68 colours),
+ * layout + robot_rot from RandomState(seed+1).  robot_xyrot[3], zone_xy[Z*2], aux[Z]. */
+int zenv_sample_layout(const zenv_config *cfg, int64_t seed, double *robot_xyrot,
+                       double *zone_xy, int32_t *aux, int32_t *restarts);
+/* FixedSeedsWrapper.reset (wrappers.py:20-23): the seed sequence drawn by
+ * np.random.default_rng(rng_seed).integers(min_seed, max_seed+1) -- PCG64 + SeedSequence. */
+int zenv_fixed_seed_sequence(uint64_t rng_seed, int64_t min_seed, int64_t max_seed,
+                             int count, int64_t *out);
+
+/* ---- lifecycle ---- */
+int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t **out);
+int zenv_destroy(zenv_t *h);
+int zenv_num_envs(const zenv_t *h);
+int zenv_get_config(const zenv_t *h, zenv_config *out);
+
+/* ---- layout bank (pre-sampled episodes in HBM) ---- */
+/* Sample layouts for env seeds seed_first .. seed_first+count-1 on n_threads host threads
+ * and upload them.  Replaces the per-episode XML rebuild of Engine.reset(). */
+int zenv_bank_build(zenv_t *h, int64_t seed_first, int count, int n_threads);
+/* Upload caller-provided layouts: robot_xyrot [S,3], zone_xy [S,Z,2], aux [S,Z] (may be NULL
+ * for TSP), seeds [S]. */
+int zenv_bank_set(zenv_t *h, const double *robot_xyrot, const double *zone_xy,
+                  const int32_t *aux, const int64_t *seeds, int count);
+int zenv_bank_size(const zenv_t *h);
+
+/* ---- episode schedule: which bank slot env i uses for its k-th episode ---- */
+/* slot = (first[i] + k*stride) mod S; first == NULL -> i mod S. */
+int zenv_schedule_sequential(zenv_t *h, const int32_t *first, int32_t stride);
+/* FixedSeedsWrapper semantics on device: env i draws seeds from its own PCG64 stream
+ * default_rng(rng_seeds[i]).integers(min_seed, max_seed+1); the bank must hold
+ * min_seed..max_seed in order (make_env.py:3-18,37-51). */
+int zenv_schedule_fixed_seeds(zenv_t *h, const uint64_t *rng_seeds, int64_t min_seed,
+                              int64_t max_seed);
+
+/* ---- the hot path ---- */
+/* ParallelEnv.reset (penv.py:46-50) / masked re-reset: mask uint8[N] host, NULL = all. */
+int zenv_reset(zenv_t *h, const uint8_t *mask);
+/* ParallelEnv.step / step_no_reset (penv.py:52-66): actions float32 [N,2]
+ * (NULL = internal action buffer written by zenv_policy); auto_reset != 0 resets finished
+ * envs in the same launch and returns the new episode's first observation with the terminal
+ * reward/done/goal_met (penv.py:8-11).  With auto_reset == 0 a finished env is a masked
+ * no-op: zero obs, reward 0, done 1 (WaitWrapper, wrappers.py:34-45). */
+int zenv_step(zenv_t *h, const float *actions, int actions_on_device, int auto_reset);
+/* Scripted action source -> internal action buffer (or dst_device if non-NULL). */
+int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0,
+                float *dst_device);
+/* K closed-loop steps {policy; step} on the handle's stream, HIP-event timed.
+ * ms_total: whole loop; ms_step_kernel: sum over the K step-kernel launches only. */
+int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
+                 int auto_reset, float *ms_total, float *ms_step_kernel);
+
+/* ---- results ---- */
+int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device);
+int zenv_device_ptr(zenv_t *h, int field, void **ptr);  /* zero-copy for GPU consumers */
+int64_t zenv_field_bytes(const zenv_t *h, int field);
+int zenv_sync(zenv_t *h);
+int64_t zenv_step_count(const zenv_t *h);   /* batched steps executed so far */
+
+/* ---- state snapshot (tests / checkpointing; the reference never checkpoints env state) ---- */
+int64_t zenv_state_bytes(const zenv_t *h);
+int zenv_get_state(zenv_t *h, void *dst, int64_t bytes);
+int zenv_set_state(zenv_t *h, const void *src, int64_t bytes);
+/* Per-env dynamic state for parity tests: qpos[N,3], qvel[N,3] float64; zone_state int32 [N,Z]
+ * (visited 0/1, or colour 0..2); cooldown int32 [N,Z]; steps int32 [N]. Any may be NULL. */
+int zenv_debug_state(zenv_t *h, double *qpos, double *qvel, int32_t *zone_state,
+                     int32_t *cooldown, int32_t *steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZENV_H */

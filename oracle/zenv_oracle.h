@@ -1,0 +1,126 @@
+/*
+ * zenv_oracle.h -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * Plain-C float64 restatement of the PointTSP / TimedTSP / ColourMatch
+ * env.step()/reset() path of andrewli77/combinatorial-rl-tasks
+ * (main/envs/{TSP,TTSP,colour_match}_env.py, zone_envs/ZoneEnvBase.py) and of
+ * the un-vendored Safety-Gym Engine + MuJoCo "point.xml" dynamics beneath it.
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors and its
+ * arithmetic lives in third-party packages (safety-gym, mujoco-py 2.0.2.9 /
+ * MuJoCo 2.0, gym) that are absent from /root/reference and from this image.
+ * Only the RNG/layout half is pinned (against numpy's legacy RandomState,
+ * which is the reference's actual dependency); the dynamics half is pinned
+ * by analytic known-answers only.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The shipped HIP path never links or calls it.
+ */
+#ifndef ZENV_ORACLE_H
+#define ZENV_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_Z 32
+
+enum { ORC_TASK_TSP = 0, ORC_TASK_TIMED = 1, ORC_TASK_COLOUR = 2 };
+enum { ORC_POLICY_UNIFORM = 0, ORC_POLICY_GREEDY = 1 };
+
+typedef struct orc_config {
+    int32_t task;              /* ORC_TASK_* */
+    int32_t num_zones;         /* num_cities, envs/__init__.py:9 */
+    int32_t num_steps;         /* envs/__init__.py:13 */
+    int32_t max_cd;            /* colour_match_env.py:16 */
+    int32_t frameskip;         /* Engine frameskip_binom_n (p = 1) */
+    int32_t pad0;
+    double zones_size;         /* ZoneEnvBase.py:51 */
+    double zones_keepout;      /* ZoneEnvBase.py:50 */
+    double robot_keepout;      /* Engine DEFAULT */
+    double extent;             /* ZoneEnvBase.py:41 */
+    double placements_margin;  /* Engine DEFAULT 0.0 */
+    double time_saved_reward;  /* TSP_env.py:15 */
+    double beta_a, beta_b;     /* TTSP_env.py:13 */
+    /* Point robot (safety_gym/xmls/point.xml, [UPSTREAM-RECALL]) */
+    double timestep;
+    double mass;               /* total body mass */
+    double com_x;              /* COM offset along body x */
+    double inertia_zz;         /* about the hinge axis (body origin) */
+    double damping[3];         /* slide x, slide y, hinge z */
+    double gear;               /* both actuators */
+    double forcerange;         /* |force| clamp of both actuators */
+    double vel_kv;             /* velocity actuator gain */
+} orc_config;
+
+typedef struct orc_env {
+    orc_config cfg;
+    /* episode-static */
+    int64_t seed;              /* value given to env.seed() */
+    double x0, y0, rot;        /* robot placement */
+    double bq0, bq3;           /* body quaternion (w, z) */
+    double zone_xy[ORC_MAX_Z][2];
+    int32_t tmax[ORC_MAX_Z];
+    /* dynamic */
+    double qpos[3], qvel[3];
+    double xpos[2];            /* world position as of the last forward */
+    double xvelp[2], xvelr;    /* world velocities as of the last forward */
+    double xquat0, xquat3;
+    int32_t visited[ORC_MAX_Z];   /* TSP/Timed */
+    int32_t colour[ORC_MAX_Z];    /* 0 Blue 1 Green 2 Red */
+    int32_t cooldown[ORC_MAX_Z];
+    int32_t goal_dist;
+    int32_t steps;
+    int32_t done;
+    int32_t layout_restarts;   /* diagnostics */
+} orc_env;
+
+/* ---- numpy-legacy RandomState restatement (exposed for pinning tests) ---- */
+typedef struct orc_rs {
+    uint32_t key[624];
+    int pos;
+    int has_gauss;
+    double gauss;
+} orc_rs;
+void orc_rs_seed(orc_rs *rs, uint32_t seed);
+uint32_t orc_rs_u32(orc_rs *rs);
+double orc_rs_double(orc_rs *rs);
+double orc_rs_uniform(orc_rs *rs, double lo, double hi);
+int64_t orc_rs_choice(orc_rs *rs, int64_t n);
+double orc_rs_beta(orc_rs *rs, double a, double b);
+
+/* deterministic sin/cos used by the dynamics (exposed for tests) */
+void orc_sincos(double x, double *s, double *c);
+
+/* ---- configuration ---- */
+void orc_default_config(int task, int num_zones, orc_config *out);
+
+/* ---- single env ---- */
+int orc_reset(orc_env *e, const orc_config *cfg, int64_t seed);
+/* step: returns 0, or -1 when the env is done (must be reset first). */
+int orc_step(orc_env *e, const float action[2], double *reward, int *done, int *goal_met);
+/* obs: obs8[8], zone_obs[Z*F] as float32 (the dtype the consumer casts to, format.py:27-28) */
+void orc_obs(const orc_env *e, float *obs8, float *zone_obs);
+int orc_zone_feat(const orc_config *cfg);
+
+/* ---- scripted policies (deterministic; same definition as the device K3 kernels) ---- */
+void orc_policy(int policy, const orc_config *cfg, const float *obs8, const float *zone_obs,
+                uint64_t env_index, uint32_t step_index, uint64_t policy_seed, float action[2]);
+
+/* ---- batch driver (cpu_baseline / parity traces) ----
+ * Runs n_env envs for n_steps closed-loop steps with auto-reset; env i starts on
+ * seed seeds0[i]; episode k of env i uses seed seeds0[i] + k*seed_stride.
+ * Outputs (any may be NULL): per-env sum of rewards, episodes finished, last
+ * finished episode return/len, final obs. Returns total env-steps executed. */
+int64_t orc_rollout(const orc_config *cfg, int n_env, int n_steps, int policy,
+                    const int64_t *seeds0, int64_t seed_stride, uint64_t policy_seed,
+                    uint64_t env_index0, int n_threads,
+                    double *reward_sum, int32_t *episodes, double *last_return,
+                    int32_t *last_len, float *final_obs8, float *final_zone_obs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,192 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): visit counts / termination step indices bit-identical,
+rewards within 1e-5.  What is asserted here is stricter: float32 observations, rewards,
+done/goal flags and the float64 joint state are all bit-identical to the oracle.
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import TASK_IDS, OracleBatch, oracle_config_from
+
+pytestmark = pytest.mark.gpu
+
+EVAL_SEED0 = 1000000   # main/scripts/evaluate.py:47
+
+
+def _make(Z, env_id, n, seed0, **overrides):
+    cfg = Z.config_for_id(env_id, **overrides)
+    env = Z.ZoneVecEnv(cfg, n, device=0)
+    env.build_bank(seed0, n)
+    env.schedule_sequential()      # env i replays bank slot i (evaluate.py: 5 runs per map)
+    return cfg, env
+
+
+@pytest.mark.parametrize("task", [0, 1, 2])
+def test_lockstep_eval_seeds(zenv_mod, oracle_mod, task):
+    """100 eval seeds, greedy actions computed by the oracle, stepped in lock step."""
+    Z, O = zenv_mod, oracle_mod
+    n = 100
+    T = 2100 if task == 0 else 700
+    cfg, env = _make(Z, TASK_IDS[task], n, EVAL_SEED0)
+    ob = OracleBatch(O, oracle_config_from(O, cfg), range(EVAL_SEED0, EVAL_SEED0 + n))
+    env.reset()
+    o_ref, zo_ref = ob.reset()
+    o, zo = env.observations()
+    assert np.array_equal(o, o_ref)
+    assert np.array_equal(zo, zo_ref)
+    n_done = n_goal = 0
+    for t in range(T):
+        a = ob.policy(O.POLICY_GREEDY, o_ref, zo_ref, t)
+        env.step(a, auto_reset=True)
+        r_ref, d_ref, g_ref = ob.step(a)
+        o_ref, zo_ref = ob.obs()
+        o, zo, r, d, g = env.results()
+        assert np.array_equal(d, d_ref), f"done mismatch at step {t}"
+        assert np.array_equal(g, g_ref), f"goal_met mismatch at step {t}"
+        assert np.array_equal(r, r_ref.astype(np.float32)), f"reward mismatch at step {t}"
+        assert np.max(np.abs(r.astype(np.float64) - r_ref)) <= 1e-5
+        assert np.array_equal(o, o_ref), f"obs mismatch at step {t}"
+        assert np.array_equal(zo, zo_ref), f"zone_obs mismatch at step {t}"
+        n_done += int(d.sum())
+        n_goal += int(g.sum())
+        if t % 97 == 0:
+            st = env.debug_state()
+            q, v, steps = ob.state()
+            assert np.array_equal(st["qpos"], q) and np.array_equal(st["qvel"], v)
+            assert np.array_equal(st["steps"], steps)
+    assert n_done > 0, "the scripted policy never finished an episode: test is too weak"
+    env.close()
+
+
+@pytest.mark.parametrize("task", [0, 1, 2])
+def test_policy_kernels_match_oracle(zenv_mod, oracle_mod, task):
+    Z, O = zenv_mod, oracle_mod
+    n = 257   # ragged: not a multiple of the 64-env tile
+    cfg, env = _make(Z, TASK_IDS[task], n, 5000)
+    ob = OracleBatch(O, oracle_config_from(O, cfg), range(5000, 5000 + n))
+    env.reset()
+    o_ref, zo_ref = ob.reset()
+    for t in range(120):
+        pol = O.POLICY_GREEDY if t % 3 else O.POLICY_UNIFORM
+        env.policy(pol, policy_seed=0x5EED, env_index0=7)
+        a_dev = env.get(Z.F_ACTIONS)
+        a_ref = ob.policy(pol, o_ref, zo_ref, t, env_index0=7)
+        assert np.array_equal(a_dev, a_ref), f"policy {pol} mismatch at step {t}"
+        env.step(None, auto_reset=True)
+        ob.step(a_ref)
+        o_ref, zo_ref = ob.obs()
+        o, zo = env.observations()
+        assert np.array_equal(o, o_ref) and np.array_equal(zo, zo_ref)
+    env.close()
+
+
+@pytest.mark.parametrize("task,zones,keepout", [(0, 25, 0.40), (1, 25, 0.40), (2, 6, 0.55), (0, 5, 0.55)])
+def test_closed_loop_rollout_matches_oracle(zenv_mod, oracle_mod, task, zones, keepout):
+    """Device-resident closed loop (policy kernel + step kernel, auto-reset onto fresh seeds)
+    against the oracle's batch driver: BASELINE.json configs 1-3 at reduced N."""
+    Z, O = zenv_mod, oracle_mod
+    n, T, stride = 1000, 400, 1000
+    cfg = Z.default_config(task, zones, zones_keepout=keepout)
+    if task != 2:
+        cfg.num_steps = 400           # force time-limit resets inside the window
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(1, 16 * stride)
+    env.schedule_sequential(stride=stride)
+    env.reset()
+    env.rollout(T, Z.POLICY_GREEDY, policy_seed=11, env_index0=0, auto_reset=True)
+    ocfg = oracle_config_from(O, cfg)
+    ref = O.rollout(ocfg, np.arange(1, 1 + n), T, O.POLICY_GREEDY, seed_stride=stride,
+                    policy_seed=11, n_threads=8)
+    assert np.array_equal(env.get(Z.F_EPISODES), ref["episodes"])
+    assert np.array_equal(env.get(Z.F_LAST_LEN), ref["last_len"])
+    assert np.array_equal(env.get(Z.F_LAST_RETURN), ref["last_return"])
+    assert np.array_equal(env.get(Z.F_OBS), ref["obs"])
+    assert np.array_equal(env.get(Z.F_ZONE_OBS), ref["zone_obs"])
+    assert ref["episodes"].max() < 16 and ref["episodes"].sum() > 0
+    env.close()
+
+
+def test_uniform_policy_rollout(zenv_mod, oracle_mod):
+    Z, O = zenv_mod, oracle_mod
+    n, T = 300, 250
+    cfg = Z.config_for_id("PointTSP-v0")
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(EVAL_SEED0, n)
+    env.schedule_sequential()
+    env.reset()
+    env.rollout(T, Z.POLICY_UNIFORM, policy_seed=0x5EED, env_index0=123, auto_reset=True)
+    ref = O.rollout(oracle_config_from(O, cfg), np.arange(EVAL_SEED0, EVAL_SEED0 + n), T,
+                    O.POLICY_UNIFORM, policy_seed=0x5EED, env_index0=123, n_threads=8)
+    assert np.array_equal(env.get(Z.F_OBS), ref["obs"])
+    assert np.array_equal(env.get(Z.F_ZONE_OBS), ref["zone_obs"])
+    assert np.array_equal(env.get(Z.F_EP_RETURN), ref["reward_sum"])
+    env.close()
+
+
+def test_no_auto_reset_masks_finished_envs(zenv_mod, oracle_mod):
+    """step_no_reset (penv.py:61-66) + WaitWrapper semantics (wrappers.py:34-45)."""
+    Z, O = zenv_mod, oracle_mod
+    n = 64
+    cfg = Z.config_for_id("PointTSP-v1", num_steps=30)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(1, n)
+    env.reset()
+    a = np.zeros((n, 2), np.float32)
+    for t in range(29):
+        env.step(a, auto_reset=False)
+        assert not env.get(Z.F_DONE).any()
+    env.step(a, auto_reset=False)
+    assert env.get(Z.F_DONE).all()
+    assert np.array_equal(env.get(Z.F_LAST_LEN), np.full(n, 30))
+    env.step(a, auto_reset=False)       # finished: zero obs, zero reward, done stays set
+    o, zo, r, d, g = env.results()
+    assert d.all() and not g.any() and not r.any() and not o.any() and not zo.any()
+    mask = np.zeros(n, np.uint8)
+    mask[::2] = 1
+    env.reset(mask)
+    env.step(a, auto_reset=False)
+    d = env.get(Z.F_DONE).astype(bool)
+    assert not d[::2].any() and d[1::2].all()
+    env.close()
+
+
+def test_state_snapshot_roundtrip(zenv_mod):
+    Z = zenv_mod
+    cfg = Z.config_for_id("ColourMatch-v0")
+    env = Z.ZoneVecEnv(cfg, 130)
+    env.build_bank(1, 130)
+    env.reset()
+    env.rollout(40, Z.POLICY_GREEDY)
+    blob = env.get_state()
+    env.rollout(25, Z.POLICY_GREEDY)
+    want = env.observations()
+    env.set_state(blob)
+    env.rollout(25, Z.POLICY_GREEDY)
+    got = env.observations()
+    assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
+    env.close()
+
+
+def test_fixed_seeds_schedule_on_device(zenv_mod):
+    """FixedSeedsWrapper (wrappers.py:10-23) seed draws done by the device PCG64."""
+    Z = zenv_mod
+    n, lo, hi = 96, 1, 100
+    cfg = Z.config_for_id("PointTSP-v1", num_steps=5)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(lo, hi - lo + 1)
+    rng_seeds = np.arange(n, dtype=np.uint64) * 10000      # train_ppo.py:112 rng_seed=seed+10000*i
+    env.schedule_fixed_seeds(rng_seeds, lo, hi)
+    env.reset()
+    a = np.zeros((n, 2), np.float32)
+    seen = [env.get(Z.F_SEED).copy()]
+    for ep in range(4):
+        for _ in range(5):
+            env.step(a, auto_reset=True)
+        seen.append(env.get(Z.F_SEED).copy())
+    seen = np.stack(seen, 1)
+    for i in range(n):
+        g = np.random.default_rng(int(rng_seeds[i]))
+        want = [int(g.integers(low=lo, high=hi + 1, size=1)[0]) for _ in range(5)]
+        assert seen[i].tolist() == want
+    env.close()
