@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched PointTSP-25 env.step() hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: the scripted on-device policy kernel
+writes (N_env, 2) actions, then ONE `zenv_step` launch advances all N_env = 65 536 envs
+(10 MuJoCo substeps, visit logic, reward/termination, fused auto-reset, obs emit).  All
+inputs (env state, layout bank) are resident in HBM before the timed region.
+
+N > 1: one process per GPU (torch.distributed, backend "nccl" == RCCL).  Envs shard
+trivially: rank r owns global envs [r*65536, (r+1)*65536); there is no collective on the
+step path; after the rollout the per-env episodic returns are all-gathered over xGMI.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
+dominant kernel (k_step_lane) and `cpu_baseline` (the float64 C oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# torch first: its bundled libamdhip64 must be the only HIP runtime in the process
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (task, zones, zones_keepout)  -- SURVEY.md 8(d) configs 1-3
+    "PointTSP-25": (0, 25, 0.40),
+    "TimedTSP-25": (1, 25, 0.40),
+    "ColourMatch-6": (2, 6, 0.55),
+    "PointTSP-15": (0, 15, 0.55),
+}
+
+
+def algorithmic_bytes(task, Z):
+    """HBM bytes one env-step must move: 1247 B for PointTSP-25."""
+    F = 6 if task == 0 else 7
+    reads = 8 + 48 + 24 + 16 * Z + Z + 16
+    writes = 48 + Z + 16 + 4 + 1 + 32 + 4 * Z * F
+    if task == 1:
+        reads += 4 * Z
+    if task == 2:
+        reads += Z
+        writes += Z
+    return reads + writes
+
+
+def load_traffic(workload, n_env):
+    """Measured HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        ent = t.get(f"{workload}@{n_env}")
+        return None if ent is None else ent["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--workload", default="PointTSP-25", choices=sorted(WORKLOADS))
+    ap.add_argument("--policy", default="greedy", choices=["greedy", "uniform"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="skip the per-launch HIP events around the step kernel")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    import combinatorial_rl_tasks_amd as Z
+    from combinatorial_rl_tasks_amd import sharding
+
+    task, zones, keepout = WORKLOADS[args.workload]
+    n_env = args.envs_per_gpu
+    cfg = Z.default_config(task, zones, zones_keepout=keepout)
+    policy = Z.POLICY_GREEDY if args.policy == "greedy" else Z.POLICY_UNIFORM
+    shard = sharding.EnvShard(rank=rank, world=world, envs_per_rank=n_env)
+
+    # env g (global index) plays map seeds 1+g, 1+g+G, 1+g+2G, ... (G = global env count)
+    env = Z.ZoneVecEnv(cfg, n_env, device=local_rank)
+    episodes_per_env = 4
+    t_bank = time.perf_counter()
+    shard.build_bank(env, episodes_per_env, n_threads=min(32, usable_cores()))
+    t_bank = time.perf_counter() - t_bank
+    env.reset()
+    env.rollout(args.warmup, policy, policy_seed=0x5EED, env_index0=shard.env_index0)
+
+    def fence():
+        env.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    ms_total, ms_kernel = env.rollout(args.steps, policy, policy_seed=0x5EED,
+                                      env_index0=shard.env_index0, auto_reset=True,
+                                      time_step_kernel=not args.no_kernel_events)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # rank-local results, then the one collective of the job: all-gather of episodic returns
+    returns = shard.gather_returns(env)          # float32 [world * n_env] on every rank
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        total_env_steps = world * n_env * args.steps
+        value = total_env_steps / elapsed
+        alg = algorithmic_bytes(task, zones)
+        roofline = None
+        if ms_kernel is not None and args.steps > 0:
+            k_avg_s = ms_kernel / 1e3 / args.steps
+            achieved = alg * n_env / k_avg_s / 1e9
+            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": load_traffic(args.workload, n_env),
+                        "kernel": "k_step_lane", "kernel_avg_us": round(k_avg_s * 1e6, 2),
+                        "algorithmic_bytes_per_env_step": alg, "env_steps_per_launch": n_env}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, task, zones, keepout, policy)
+        ep = env.get(Z.F_EPISODES)
+        out = {
+            "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}, N_env={n_env} per GPU, num_steps=2000, "
+                                   f"zones_keepout={keepout}, policy=pi_{args.policy} (on-device), "
+                                   "auto-reset on",
+                       "n_env_total": world * n_env, "zones": zones,
+                       "parallelism": f"env-shard x{world}, all-gather(ep_return) after rollout"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "aux": {"hip_event_ms_total": round(ms_total, 3), "bank_build_s": round(t_bank, 2),
+                    "episodes_finished_rank0": int(ep.sum()),
+                    "mean_last_return_all_ranks": float(np.mean(returns[returns != 0]))
+                    if (returns != 0).any() else 0.0,
+                    "parity_spot_check": parity_spot_check(env, cfg, shard, args, policy)},
+        }
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def usable_cores():
+    """Host threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("ZENV_CPU_THREADS", "64"))))
+
+
+def cpu_baseline(cfg, task, zones, keepout, policy):
+    """The float64 C oracle (the build's own port; the mujoco-py reference cannot run here)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from tests.helpers import oracle_config_from
+    ocfg = oracle_config_from(O, cfg)
+    cores = usable_cores()
+    n, T = 16384, 500
+    seeds = np.arange(1, 1 + n)
+    O.rollout(ocfg, seeds[:256], 20, policy, n_threads=cores)      # warm the pages/threads
+    t0 = time.perf_counter()
+    r = O.rollout(ocfg, seeds, T, policy, seed_stride=65536, policy_seed=0x5EED, n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(r["total_steps"] / dt, 1), "unit": "env-steps/s", "cores": cores,
+            "kind": "port",
+            "sample": f"first {n} envs x {T} steps of the same workload, OpenMP over envs, "
+                      f"{dt:.2f}s wall"}
+
+
+def parity_spot_check(env, cfg, shard, args, policy):
+    """First 16 envs of rank 0 vs the oracle over the whole warmup+timed rollout."""
+    try:
+        import combinatorial_rl_tasks_amd as Z
+        from oracle import oracle as O
+        from tests.helpers import oracle_config_from
+        n = 16
+        T = args.warmup + args.steps
+        ref = O.rollout(oracle_config_from(O, cfg), shard.first_seeds()[:n], T, policy,
+                        seed_stride=shard.seed_stride, policy_seed=0x5EED,
+                        env_index0=shard.env_index0, n_threads=4)
+        if ref["episodes"].max() >= 4:
+            return "skipped (bank wrapped)"
+        ok = (np.array_equal(env.get(Z.F_OBS)[:n], ref["obs"])
+              and np.array_equal(env.get(Z.F_ZONE_OBS)[:n], ref["zone_obs"])
+              and np.array_equal(env.get(Z.F_EPISODES)[:n], ref["episodes"]))
+        return "bit-identical" if ok else "MISMATCH"
+    except Exception as ex:  # the bench line must still print
+        return f"error: {ex}"
+
+
+if __name__ == "__main__":
+    main()

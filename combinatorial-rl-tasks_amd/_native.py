@@ -65,6 +65,7 @@ _PROTOTYPES = {
     "zenv_num_envs": (C.c_int, [_H]),
     "zenv_get_config": (C.c_int, [_H, C.POINTER(Config)]),
     "zenv_bank_build": (C.c_int, [_H, C.c_int64, C.c_int, C.c_int]),
+    "zenv_bank_build_seeds": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
     "zenv_bank_set": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "zenv_bank_size": (C.c_int, [_H]),
     "zenv_schedule_sequential": (C.c_int, [_H, C.c_void_p, C.c_int32]),

@@ -382,23 +382,24 @@ static int upload_bank(zenv *h, const std::vector<double> &robot4, const std::ve
     return ZENV_OK;
 }
 
-extern "C" int zenv_bank_build(zenv_t *h, int64_t seed_first, int count, int n_threads)
+extern "C" int zenv_bank_build_seeds(zenv_t *h, const int64_t *seed_list, int count, int n_threads)
 {
-    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (!h || !seed_list) return fail(ZENV_E_ARG, "null argument");
     if (count < 1) return fail(ZENV_E_ARG, "count must be >= 1");
-    if (seed_first < 0 || seed_first + count > 0xFFFFFFFFll)
-        return fail(ZENV_E_ARG, "Seed must be between 0 and 2**32 - 1");
     const int Z = h->cfg.num_zones;
     const size_t S = count;
+    for (size_t i = 0; i < S; ++i)
+        if (seed_list[i] < 0 || seed_list[i] + 1 > 0xFFFFFFFFll)
+            return fail(ZENV_E_ARG, "Seed must be between 0 and 2**32 - 1");
     std::vector<double> robot4(S * 4), zone(S * Z * 2);
     std::vector<int32_t> aux(S * Z);
-    std::vector<int64_t> seeds(S);
+    std::vector<int64_t> seeds(seed_list, seed_list + S);
     std::vector<int> status(S, 0);
     n_threads = std::max(1, std::min(n_threads, 256));
     auto work = [&](int tid) {
         for (size_t i = tid; i < S; i += n_threads) {
             Layout L;
-            status[i] = sample_layout(h->cfg, seed_first + (int64_t)i, L);
+            status[i] = sample_layout(h->cfg, seeds[i], L);
             double s, c;
             det_sincos(L.robot_rot / 2, s, c);   // world.py rot2quat: [cos(rot/2), 0, 0, sin(rot/2)]
             robot4[4 * i + 0] = L.robot_x;
@@ -410,7 +411,6 @@ extern "C" int zenv_bank_build(zenv_t *h, int64_t seed_first, int count, int n_t
                 zone[(i * Z + z) * 2 + 1] = L.zone_xy[z][1];
                 aux[i * Z + z] = L.aux[z];
             }
-            seeds[i] = seed_first + (int64_t)i;
         }
     };
     if (n_threads == 1) {
@@ -422,9 +422,17 @@ extern "C" int zenv_bank_build(zenv_t *h, int64_t seed_first, int count, int n_t
     }
     for (size_t i = 0; i < S; ++i)
         if (status[i])
-            return fail(ZENV_E_LAYOUT, "Failed to sample layout of objects (seed %lld)",
-                        (long long)(seed_first + (int64_t)i));
+            return fail(ZENV_E_LAYOUT, "Failed to sample layout of objects (seed %lld)", (long long)seeds[i]);
     return upload_bank(h, robot4, zone, aux, seeds);
+}
+
+extern "C" int zenv_bank_build(zenv_t *h, int64_t seed_first, int count, int n_threads)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (count < 1) return fail(ZENV_E_ARG, "count must be >= 1");
+    std::vector<int64_t> seeds(count);
+    for (int i = 0; i < count; ++i) seeds[i] = seed_first + i;
+    return zenv_bank_build_seeds(h, seeds.data(), count, n_threads);
 }
 
 extern "C" int zenv_bank_set(zenv_t *h, const double *robot_xyrot, const double *zone_xy, const int32_t *aux_in,

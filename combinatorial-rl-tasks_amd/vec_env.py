@@ -115,6 +115,10 @@ class ZoneVecEnv:
     def build_bank(self, seed_first, count, n_threads=8):
         check(lib().zenv_bank_build(self._h, int(seed_first), int(count), int(n_threads)))
 
+    def build_bank_seeds(self, seeds, n_threads=8):
+        s = np.ascontiguousarray(seeds, np.int64).reshape(-1)
+        check(lib().zenv_bank_build_seeds(self._h, s.ctypes.data, s.size, int(n_threads)))
+
     def set_bank(self, robot_xyrot, zone_xy, aux=None, seeds=None):
         robot = np.ascontiguousarray(robot_xyrot, np.float64).reshape(-1, 3)
         S = robot.shape[0]

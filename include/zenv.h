@@ -123,6 +123,8 @@ int zenv_get_config(const zenv_t *h, zenv_config *out);
 /* Sample layouts for env seeds seed_first .. seed_first+count-1 on n_threads host threads
  * and upload them.  Replaces the per-episode XML rebuild of Engine.reset(). */
 int zenv_bank_build(zenv_t *h, int64_t seed_first, int count, int n_threads);
+/* Same for an arbitrary list of env seeds (slot j <-> seeds[j]). */
+int zenv_bank_build_seeds(zenv_t *h, const int64_t *seeds, int count, int n_threads);
 /* Upload caller-provided layouts: robot_xyrot [S,3], zone_xy [S,Z,2], aux [S,Z] (may be NULL
  * for TSP), seeds [S]. */
 int zenv_bank_set(zenv_t *h, const double *robot_xyrot, const double *zone_xy,
