@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--workload", default="PointTSP-25", choices=sorted(WORKLOADS))
     ap.add_argument("--policy", default="greedy", choices=["greedy", "uniform"])
+    ap.add_argument("--override", action="append", default=[],
+                    help="experiment only: config key=value (e.g. frameskip=1); marks the run invalid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the per-launch HIP events around the step kernel")
@@ -102,6 +104,9 @@ def main():
     task, zones, keepout = WORKLOADS[args.workload]
     n_env = args.envs_per_gpu
     cfg = Z.default_config(task, zones, zones_keepout=keepout)
+    for kv in args.override:
+        key, val = kv.split("=")
+        setattr(cfg, key, type(getattr(cfg, key))(float(val)))
     policy = Z.POLICY_GREEDY if args.policy == "greedy" else Z.POLICY_UNIFORM
     shard = sharding.EnvShard(rank=rank, world=world, envs_per_rank=n_env)
 
@@ -162,7 +167,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}, N_env={n_env} per GPU, num_steps=2000, "
                                    f"zones_keepout={keepout}, policy=pi_{args.policy} (on-device), "
-                                   "auto-reset on",
+                                   "auto-reset on" + (f" EXPERIMENT {args.override}" if args.override else ""),
                        "n_env_total": world * n_env, "zones": zones,
                        "parallelism": f"env-shard x{world}, all-gather(ep_return) after rollout"},
             "roofline": roofline,

@@ -9,7 +9,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libzenv_hip.so")
 SOURCES = ["kernels.hip", "zenv_api.cpp", "host_sampler.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra", "-Wno-unused-parameter"]
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-pass-failed"]
 
 
 def _hipcc():

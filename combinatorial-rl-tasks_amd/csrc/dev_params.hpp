@@ -27,6 +27,9 @@ struct DevParams {
     double A22, inv00, inv11;
     double hit_d2;        // largest d2 with sqrt(d2) <= zones_size
     double tsr;           // time_saved_reward
+    double inv3, inv1_5;  // RN(1/3), RN(1/1.5)
+    double d_steps, inv_steps;   // (double)num_steps and RN(1/num_steps)
+    double d_maxcd, inv_maxcd;   // (double)max_cd and RN(1/max_cd)
     // state
     double *q0, *q1, *q2, *v0, *v1, *v2;
     double *x0, *y0, *bq0, *bq3;

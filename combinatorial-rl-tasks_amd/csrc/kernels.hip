@@ -14,6 +14,7 @@
 // No MFMA: there is no contraction anywhere on this path; the bound is HBM bytes.
 // Build with -ffp-contract=off: the float64 state must match the CPU oracle bit for bit.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "det_math.hpp"
 #include "dev_params.hpp"
@@ -94,6 +95,20 @@ __device__ int next_bank_slot(const DevParams &p, int env)
     return (int)(m >> 32);
 }
 
+
+// a / b for a divisor known on the host, b = 3, 1.5 or a positive integer < 2^31, with
+// inv_b = RN(1/b): q1 = RN(a*inv_b); r = a - b*q1 (exact in one fma); q = RN(q1 + r*inv_b).
+// The result equals the IEEE quotient RN(a/b) bit for bit (argument in DESIGN.md: r is exact
+// and the exact value of q1 + r*inv_b lies within 2^-53 ulp of a/b, which for these b is
+// never that close to a rounding boundary), at 3 instructions instead of the ~14 of v_div_*.
+__device__ __forceinline__ double div_const(double a, double b, double inv_b)
+{
+    const double q1 = a * inv_b;
+    const double r = __builtin_fma(-b, q1, a);
+    const double q = __builtin_fma(r, inv_b, q1);
+    return a == 0.0 ? a : q;   // keeps the sign of a zero numerator like a true division
+}
+
 // Per-lane registers of one env
 struct EnvRegs {
     double q0, q1, q2, v0, v1, v2;
@@ -138,15 +153,15 @@ __device__ __forceinline__ Pose forward_pose(const EnvRegs &e)
 __device__ __forceinline__ void emit_obs8(const DevParams &p, const EnvRegs &e, float *o)
 {
     const Pose f = forward_pose(e);
-    o[0] = (float)(1.0 - (double)e.steps / (double)p.num_steps);
-    o[1] = (float)(f.px / 3.0);
-    o[2] = (float)(f.py / 3.0);
+    o[0] = (float)(1.0 - div_const((double)e.steps, p.d_steps, p.inv_steps));
+    o[1] = (float)div_const(f.px, 3.0, p.inv3);
+    o[2] = (float)div_const(f.py, 3.0, p.inv3);
     const double a0 = (double)(float)f.xq0, a3 = (double)(float)f.xq3;
     o[3] = (float)(a0 * a0 - a3 * a3);
     o[4] = (float)((2.0 * a0) * a3);
-    o[5] = (float)(f.vx / 1.5);
-    o[6] = (float)(f.vy / 1.5);
-    o[7] = (float)(f.w / 3.0);
+    o[5] = (float)div_const(f.vx, 1.5, p.inv1_5);
+    o[6] = (float)div_const(f.vy, 1.5, p.inv1_5);
+    o[7] = (float)div_const(f.w, 3.0, p.inv3);
 }
 
 __device__ __forceinline__ void store_obs8(const DevParams &p, int env, const float *o)
@@ -161,21 +176,30 @@ template <int TASK>
 __device__ __forceinline__ void write_row(const DevParams &p, float *row, double zx, double zy,
                                           int flag_or_colour, int aux, int k)
 {
-    row[0] = (float)(zx / 3.0);
-    row[1] = (float)(zy / 3.0);
+    const float fx = (float)div_const(zx, 3.0, p.inv3);
+    const float fy = (float)div_const(zy, 3.0, p.inv3);
     if (TASK == ZENV_TASK_COLOUR_MATCH) {
+        row[0] = fx;
+        row[1] = fy;
         row[2] = flag_or_colour == 2 ? 1.f : 0.f;
         row[3] = flag_or_colour == 1 ? 1.f : 0.f;
         row[4] = flag_or_colour == 0 ? 1.f : 0.f;
         row[5] = 0.25f;
-        row[6] = (float)((double)(float)aux / (double)p.max_cd);
-    } else {
+        row[6] = (float)div_const((double)(float)aux, p.d_maxcd, p.inv_maxcd);
+    } else if (TASK == ZENV_TASK_TIMED_TSP) {
+        row[0] = fx;
+        row[1] = fy;
         row[2] = flag_or_colour ? 1.f : 0.f;
         row[3] = 1.f;
         row[4] = flag_or_colour ? 0.f : 1.f;
         row[5] = 0.25f;
-        if (TASK == ZENV_TASK_TIMED_TSP)
-            row[6] = flag_or_colour ? 1.f : (float)((double)(aux - k) / (double)p.num_steps);
+        row[6] = flag_or_colour ? 1.f : (float)div_const((double)(aux - k), p.d_steps, p.inv_steps);
+    } else {
+        // 24-byte rows: three 8-byte stores (ds_write_b64 when `row` is the LDS tile)
+        float2 *r2 = reinterpret_cast<float2 *>(row);
+        r2[0] = make_float2(fx, fy);
+        r2[1] = make_float2(flag_or_colour ? 1.f : 0.f, 1.f);
+        r2[2] = make_float2(flag_or_colour ? 0.f : 1.f, 0.25f);
     }
 }
 
@@ -287,48 +311,88 @@ __device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_
 }
 
 // =========================================================================== K1: step
-template <int TASK>
+// Phase order inside the wave is chosen for memory/compute overlap, not source order of the
+// reference: nothing that decides reward / done / reset / zone rows depends on this step's
+// physics (set_mocaps() sees the PRE-physics pose), so the zone pass runs first, the
+// 64 x Z x F tile is flushed at once (stores drain asynchronously) and the 10 serial
+// MuJoCo substeps + the 8-float obs run underneath the draining stores.
+//
+// ZT > 0: zone count known at compile time -> the zone loop is fully unrolled and every
+// zone load of the wave (2*Z x 512 B, + Z x 256 B tmax / Z x 64 B cooldown) is issued up
+// front.  ZT == 0: generic runtime-Z fallback with the loads inside the loop.
+template <int TASK, int ZT>
 __global__ __launch_bounds__(kWave) void k_step_lane(DevParams p, const float *__restrict__ actions,
                                                      int auto_reset)
 {
     extern __shared__ __align__(16) float tile[];
     constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
+    constexpr int ZR = ZT > 0 ? ZT : 1;
     const int lane = threadIdx.x;
     const int env0 = blockIdx.x * kWave;
     const int env = env0 + lane;
-    const int N = p.N, Z = p.Z, ZF = Z * F;
+    const int N = p.N;
+    const int Z = ZT > 0 ? ZT : p.Z;
+    const int ZF = Z * F;
     float *rows = tile + lane * ZF;
 
+    EnvRegs e;
+    double c0 = 0.0, c1 = 0.0;
+    bool run_physics = false, zero_obs = false;
+
     if (env < N) {
-        float o[8];
+        // ---- issue every load of this env first
+        const uint8_t was_done = p.done_state[env];
+        load_regs(p, env, TASK, e);
+        const float2 act = reinterpret_cast<const float2 *>(actions)[env];
+        double ep_ret = p.ep_return[env];
+        double zxr[ZR], zyr[ZR];
+        int auxr[ZR];
+        if (ZT > 0) {
+#pragma unroll
+            for (int z = 0; z < ZR; ++z) {
+                const size_t zi = (size_t)z * N + env;
+                zxr[z] = p.zx[zi];
+                zyr[z] = p.zy[zi];
+                auxr[z] = 0;
+                if (TASK == ZENV_TASK_TIMED_TSP) auxr[z] = p.tmax[zi];
+                if (TASK == ZENV_TASK_COLOUR_MATCH) auxr[z] = p.cooldown[zi];
+            }
+        }
+
         float rew_out = 0.f;
         uint8_t done_out = 1, goal_out = 0;
-        if (p.done_state[env]) {
+        if (was_done) {
             // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
             for (int i = 0; i < ZF; ++i) rows[i] = 0.f;
-            for (int i = 0; i < 8; ++i) o[i] = 0.f;
+            zero_obs = true;
         } else {
-            EnvRegs e;
-            load_regs(p, env, TASK, e);
-            const float2 act = reinterpret_cast<const float2 *>(actions)[env];
             // Engine.step: ctrl = clip(action, ctrlrange)
-            const double c0 = det_clamp((double)act.x, -1.0, 1.0);
-            const double c1 = det_clamp((double)act.y, -1.0, 1.0);
+            c0 = det_clamp((double)act.x, -1.0, 1.0);
+            c1 = det_clamp((double)act.y, -1.0, 1.0);
             const int k = e.steps + 1;   // step index after this call
+            double rx, ry;               // pre-physics pose: what set_mocaps() sees
+            world_pos(e, rx, ry);
 
             // ---- zone pass: set_mocaps() of the first substep, with the pre-physics pose
-            double rx, ry;
-            world_pos(e, rx, ry);
             int first = -1;
             bool timed_out = false;
-            for (int z = 0; z < Z; ++z) {
+#pragma unroll
+            for (int z = 0; z < (ZT > 0 ? ZT : Z); ++z) {
                 const size_t zi = (size_t)z * N + env;
-                const double zx = p.zx[zi], zy = p.zy[zi];
+                double zx, zy;
+                int aux = 0;
+                if (ZT > 0) {
+                    zx = zxr[z]; zy = zyr[z]; aux = auxr[z];
+                } else {
+                    zx = p.zx[zi]; zy = p.zy[zi];
+                    if (TASK == ZENV_TASK_TIMED_TSP) aux = p.tmax[zi];
+                    if (TASK == ZENV_TASK_COLOUR_MATCH) aux = p.cooldown[zi];
+                }
                 const double dx = zx - rx, dy = zy - ry;
                 const double d2 = dx * dx + dy * dy;
                 const bool inside = d2 <= p.hit_d2;
                 if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                    int cd = p.cooldown[zi];
+                    int cd = aux;
                     if (cd > 0) cd -= 1;                       // colour_match_env.py:98-100
                     int col = (int)((e.colpack >> (2 * z)) & 3ull);
                     if (first < 0 && cd == 0 && inside) {       // :106-120, lowest index wins
@@ -346,19 +410,14 @@ __global__ __launch_bounds__(kWave) void k_step_lane(DevParams p, const float *_
                         vis = true;
                         e.vis |= 1u << z;
                     }
-                    int tm = 0;
                     if (TASK == ZENV_TASK_TIMED_TSP) {
-                        tm = p.tmax[zi];
-                        if (!vis && (tm - k) <= 0) timed_out = true;   // TTSP_env.py:67
+                        if (!vis && (aux - k) <= 0) timed_out = true;   // TTSP_env.py:67
                     }
-                    write_row<TASK>(p, rows + z * F, zx, zy, vis ? 1 : 0, tm, k);
+                    write_row<TASK>(p, rows + z * F, zx, zy, vis ? 1 : 0, aux, k);
                 }
             }
 
-            // ---- physics: frameskip x mj_step
-            for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
-
-            // ---- reward / goal / termination (Engine.step order)
+            // ---- reward / goal / termination (Engine.step order; none of it needs the physics)
             double r = 0.0;
             bool goal;
             if (TASK == ZENV_TASK_COLOUR_MATCH) {
@@ -383,38 +442,61 @@ __global__ __launch_bounds__(kWave) void k_step_lane(DevParams p, const float *_
             if (k >= p.num_steps) done = true;
             if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
 
-            double ep_ret = p.ep_return[env] + r;
+            ep_ret = ep_ret + r;
             rew_out = (float)r;
             done_out = done ? 1 : 0;
             p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
 
-            bool frame_changed = false;
+            run_physics = true;
             if (done) {
                 p.last_return[env] = ep_ret;
                 p.last_len[env] = k;
                 p.episodes[env] += 1;
                 if (auto_reset) {
-                    // penv.py:8-11: the returned obs is the first obs of the next episode
+                    // penv.py:8-11: the returned obs is the first obs of the next episode;
+                    // this step's physics result is never observed, so it is skipped
                     const int slot = next_bank_slot(p, env);
                     reset_env<TASK>(p, env, slot, e, rows);
                     ep_ret = 0.0;
-                    frame_changed = true;
+                    run_physics = false;
+                    p.x0[env] = e.x0; p.y0[env] = e.y0; p.bq0[env] = e.bq0; p.bq3[env] = e.bq3;
                 } else {
                     p.done_state[env] = 1;
                 }
             }
             p.ep_return[env] = ep_ret;
-            store_regs(p, env, TASK, e, frame_changed);
-            emit_obs8(p, e, o);
+            p.steps[env] = e.steps;
+            if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                p.colpack[env] = e.colpack;
+                p.goal_dist[env] = e.goal_dist;
+            } else {
+                p.vis[env] = e.vis;
+            }
         }
-        store_obs8(p, env, o);
         p.reward[env] = rew_out;
         p.done_out[env] = done_out;
         p.goal_met[env] = goal_out;
     }
+
+    // ---- the wave's 64 x Z x F float32 tile leaves as one contiguous burst
     __syncthreads();
     const int n_blk = min(kWave, N - env0);
     flush_tile(tile, p.zone_obs + (size_t)env0 * ZF, n_blk * ZF, lane);
+
+    // ---- physics (frameskip x mj_step) + the 8-float obs, underneath the draining stores
+    if (env < N) {
+        float o[8];
+        if (zero_obs) {
+            for (int i = 0; i < 8; ++i) o[i] = 0.f;
+        } else {
+            if (run_physics)
+                for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
+            p.q0[env] = e.q0; p.q1[env] = e.q1; p.q2[env] = e.q2;
+            p.v0[env] = e.v0; p.v1[env] = e.v1; p.v2[env] = e.v2;
+            emit_obs8(p, e, o);
+        }
+        store_obs8(p, env, o);
+    }
 }
 
 // =========================================================================== K2: reset
@@ -542,20 +624,32 @@ __global__ __launch_bounds__(kWave) void k_policy_lane(DevParams p, int policy, 
 static inline int n_blocks(int n) { return (n + kWave - 1) / kWave; }
 static inline size_t tile_bytes(const DevParams &p) { return (size_t)kWave * p.Z * p.F * sizeof(float); }
 
-hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset, hipStream_t s)
+template <int TASK>
+static void launch_step_task(const DevParams &p, const float *actions, int auto_reset, hipStream_t s,
+                             hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const dim3 grid(n_blocks(p.N)), block(kWave);
     const size_t lds = tile_bytes(p);
+    // hipExtLaunchKernelGGL stamps ev_start/ev_stop with the dispatch's own begin/end
+#define ZENV_LAUNCH(ZT) \
+    hipExtLaunchKernelGGL((k_step_lane<TASK, ZT>), grid, block, lds, s, ev_start, ev_stop, 0, p, actions, auto_reset)
+    switch (p.Z) {
+    case 5: ZENV_LAUNCH(5); break;
+    case 6: ZENV_LAUNCH(6); break;
+    case 15: ZENV_LAUNCH(15); break;
+    case 25: ZENV_LAUNCH(25); break;
+    default: ZENV_LAUNCH(0); break;
+    }
+#undef ZENV_LAUNCH
+}
+
+hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset, hipStream_t s,
+                       hipEvent_t ev_start, hipEvent_t ev_stop)
+{
     switch (p.task) {
-    case ZENV_TASK_TSP:
-        hipLaunchKernelGGL(k_step_lane<ZENV_TASK_TSP>, grid, block, lds, s, p, actions, auto_reset);
-        break;
-    case ZENV_TASK_TIMED_TSP:
-        hipLaunchKernelGGL(k_step_lane<ZENV_TASK_TIMED_TSP>, grid, block, lds, s, p, actions, auto_reset);
-        break;
-    default:
-        hipLaunchKernelGGL(k_step_lane<ZENV_TASK_COLOUR_MATCH>, grid, block, lds, s, p, actions, auto_reset);
-        break;
+    case ZENV_TASK_TSP: launch_step_task<ZENV_TASK_TSP>(p, actions, auto_reset, s, ev_start, ev_stop); break;
+    case ZENV_TASK_TIMED_TSP: launch_step_task<ZENV_TASK_TIMED_TSP>(p, actions, auto_reset, s, ev_start, ev_stop); break;
+    default: launch_step_task<ZENV_TASK_COLOUR_MATCH>(p, actions, auto_reset, s, ev_start, ev_stop); break;
     }
     return hipGetLastError();
 }

@@ -74,7 +74,7 @@ int validate_config(const zenv_config &c)
     if (c.num_zones < 1 || c.num_zones > ZENV_MAX_ZONES)
         return fail(ZENV_E_ARG, "num_zones %d outside [1,%d]", c.num_zones, ZENV_MAX_ZONES);
     if (c.num_steps < 1) return fail(ZENV_E_ARG, "num_steps must be positive");
-    if (c.max_cd < 0 || c.max_cd > 255) return fail(ZENV_E_ARG, "max_cd %d outside [0,255]", c.max_cd);
+    if (c.max_cd < 1 || c.max_cd > 255) return fail(ZENV_E_ARG, "max_cd %d outside [1,255]", c.max_cd);
     if (c.frameskip < 1 || c.frameskip > 1000) return fail(ZENV_E_ARG, "bad frameskip %d", c.frameskip);
     if (!(c.mass > 0) || !(c.inertia_zz > 0) || !(c.timestep > 0)) return fail(ZENV_E_ARG, "bad model constants");
     if (c.kernel != ZENV_KERNEL_LANE_PER_ENV)
@@ -105,6 +105,12 @@ void derive_constants(const zenv_config &c, DevParams &p)
     p.inv11 = 1.0 / A11;
     p.hit_d2 = sqrt_threshold(c.zones_size);
     p.tsr = c.time_saved_reward;
+    p.inv3 = 1.0 / 3.0;
+    p.inv1_5 = 1.0 / 1.5;
+    p.d_steps = (double)c.num_steps;
+    p.inv_steps = 1.0 / p.d_steps;
+    p.d_maxcd = (double)c.max_cd;
+    p.inv_maxcd = 1.0 / p.d_maxcd;
 }
 
 template <typename T>
@@ -591,9 +597,10 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     HIP_TRY(hipEventRecord(h->events[0], h->stream));
     for (int t = 0; t < steps; ++t) {
         HIP_TRY(launch_policy(h->p, policy, policy_seed, env_index0, (uint32_t)h->step_count, h->p.actions, h->stream));
-        if (per_kernel) HIP_TRY(hipEventRecord(h->events[2 + 2 * t], h->stream));
-        HIP_TRY(launch_step(h->p, h->p.actions, auto_reset, h->stream));
-        if (per_kernel) HIP_TRY(hipEventRecord(h->events[3 + 2 * t], h->stream));
+        if (per_kernel)
+            HIP_TRY(launch_step(h->p, h->p.actions, auto_reset, h->stream, h->events[2 + 2 * t], h->events[3 + 2 * t]));
+        else
+            HIP_TRY(launch_step(h->p, h->p.actions, auto_reset, h->stream));
         h->step_count += 1;
     }
     HIP_TRY(hipEventRecord(h->events[1], h->stream));
