@@ -3,10 +3,12 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch: the scripted on-device policy kernel
-writes (N_env, 2) actions, then ONE `zenv_step` launch advances all N_env = 65 536 envs
-(10 MuJoCo substeps, visit logic, reward/termination, fused auto-reset, obs emit).  All
-inputs (env state, layout bank) are resident in HBM before the timed region.
+One "step" = one pass of the hot path over one batch: ONE step-kernel launch consumes the
+(N_env, 2) action buffer and advances all N_env = 65 536 envs (10 MuJoCo substeps, visit
+logic, reward/termination, fused auto-reset, obs emit); the scripted closed-loop policy
+pi_greedy(obs) that fills the action buffer for the next step runs inside the same launch
+(--unfused: as its own kernel before every step; identical results).  All inputs (env
+state, layout bank) are resident in HBM before the timed region.
 
 N > 1: one process per GPU (torch.distributed, backend "nccl" == RCCL).  Envs shard
 trivially: rank r owns global envs [r*65536, (r+1)*65536); there is no collective on the
@@ -76,6 +78,8 @@ def main():
     ap.add_argument("--policy", default="greedy", choices=["greedy", "uniform"])
     ap.add_argument("--override", action="append", default=[],
                     help="experiment only: config key=value (e.g. frameskip=1); marks the run invalid")
+    ap.add_argument("--unfused", action="store_true",
+                    help="run the stand-alone policy kernel before every step instead of the fused action source")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the per-launch HIP events around the step kernel")
@@ -117,7 +121,8 @@ def main():
     shard.build_bank(env, episodes_per_env, n_threads=min(32, usable_cores()))
     t_bank = time.perf_counter() - t_bank
     env.reset()
-    env.rollout(args.warmup, policy, policy_seed=0x5EED, env_index0=shard.env_index0)
+    env.rollout(args.warmup, policy, policy_seed=0x5EED, env_index0=shard.env_index0,
+                fused=not args.unfused)
 
     def fence():
         env.sync()
@@ -130,7 +135,8 @@ def main():
     t0 = time.perf_counter()
     ms_total, ms_kernel = env.rollout(args.steps, policy, policy_seed=0x5EED,
                                       env_index0=shard.env_index0, auto_reset=True,
-                                      time_step_kernel=not args.no_kernel_events)
+                                      time_step_kernel=not args.no_kernel_events,
+                                      fused=not args.unfused)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -166,7 +172,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}, N_env={n_env} per GPU, num_steps=2000, "
-                                   f"zones_keepout={keepout}, policy=pi_{args.policy} (on-device), "
+                                   f"zones_keepout={keepout}, policy=pi_{args.policy} (on-device, "
+                                   f"{'own kernel' if args.unfused else 'fused into the step launch'}), "
                                    "auto-reset on" + (f" EXPERIMENT {args.override}" if args.override else ""),
                        "n_env_total": world * n_env, "zones": zones,
                        "parallelism": f"env-shard x{world}, all-gather(ep_return) after rollout"},

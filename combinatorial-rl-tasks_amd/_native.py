@@ -17,6 +17,7 @@ OBS_DIM = 8
 TASK_TSP, TASK_TIMED_TSP, TASK_COLOUR_MATCH = 0, 1, 2
 POLICY_UNIFORM, POLICY_GREEDY = 0, 1
 KERNEL_LANE_PER_ENV, KERNEL_WAVE_PER_ENV = 0, 1
+ROLLOUT_UNFUSED = 1
 
 E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE = -1, -2, -3, -4, -5
 
@@ -73,7 +74,7 @@ _PROTOTYPES = {
     "zenv_reset": (C.c_int, [_H, C.c_void_p]),
     "zenv_step": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
     "zenv_policy": (C.c_int, [_H, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
-    "zenv_rollout": (C.c_int, [_H, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
+    "zenv_rollout": (C.c_int, [_H, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int,
                                C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "zenv_get": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int]),
     "zenv_device_ptr": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),

@@ -2,9 +2,10 @@
 //
 // HBM layout (lane-per-env kernels): everything is struct-of-arrays over the env index so
 // that lane i of a wave touches element i of each array (64 x 8 B = 512 B per wave-load):
-//   dyn      q[3][N], v[3][N]           float64   joint positions / velocities
-//   frame    x0,y0,bq0,bq3 [N]          float64   episode-static robot placement (body quat w,z)
-//   zones    zx[Z][N], zy[Z][N]         float64   zone centres, zone-major
+//   dyn      qa,qb,qc [N] double2       float64   (q0,q1) (q2,v0) (v1,v2) joint pos / vel
+//   frame    fa,fb [N] double2          float64   (x0,y0) (bq0,bq3) episode-static placement
+//   zones    zxy[Z][N] double2          float64   zone centres (x,y), zone-major
+// (pairs so that every access is 16 B per lane = 1 KiB per wave instruction)
 //   TSP/TTSP vis[N] u32 bitmask; tmax[Z][N] i32 (TimedTSP)
 //   Colour   colpack[N] u64 (2 bits/zone), cooldown[Z][N] u8, goal_dist[N] i32
 //   counters steps[N] i32, done_state[N] u8, ep_return[N] f64, episodes/last_len[N] i32 ...
@@ -12,6 +13,8 @@
 // (main/src/utils/format.py:25-29): obs [N][8] f32, zone_obs [N][Z][F] f32.
 #pragma once
 #include <cstdint>
+
+#include <hip/hip_runtime_api.h>   // double2
 
 namespace zenvk {
 
@@ -31,9 +34,9 @@ struct DevParams {
     double d_steps, inv_steps;   // (double)num_steps and RN(1/num_steps)
     double d_maxcd, inv_maxcd;   // (double)max_cd and RN(1/max_cd)
     // state
-    double *q0, *q1, *q2, *v0, *v1, *v2;
-    double *x0, *y0, *bq0, *bq3;
-    double *zx, *zy;
+    double2 *qa, *qb, *qc;   // (q0,q1) (q2,v0) (v1,v2): 16 B/lane accesses
+    double2 *fa, *fb;        // (x0,y0) (bq0,bq3)
+    double2 *zxy;            // [Z][N] (zone x, zone y)
     uint32_t *vis;
     int32_t *tmax;
     uint64_t *colpack;
@@ -56,6 +59,7 @@ struct DevParams {
     // outputs
     float *obs, *zone_obs, *reward, *actions;
     uint8_t *done_out, *goal_met;
+    unsigned long long *dbg;   // diagnostic stamps (ZENV_STAMPS builds), else null
 };
 
 enum { SCHED_SEQUENTIAL = 0, SCHED_FIXED_SEEDS = 1 };

@@ -101,12 +101,19 @@ __device__ int next_bank_slot(const DevParams &p, int env)
 // The result equals the IEEE quotient RN(a/b) bit for bit (argument in DESIGN.md: r is exact
 // and the exact value of q1 + r*inv_b lies within 2^-53 ulp of a/b, which for these b is
 // never that close to a rounding boundary), at 3 instructions instead of the ~14 of v_div_*.
+// A zero numerator gives +0.0.
 __device__ __forceinline__ double div_const(double a, double b, double inv_b)
 {
     const double q1 = a * inv_b;
     const double r = __builtin_fma(-b, q1, a);
-    const double q = __builtin_fma(r, inv_b, q1);
-    return a == 0.0 ? a : q;   // keeps the sign of a zero numerator like a true division
+    return __builtin_fma(r, inv_b, q1);
+}
+// Same with the sign of a zero numerator preserved (-0.0 / b = -0.0 like a true division).
+// Zone coordinates and step counts cannot be -0.0; velocities use this form.
+__device__ __forceinline__ double div_const_z(double a, double b, double inv_b)
+{
+    const double q = div_const(a, b, inv_b);
+    return a == 0.0 ? a : q;
 }
 
 // Per-lane registers of one env
@@ -154,14 +161,14 @@ __device__ __forceinline__ void emit_obs8(const DevParams &p, const EnvRegs &e, 
 {
     const Pose f = forward_pose(e);
     o[0] = (float)(1.0 - div_const((double)e.steps, p.d_steps, p.inv_steps));
-    o[1] = (float)div_const(f.px, 3.0, p.inv3);
-    o[2] = (float)div_const(f.py, 3.0, p.inv3);
+    o[1] = (float)div_const_z(f.px, 3.0, p.inv3);
+    o[2] = (float)div_const_z(f.py, 3.0, p.inv3);
     const double a0 = (double)(float)f.xq0, a3 = (double)(float)f.xq3;
     o[3] = (float)(a0 * a0 - a3 * a3);
     o[4] = (float)((2.0 * a0) * a3);
-    o[5] = (float)div_const(f.vx, 1.5, p.inv1_5);
-    o[6] = (float)div_const(f.vy, 1.5, p.inv1_5);
-    o[7] = (float)div_const(f.w, 3.0, p.inv3);
+    o[5] = (float)div_const_z(f.vx, 1.5, p.inv1_5);
+    o[6] = (float)div_const_z(f.vy, 1.5, p.inv1_5);
+    o[7] = (float)div_const_z(f.w, 3.0, p.inv3);
 }
 
 __device__ __forceinline__ void store_obs8(const DevParams &p, int env, const float *o)
@@ -222,8 +229,7 @@ __device__ void reset_env(const DevParams &p, int env, int slot, EnvRegs &e, flo
     for (int z = 0; z < Z; ++z) {
         const double zx = bz[2 * z], zy = bz[2 * z + 1];
         const size_t zi = (size_t)z * N + env;
-        p.zx[zi] = zx;
-        p.zy[zi] = zy;
+        p.zxy[zi] = make_double2(zx, zy);
         int flag = 0, aux = 0;
         if (TASK == ZENV_TASK_TIMED_TSP) {
             aux = ba[z];
@@ -239,29 +245,24 @@ __device__ void reset_env(const DevParams &p, int env, int slot, EnvRegs &e, flo
     p.seed[env] = p.bank_seed[slot];
 }
 
-__device__ __forceinline__ void load_regs(const DevParams &p, int env, int task, EnvRegs &e)
+__device__ __forceinline__ void store_dyn(const DevParams &p, int env, const EnvRegs &e)
 {
-    e.q0 = p.q0[env]; e.q1 = p.q1[env]; e.q2 = p.q2[env];
-    e.v0 = p.v0[env]; e.v1 = p.v1[env]; e.v2 = p.v2[env];
-    e.x0 = p.x0[env]; e.y0 = p.y0[env]; e.bq0 = p.bq0[env]; e.bq3 = p.bq3[env];
-    e.steps = p.steps[env];
-    e.vis = 0u; e.colpack = 0ull; e.goal_dist = 0;
-    if (task == ZENV_TASK_COLOUR_MATCH) {
-        e.colpack = p.colpack[env];
-        e.goal_dist = p.goal_dist[env];
-    } else {
-        e.vis = p.vis[env];
-    }
+    p.qa[env] = make_double2(e.q0, e.q1);
+    p.qb[env] = make_double2(e.q2, e.v0);
+    p.qc[env] = make_double2(e.v1, e.v2);
+}
+
+__device__ __forceinline__ void store_frame(const DevParams &p, int env, const EnvRegs &e)
+{
+    p.fa[env] = make_double2(e.x0, e.y0);
+    p.fb[env] = make_double2(e.bq0, e.bq3);
 }
 
 __device__ __forceinline__ void store_regs(const DevParams &p, int env, int task, const EnvRegs &e,
                                            bool frame_too)
 {
-    p.q0[env] = e.q0; p.q1[env] = e.q1; p.q2[env] = e.q2;
-    p.v0[env] = e.v0; p.v1[env] = e.v1; p.v2[env] = e.v2;
-    if (frame_too) {
-        p.x0[env] = e.x0; p.y0[env] = e.y0; p.bq0[env] = e.bq0; p.bq3[env] = e.bq3;
-    }
+    store_dyn(p, env, e);
+    if (frame_too) store_frame(p, env, e);
     p.steps[env] = e.steps;
     if (task == ZENV_TASK_COLOUR_MATCH) {
         p.colpack[env] = e.colpack;
@@ -306,196 +307,441 @@ __device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_
     const int n4 = n_floats >> 2;
     const float4 *s4 = reinterpret_cast<const float4 *>(tile);
     float4 *d4 = reinterpret_cast<float4 *>(dst);
-    for (int i = lane; i < n4; i += kWave) d4[i] = s4[i];
-    for (int i = (n4 << 2) + lane; i < n_floats; i += kWave) dst[i] = tile[i];
+    int i = lane;
+    // four ds_read_b128 in flight per lane before the four dwordx4 stores
+    for (; i + 3 * kWave < n4; i += 4 * kWave) {
+        const float4 a = s4[i], b = s4[i + kWave], c = s4[i + 2 * kWave], d = s4[i + 3 * kWave];
+        d4[i] = a; d4[i + kWave] = b; d4[i + 2 * kWave] = c; d4[i + 3 * kWave] = d;
+    }
+    for (; i < n4; i += kWave) d4[i] = s4[i];
+    for (int j = (n4 << 2) + lane; j < n_floats; j += kWave) dst[j] = tile[j];
+}
+
+// =========================================================================== K3: policies
+// Scripted action sources (the build's own, same definition as oracle/zenv_oracle.c:orc_policy).
+// Both are functions of the float32 observation only.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ float2 uniform_action(uint64_t global_env, uint32_t step_index, uint64_t seed)
+{
+    uint32_t c[4] = { (uint32_t)global_env, (uint32_t)(global_env >> 32), step_index, 0u };
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float2 a;
+    a.x = 2.0f * ((float)(c[0] >> 8) * 5.9604644775390625e-08f) - 1.0f;
+    a.y = 2.0f * ((float)(c[1] >> 8) * 5.9604644775390625e-08f) - 1.0f;
+    return a;
+}
+
+// Steer towards the nearest eligible zone.  rows: this env's [Z][F] float32 zone_obs rows
+// (LDS or global); (opx, opy, ohx, ohy) = obs[1..4].
+template <int TASK, int ZT = 0>
+__device__ __forceinline__ float2 greedy_action(const float *rows, int Zrt, float opx, float opy, float ohx,
+                                                float ohy)
+{
+    constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
+    const int Z = ZT > 0 ? ZT : Zrt;
+    const double px = 3.0 * (double)opx, py = 3.0 * (double)opy;
+    const double hx = (double)ohx, hy = (double)ohy;
+    int target_colour = -1;
+    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+        int cb = 0, cg = 0, cr = 0;
+#pragma unroll
+        for (int z = 0; z < Z; ++z) {
+            const float *row = rows + z * F;
+            const int col = row[4] != 0.f ? 0 : (row[3] != 0.f ? 1 : 2);
+            cb += col == 0; cg += col == 1; cr += col == 2;
+        }
+        target_colour = 0;
+        int best_cnt = cb;
+        if (cg > best_cnt) { target_colour = 1; best_cnt = cg; }
+        if (cr > best_cnt) { target_colour = 2; }
+    }
+    // nearest eligible zone, lowest index on ties (== the oracle's sequential `d2 < best` scan)
+    int best = -1;
+    double bd2 = 0.0, bdx = 0.0, bdy = 0.0;
+    if (ZT > 0) {
+        // all distances first (independent), then a pairwise tournament: log-depth dependency
+        // chain instead of a Z-long one.  Ineligible zones carry +inf.
+        constexpr int ZP = ZT > 0 ? ZT : 1;
+        double d2s[ZP];
+        int idx[ZP];
+#pragma unroll
+        for (int z = 0; z < ZP; ++z) {
+            const float *row = rows + z * F;
+            bool eligible;
+            if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                const int col = row[4] != 0.f ? 0 : (row[3] != 0.f ? 1 : 2);
+                eligible = (row[6] == 0.f) && (col != target_colour);
+            } else {
+                eligible = row[2] == 0.f;
+            }
+            const double dx = 3.0 * (double)row[0] - px, dy = 3.0 * (double)row[1] - py;
+            const double d2 = dx * dx + dy * dy;
+            d2s[z] = eligible ? d2 : __builtin_inf();
+            idx[z] = z;
+        }
+#pragma unroll
+        for (int stride = 1; stride < ZP; stride *= 2) {
+#pragma unroll
+            for (int z = 0; z + stride < ZP; z += 2 * stride) {
+                // the left entry always has the lower zone index: it wins ties
+                const bool take = d2s[z + stride] < d2s[z];
+                d2s[z] = take ? d2s[z + stride] : d2s[z];
+                idx[z] = take ? idx[z + stride] : idx[z];
+            }
+        }
+        if (d2s[0] < __builtin_inf()) {
+            best = idx[0];
+            const float *row = rows + best * F;
+            bdx = 3.0 * (double)row[0] - px;
+            bdy = 3.0 * (double)row[1] - py;
+            bd2 = bdx * bdx + bdy * bdy;
+        }
+    } else {
+        for (int z = 0; z < Z; ++z) {
+            const float *row = rows + z * F;
+            bool eligible;
+            if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                const int col = row[4] != 0.f ? 0 : (row[3] != 0.f ? 1 : 2);
+                eligible = (row[6] == 0.f) && (col != target_colour);
+            } else {
+                eligible = row[2] == 0.f;
+            }
+            const double dx = 3.0 * (double)row[0] - px, dy = 3.0 * (double)row[1] - py;
+            const double d2 = dx * dx + dy * dy;
+            if (eligible && (best < 0 || d2 < bd2)) { best = z; bd2 = d2; bdx = dx; bdy = dy; }
+        }
+    }
+    float2 a = make_float2(0.f, 0.f);
+    if (best >= 0 && bd2 > 1e-18) {
+        const double n = sqrt(bd2);
+        const double cs = (hx * bdx + hy * bdy) / n;
+        const double sn = (hx * bdy - hy * bdx) / n;
+        if (cs < 0.0) a.y = sn >= 0.0 ? 1.f : -1.f;
+        else a.y = (float)det_clamp(4.0 * sn, -1.0, 1.0);
+        a.x = cs > 0.8 ? 1.f : 0.f;
+    }
+    return a;
+}
+
+template <int TASK, int ZT>
+__device__ __forceinline__ float2 scripted_action(const StepPolicy &pol, int env, const float *rows, int Z,
+                                                  const float *o)
+{
+    if (pol.policy == ZENV_POLICY_UNIFORM)
+        return uniform_action(pol.env_index0 + (uint64_t)env, pol.step_index, pol.seed);
+    return greedy_action<TASK, ZT>(rows, Z, o[1], o[2], o[3], o[4]);
+}
+
+template <int TASK>
+__global__ __launch_bounds__(kWave) void k_policy_lane(DevParams p, StepPolicy pol)
+{
+    extern __shared__ __align__(16) float tile[];
+    constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
+    const int lane = threadIdx.x;
+    const int env0 = blockIdx.x * kWave;
+    const int env = env0 + lane;
+    const int N = p.N, Z = p.Z, ZF = Z * F;
+
+    if (pol.policy == ZENV_POLICY_UNIFORM) {
+        if (env < N)
+            reinterpret_cast<float2 *>(pol.out)[env] =
+                uniform_action(pol.env_index0 + (uint64_t)env, pol.step_index, pol.seed);
+        return;
+    }
+    // greedy: stage the wave's zone_obs rows through LDS (coalesced 16 B/lane loads)
+    {
+        const int n_blk = min(kWave, N - env0);
+        const int n_floats = n_blk * ZF, n4 = n_floats >> 2;
+        const float *src = p.zone_obs + (size_t)env0 * ZF;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *t4 = reinterpret_cast<float4 *>(tile);
+        for (int i = lane; i < n4; i += kWave) t4[i] = s4[i];
+        for (int i = (n4 << 2) + lane; i < n_floats; i += kWave) tile[i] = src[i];
+    }
+    __syncthreads();
+    if (env >= N) return;
+    const float4 *ob = reinterpret_cast<const float4 *>(p.obs + (size_t)env * 8);
+    const float4 oa = ob[0], obb = ob[1];
+    reinterpret_cast<float2 *>(pol.out)[env] = greedy_action<TASK>(tile + lane * ZF, Z, oa.y, oa.z, oa.w, obb.x);
 }
 
 // =========================================================================== K1: step
-// Phase order inside the wave is chosen for memory/compute overlap, not source order of the
-// reference: nothing that decides reward / done / reset / zone rows depends on this step's
-// physics (set_mocaps() sees the PRE-physics pose), so the zone pass runs first, the
-// 64 x Z x F tile is flushed at once (stores drain asynchronously) and the 10 serial
-// MuJoCo substeps + the 8-float obs run underneath the draining stores.
+// A 128-thread workgroup (two wave64) owns a tile of 64 consecutive envs, lane i <-> env i in
+// BOTH waves, with the work split by what it is bound by:
+//   wave 0, "zone wave"   (memory):  streams the zone-major zone arrays, runs set_mocaps(),
+//       reward / goal / termination / auto-reset (none of which needs this step's physics:
+//       set_mocaps() sees the PRE-physics pose), builds the 64 x Z x F float32 tile in LDS
+//       and flushes it as one contiguous burst of dwordx4 stores;
+//   wave 1, "physics wave" (latency): the 10 serial MuJoCo substeps and the 8-float obs.
+// The two meet once (one s_barrier): the zone wave tells the physics wave per env whether
+// its result is observable (mode 0) or superseded by a reset / masked no-op (mode 1) and
+// what the new step count is.  On different SIMDs the ~5 us serial fp64 chain of the physics
+// wave runs underneath the zone wave's load->LDS->store stream instead of after it.
 //
 // ZT > 0: zone count known at compile time -> the zone loop is fully unrolled and every
 // zone load of the wave (2*Z x 512 B, + Z x 256 B tmax / Z x 64 B cooldown) is issued up
 // front.  ZT == 0: generic runtime-Z fallback with the loads inside the loop.
+constexpr int kStepThreads = 2 * kWave;
+
+// Diagnostic build only (-DZENV_STAMPS, never shipped): lane 0 of each wave drops
+// s_memrealtime (100 MHz) stamps into p.dbg[block][16] at phase boundaries.
+#ifdef ZENV_STAMPS
+#define ZSTAMP(slot)                                                                      \
+    do {                                                                                  \
+        if (p.dbg && lane == 0) p.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define ZSTAMP(slot) do { } while (0)
+#endif
+
+// amdgpu_waves_per_eu(2, 2): the grid needs exactly two waves per SIMD (4 tiles x 2 waves per
+// CU), so the scheduler may spend up to 256 VGPRs to keep every zone load in flight at once
+// instead of sinking loads to save registers for an occupancy the launch never uses.
 template <int TASK, int ZT>
-__global__ __launch_bounds__(kWave) void k_step_lane(DevParams p, const float *__restrict__ actions,
-                                                     int auto_reset)
+__global__ __launch_bounds__(kStepThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_step_lane(DevParams p, const float *__restrict__ actions,
+                                                            int auto_reset, StepPolicy pol)
 {
     extern __shared__ __align__(16) float tile[];
     constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
     constexpr int ZR = ZT > 0 ? ZT : 1;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
     const int env0 = blockIdx.x * kWave;
     const int env = env0 + lane;
     const int N = p.N;
     const int Z = ZT > 0 ? ZT : p.Z;
     const int ZF = Z * F;
     float *rows = tile + lane * ZF;
+    int *xmode = reinterpret_cast<int *>(tile + kWave * ZF);   // zone wave -> physics wave
+    int *xstep = xmode + kWave;
 
     EnvRegs e;
-    double c0 = 0.0, c1 = 0.0;
-    bool run_physics = false, zero_obs = false;
+    e.steps = 0;
+    float o[8];   // physics wave: this step's obs
 
-    if (env < N) {
-        // ---- issue every load of this env first
-        const uint8_t was_done = p.done_state[env];
-        load_regs(p, env, TASK, e);
-        const float2 act = reinterpret_cast<const float2 *>(actions)[env];
-        double ep_ret = p.ep_return[env];
-        double zxr[ZR], zyr[ZR];
-        int auxr[ZR];
-        if (ZT > 0) {
-#pragma unroll
-            for (int z = 0; z < ZR; ++z) {
-                const size_t zi = (size_t)z * N + env;
-                zxr[z] = p.zx[zi];
-                zyr[z] = p.zy[zi];
-                auxr[z] = 0;
-                if (TASK == ZENV_TASK_TIMED_TSP) auxr[z] = p.tmax[zi];
-                if (TASK == ZENV_TASK_COLOUR_MATCH) auxr[z] = p.cooldown[zi];
+    if (role == 0) {
+        // =================================================================== zone wave
+        ZSTAMP(0);
+        if (env < N) {
+            // ---- issue every load of this env first
+            const uint8_t was_done = p.done_state[env];
+            {
+                const double2 qa = p.qa[env], fa = p.fa[env], fb = p.fb[env];
+                e.q0 = qa.x; e.q1 = qa.y;
+                e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
             }
-        }
-
-        float rew_out = 0.f;
-        uint8_t done_out = 1, goal_out = 0;
-        if (was_done) {
-            // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
-            for (int i = 0; i < ZF; ++i) rows[i] = 0.f;
-            zero_obs = true;
-        } else {
-            // Engine.step: ctrl = clip(action, ctrlrange)
-            c0 = det_clamp((double)act.x, -1.0, 1.0);
-            c1 = det_clamp((double)act.y, -1.0, 1.0);
-            const int k = e.steps + 1;   // step index after this call
-            double rx, ry;               // pre-physics pose: what set_mocaps() sees
-            world_pos(e, rx, ry);
-
-            // ---- zone pass: set_mocaps() of the first substep, with the pre-physics pose
-            int first = -1;
-            bool timed_out = false;
+            e.steps = p.steps[env];
+            e.vis = 0u; e.colpack = 0ull; e.goal_dist = 0;
+            if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                e.colpack = p.colpack[env];
+                e.goal_dist = p.goal_dist[env];
+            } else {
+                e.vis = p.vis[env];
+            }
+            double ep_ret = p.ep_return[env];
+            double zxr[ZR], zyr[ZR];
+            int auxr[ZR];
+            if (ZT > 0) {
+                // issue order = consumption order: pose first, then zone 0, 1, ... so the
+                // in-order vmcnt waits of the zone pass release one zone at a time
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int z = 0; z < (ZT > 0 ? ZT : Z); ++z) {
-                const size_t zi = (size_t)z * N + env;
-                double zx, zy;
-                int aux = 0;
-                if (ZT > 0) {
-                    zx = zxr[z]; zy = zyr[z]; aux = auxr[z];
-                } else {
-                    zx = p.zx[zi]; zy = p.zy[zi];
-                    if (TASK == ZENV_TASK_TIMED_TSP) aux = p.tmax[zi];
-                    if (TASK == ZENV_TASK_COLOUR_MATCH) aux = p.cooldown[zi];
+                for (int z = 0; z < ZR; ++z) {
+                    const size_t zi = (size_t)z * N + env;
+                    const double2 zz = p.zxy[zi];   // one 16 B/lane load: 1 KiB per wave
+                    zxr[z] = zz.x;
+                    zyr[z] = zz.y;
+                    auxr[z] = 0;
+                    if (TASK == ZENV_TASK_TIMED_TSP) auxr[z] = p.tmax[zi];
+                    if (TASK == ZENV_TASK_COLOUR_MATCH) auxr[z] = p.cooldown[zi];
                 }
-                const double dx = zx - rx, dy = zy - ry;
-                const double d2 = dx * dx + dy * dy;
-                const bool inside = d2 <= p.hit_d2;
+                // nothing below may be scheduled above this point, nor any load below it
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            float rew_out = 0.f;
+            uint8_t done_out = 1, goal_out = 0;
+            int mode = 1;
+            if (was_done) {
+                // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
+                for (int i = 0; i < ZF; ++i) rows[i] = 0.f;
+                for (int i = 0; i < 8; ++i) o[i] = 0.f;
+                store_obs8(p, env, o);
+                if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = make_float2(0.f, 0.f);
+            } else {
+                const int k = e.steps + 1;   // step index after this call
+                double rx, ry;               // pre-physics pose: what set_mocaps() sees
+                world_pos(e, rx, ry);
+                ZSTAMP(1);
+
+                // ---- zone pass: set_mocaps() of the first substep
+                int first = -1;
+                bool timed_out = false;
+#pragma unroll
+                for (int z = 0; z < (ZT > 0 ? ZT : Z); ++z) {
+                    const size_t zi = (size_t)z * N + env;
+                    double zx, zy;
+                    int aux = 0;
+                    if (ZT > 0) {
+                        zx = zxr[z]; zy = zyr[z]; aux = auxr[z];
+                    } else {
+                        const double2 zz = p.zxy[zi];
+                        zx = zz.x; zy = zz.y;
+                        if (TASK == ZENV_TASK_TIMED_TSP) aux = p.tmax[zi];
+                        if (TASK == ZENV_TASK_COLOUR_MATCH) aux = p.cooldown[zi];
+                    }
+                    const double dx = zx - rx, dy = zy - ry;
+                    const double d2 = dx * dx + dy * dy;
+                    const bool inside = d2 <= p.hit_d2;
+                    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                        int cd = aux;
+                        if (cd > 0) cd -= 1;                       // colour_match_env.py:98-100
+                        int col = (int)((e.colpack >> (2 * z)) & 3ull);
+                        if (first < 0 && cd == 0 && inside) {       // :106-120, lowest index wins
+                            first = z;
+                            col = (col == 2) ? 0 : col + 1;         // Blue->Green->Red->Blue
+                            e.colpack = (e.colpack & ~(3ull << (2 * z))) | ((uint64_t)col << (2 * z));
+                            cd = p.max_cd;
+                        }
+                        p.cooldown[zi] = (uint8_t)cd;
+                        write_row<TASK>(p, rows + z * F, zx, zy, col, cd, k);
+                    } else {
+                        bool vis = (e.vis >> z) & 1u;
+                        if (first < 0 && !vis && inside) {          // TSP_env.py:54-69
+                            first = z;
+                            vis = true;
+                            e.vis |= 1u << z;
+                        }
+                        if (TASK == ZENV_TASK_TIMED_TSP) {
+                            if (!vis && (aux - k) <= 0) timed_out = true;   // TTSP_env.py:67
+                        }
+                        write_row<TASK>(p, rows + z * F, zx, zy, vis ? 1 : 0, aux, k);
+                    }
+                }
+
+                // ---- reward / goal / termination (Engine.step order; none of it needs the physics)
+                double r = 0.0;
+                bool goal;
                 if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                    int cd = aux;
-                    if (cd > 0) cd -= 1;                       // colour_match_env.py:98-100
-                    int col = (int)((e.colpack >> (2 * z)) & 3ull);
-                    if (first < 0 && cd == 0 && inside) {       // :106-120, lowest index wins
-                        first = z;
-                        col = (col == 2) ? 0 : col + 1;         // Blue->Green->Red->Blue
-                        e.colpack = (e.colpack & ~(3ull << (2 * z))) | ((uint64_t)col << (2 * z));
-                        cd = p.max_cd;
+                    if (first >= 0) {
+                        const int nd = hamming_to_goal(e.colpack, Z);
+                        r = (double)(e.goal_dist - nd);
+                        e.goal_dist = nd;
                     }
-                    p.cooldown[zi] = (uint8_t)cd;
-                    write_row<TASK>(p, rows + z * F, zx, zy, col, cd, k);
+                    goal = e.goal_dist == 0;
                 } else {
-                    bool vis = (e.vis >> z) & 1u;
-                    if (first < 0 && !vis && inside) {          // TSP_env.py:54-69
-                        first = z;
-                        vis = true;
-                        e.vis |= 1u << z;
-                    }
-                    if (TASK == ZENV_TASK_TIMED_TSP) {
-                        if (!vis && (aux - k) <= 0) timed_out = true;   // TTSP_env.py:67
-                    }
-                    write_row<TASK>(p, rows + z * F, zx, zy, vis ? 1 : 0, aux, k);
+                    r = first >= 0 ? 1.0 : 0.0;
+                    const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
+                    goal = e.vis == full;
                 }
-            }
-
-            // ---- reward / goal / termination (Engine.step order; none of it needs the physics)
-            double r = 0.0;
-            bool goal;
-            if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                if (first >= 0) {
-                    const int nd = hamming_to_goal(e.colpack, Z);
-                    r = (double)(e.goal_dist - nd);
-                    e.goal_dist = nd;
+                bool done = false;
+                if (goal) {
+                    r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
+                    done = true;
+                    goal_out = 1;
                 }
-                goal = e.goal_dist == 0;
-            } else {
-                r = first >= 0 ? 1.0 : 0.0;
-                const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
-                goal = e.vis == full;
-            }
-            bool done = false;
-            if (goal) {
-                r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
-                done = true;
-                goal_out = 1;
-            }
-            e.steps = k;
-            if (k >= p.num_steps) done = true;
-            if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
+                e.steps = k;
+                if (k >= p.num_steps) done = true;
+                if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
 
-            ep_ret = ep_ret + r;
-            rew_out = (float)r;
-            done_out = done ? 1 : 0;
-            p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
+                ep_ret = ep_ret + r;
+                rew_out = (float)r;
+                done_out = done ? 1 : 0;
+                p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
 
-            run_physics = true;
-            if (done) {
-                p.last_return[env] = ep_ret;
-                p.last_len[env] = k;
-                p.episodes[env] += 1;
-                if (auto_reset) {
-                    // penv.py:8-11: the returned obs is the first obs of the next episode;
-                    // this step's physics result is never observed, so it is skipped
-                    const int slot = next_bank_slot(p, env);
-                    reset_env<TASK>(p, env, slot, e, rows);
-                    ep_ret = 0.0;
-                    run_physics = false;
-                    p.x0[env] = e.x0; p.y0[env] = e.y0; p.bq0[env] = e.bq0; p.bq3[env] = e.bq3;
+                mode = 0;
+                if (done) {
+                    p.last_return[env] = ep_ret;
+                    p.last_len[env] = k;
+                    p.episodes[env] += 1;
+                    if (auto_reset) {
+                        // penv.py:8-11: the returned obs is the first obs of the next episode;
+                        // this step's physics result is never observed (mode 1 discards it)
+                        const int slot = next_bank_slot(p, env);
+                        reset_env<TASK>(p, env, slot, e, rows);
+                        ep_ret = 0.0;
+                        mode = 1;
+                        store_frame(p, env, e);
+                        store_dyn(p, env, e);   // reset_env zeroed q, v
+                        emit_obs8(p, e, o);
+                        store_obs8(p, env, o);
+                        if (pol.policy >= 0)   // next action from the new episode's first obs
+                            reinterpret_cast<float2 *>(pol.out)[env] = scripted_action<TASK, ZT>(pol, env, rows, Z, o);
+                    } else {
+                        p.done_state[env] = 1;
+                    }
+                }
+                p.ep_return[env] = ep_ret;
+                p.steps[env] = e.steps;
+                if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                    p.colpack[env] = e.colpack;
+                    p.goal_dist[env] = e.goal_dist;
                 } else {
-                    p.done_state[env] = 1;
+                    p.vis[env] = e.vis;
                 }
             }
-            p.ep_return[env] = ep_ret;
-            p.steps[env] = e.steps;
-            if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                p.colpack[env] = e.colpack;
-                p.goal_dist[env] = e.goal_dist;
-            } else {
-                p.vis[env] = e.vis;
-            }
+            xmode[lane] = mode;
+            xstep[lane] = e.steps;
+            p.reward[env] = rew_out;
+            p.done_out[env] = done_out;
+            p.goal_met[env] = goal_out;
         }
-        p.reward[env] = rew_out;
-        p.done_out[env] = done_out;
-        p.goal_met[env] = goal_out;
+        ZSTAMP(2);
+    } else {
+        // =================================================================== physics wave
+        ZSTAMP(8);
+        if (env < N) {
+            {
+                const double2 qa = p.qa[env], qb = p.qb[env], qc = p.qc[env];
+                const double2 fa = p.fa[env], fb = p.fb[env];
+                e.q0 = qa.x; e.q1 = qa.y; e.q2 = qb.x;
+                e.v0 = qb.y; e.v1 = qc.x; e.v2 = qc.y;
+                e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
+            }
+            const float2 act = reinterpret_cast<const float2 *>(actions)[env];
+            // Engine.step: ctrl = clip(action, ctrlrange); frameskip x mj_step
+            const double c0 = det_clamp((double)act.x, -1.0, 1.0);
+            const double c1 = det_clamp((double)act.y, -1.0, 1.0);
+            ZSTAMP(9);
+            for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
+            emit_obs8(p, e, o);   // o[0] (remaining) is patched after the rendezvous
+        }
+        ZSTAMP(10);
     }
 
-    // ---- the wave's 64 x Z x F float32 tile leaves as one contiguous burst
+    // The one rendezvous of the two waves: the tile rows + per-env mode / step count are in
+    // LDS.  After it the zone wave streams the tile out while the physics wave finishes.
     __syncthreads();
-    const int n_blk = min(kWave, N - env0);
-    flush_tile(tile, p.zone_obs + (size_t)env0 * ZF, n_blk * ZF, lane);
+    if (role == 0) ZSTAMP(4); else ZSTAMP(11);
 
-    // ---- physics (frameskip x mj_step) + the 8-float obs, underneath the draining stores
-    if (env < N) {
-        float o[8];
-        if (zero_obs) {
-            for (int i = 0; i < 8; ++i) o[i] = 0.f;
-        } else {
-            if (run_physics)
-                for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
-            p.q0[env] = e.q0; p.q1[env] = e.q1; p.q2[env] = e.q2;
-            p.v0[env] = e.v0; p.v1[env] = e.v1; p.v2[env] = e.v2;
-            emit_obs8(p, e, o);
+    if (role == 0) {
+        const int n_blk = min(kWave, N - env0);
+        flush_tile(tile, p.zone_obs + (size_t)env0 * ZF, n_blk * ZF, lane);
+        ZSTAMP(3);
+    } else if (env < N) {
+        if (xmode[lane] == 0) {
+            e.steps = xstep[lane];
+            store_dyn(p, env, e);
+            o[0] = (float)(1.0 - div_const((double)e.steps, p.d_steps, p.inv_steps));
+            store_obs8(p, env, o);
+            // fused K3: the action of the NEXT step, from this step's obs and the tile in LDS
+            ZSTAMP(12);
+            if (pol.policy >= 0)
+                reinterpret_cast<float2 *>(pol.out)[env] = scripted_action<TASK, ZT>(pol, env, rows, Z, o);
         }
-        store_obs8(p, env, o);
+        ZSTAMP(13);
     }
 }
 
@@ -522,117 +768,23 @@ __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t
     p.goal_met[env] = 0;
 }
 
-// =========================================================================== K3: policies
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
-{
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-
-template <int TASK>
-__global__ __launch_bounds__(kWave) void k_policy_lane(DevParams p, int policy, uint64_t policy_seed,
-                                                       uint64_t env_index0, uint32_t step_index,
-                                                       float *__restrict__ out)
-{
-    extern __shared__ __align__(16) float tile[];
-    constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
-    const int lane = threadIdx.x;
-    const int env0 = blockIdx.x * kWave;
-    const int env = env0 + lane;
-    const int N = p.N, Z = p.Z, ZF = Z * F;
-
-    if (policy == ZENV_POLICY_UNIFORM) {
-        if (env < N) {
-            const uint64_t gi = env_index0 + (uint64_t)env;
-            uint32_t c[4] = { (uint32_t)gi, (uint32_t)(gi >> 32), step_index, 0u };
-            philox4x32_10(c, (uint32_t)policy_seed, (uint32_t)(policy_seed >> 32));
-            float2 a;
-            a.x = 2.0f * ((float)(c[0] >> 8) * 5.9604644775390625e-08f) - 1.0f;
-            a.y = 2.0f * ((float)(c[1] >> 8) * 5.9604644775390625e-08f) - 1.0f;
-            reinterpret_cast<float2 *>(out)[env] = a;
-        }
-        return;
-    }
-
-    // greedy: stage the wave's zone_obs rows through LDS (coalesced 16 B/lane loads)
-    {
-        const int n_blk = min(kWave, N - env0);
-        const int n_floats = n_blk * ZF, n4 = n_floats >> 2;
-        const float *src = p.zone_obs + (size_t)env0 * ZF;
-        const float4 *s4 = reinterpret_cast<const float4 *>(src);
-        float4 *t4 = reinterpret_cast<float4 *>(tile);
-        for (int i = lane; i < n4; i += kWave) t4[i] = s4[i];
-        for (int i = (n4 << 2) + lane; i < n_floats; i += kWave) tile[i] = src[i];
-    }
-    __syncthreads();
-    if (env >= N) return;
-    const float *rows = tile + lane * ZF;
-    const float4 *ob = reinterpret_cast<const float4 *>(p.obs + (size_t)env * 8);
-    const float4 oa = ob[0], obb = ob[1];
-    const double px = 3.0 * (double)oa.y, py = 3.0 * (double)oa.z;
-    const double hx = (double)oa.w, hy = (double)obb.x;
-
-    int target_colour = -1;
-    if (TASK == ZENV_TASK_COLOUR_MATCH) {
-        int cb = 0, cg = 0, cr = 0;
-        for (int z = 0; z < Z; ++z) {
-            const float *row = rows + z * F;
-            const int col = row[4] != 0.f ? 0 : (row[3] != 0.f ? 1 : 2);
-            cb += col == 0; cg += col == 1; cr += col == 2;
-        }
-        target_colour = 0;
-        int best_cnt = cb;
-        if (cg > best_cnt) { target_colour = 1; best_cnt = cg; }
-        if (cr > best_cnt) { target_colour = 2; }
-    }
-    int best = -1;
-    double bd2 = 0.0, bdx = 0.0, bdy = 0.0;
-    for (int z = 0; z < Z; ++z) {
-        const float *row = rows + z * F;
-        bool eligible;
-        if (TASK == ZENV_TASK_COLOUR_MATCH) {
-            const int col = row[4] != 0.f ? 0 : (row[3] != 0.f ? 1 : 2);
-            eligible = (row[6] == 0.f) && (col != target_colour);
-        } else {
-            eligible = row[2] == 0.f;
-        }
-        const double dx = 3.0 * (double)row[0] - px, dy = 3.0 * (double)row[1] - py;
-        const double d2 = dx * dx + dy * dy;
-        if (eligible && (best < 0 || d2 < bd2)) { best = z; bd2 = d2; bdx = dx; bdy = dy; }
-    }
-    float2 a = make_float2(0.f, 0.f);
-    if (best >= 0 && bd2 > 1e-18) {
-        const double n = sqrt(bd2);
-        const double cs = (hx * bdx + hy * bdy) / n;
-        const double sn = (hx * bdy - hy * bdx) / n;
-        if (cs < 0.0) a.y = sn >= 0.0 ? 1.f : -1.f;
-        else a.y = (float)det_clamp(4.0 * sn, -1.0, 1.0);
-        a.x = cs > 0.8 ? 1.f : 0.f;
-    }
-    reinterpret_cast<float2 *>(out)[env] = a;
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------------------- launchers
 static inline int n_blocks(int n) { return (n + kWave - 1) / kWave; }
 static inline size_t tile_bytes(const DevParams &p) { return (size_t)kWave * p.Z * p.F * sizeof(float); }
+static inline size_t step_lds_bytes(const DevParams &p) { return tile_bytes(p) + 2 * kWave * sizeof(int); }
 
 template <int TASK>
-static void launch_step_task(const DevParams &p, const float *actions, int auto_reset, hipStream_t s,
-                             hipEvent_t ev_start, hipEvent_t ev_stop)
+static void launch_step_task(const DevParams &p, const float *actions, int auto_reset, const StepPolicy &pol,
+                             hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    const dim3 grid(n_blocks(p.N)), block(kWave);
-    const size_t lds = tile_bytes(p);
+    const dim3 grid(n_blocks(p.N)), block(kStepThreads);
+    const size_t lds = step_lds_bytes(p);
     // hipExtLaunchKernelGGL stamps ev_start/ev_stop with the dispatch's own begin/end
-#define ZENV_LAUNCH(ZT) \
-    hipExtLaunchKernelGGL((k_step_lane<TASK, ZT>), grid, block, lds, s, ev_start, ev_stop, 0, p, actions, auto_reset)
+#define ZENV_LAUNCH(ZT)                                                                                 \
+    hipExtLaunchKernelGGL((k_step_lane<TASK, ZT>), grid, block, lds, s, ev_start, ev_stop, 0, p, actions, \
+                          auto_reset, pol)
     switch (p.Z) {
     case 5: ZENV_LAUNCH(5); break;
     case 6: ZENV_LAUNCH(6); break;
@@ -643,13 +795,13 @@ static void launch_step_task(const DevParams &p, const float *actions, int auto_
 #undef ZENV_LAUNCH
 }
 
-hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset, hipStream_t s,
-                       hipEvent_t ev_start, hipEvent_t ev_stop)
+hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset, const StepPolicy &pol,
+                       hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     switch (p.task) {
-    case ZENV_TASK_TSP: launch_step_task<ZENV_TASK_TSP>(p, actions, auto_reset, s, ev_start, ev_stop); break;
-    case ZENV_TASK_TIMED_TSP: launch_step_task<ZENV_TASK_TIMED_TSP>(p, actions, auto_reset, s, ev_start, ev_stop); break;
-    default: launch_step_task<ZENV_TASK_COLOUR_MATCH>(p, actions, auto_reset, s, ev_start, ev_stop); break;
+    case ZENV_TASK_TSP: launch_step_task<ZENV_TASK_TSP>(p, actions, auto_reset, pol, s, ev_start, ev_stop); break;
+    case ZENV_TASK_TIMED_TSP: launch_step_task<ZENV_TASK_TIMED_TSP>(p, actions, auto_reset, pol, s, ev_start, ev_stop); break;
+    default: launch_step_task<ZENV_TASK_COLOUR_MATCH>(p, actions, auto_reset, pol, s, ev_start, ev_stop); break;
     }
     return hipGetLastError();
 }
@@ -671,24 +823,14 @@ hipError_t launch_reset(const DevParams &p, const uint8_t *mask, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_policy(const DevParams &p, int policy, uint64_t policy_seed, uint64_t env_index0,
-                         uint32_t step_index, float *out, hipStream_t s)
+hipError_t launch_policy(const DevParams &p, const StepPolicy &pol, hipStream_t s)
 {
     const dim3 grid(n_blocks(p.N)), block(kWave);
-    const size_t lds = policy == ZENV_POLICY_GREEDY ? tile_bytes(p) : 0;
+    const size_t lds = pol.policy == ZENV_POLICY_GREEDY ? tile_bytes(p) : 0;
     switch (p.task) {
-    case ZENV_TASK_TSP:
-        hipLaunchKernelGGL(k_policy_lane<ZENV_TASK_TSP>, grid, block, lds, s, p, policy, policy_seed,
-                           env_index0, step_index, out);
-        break;
-    case ZENV_TASK_TIMED_TSP:
-        hipLaunchKernelGGL(k_policy_lane<ZENV_TASK_TIMED_TSP>, grid, block, lds, s, p, policy,
-                           policy_seed, env_index0, step_index, out);
-        break;
-    default:
-        hipLaunchKernelGGL(k_policy_lane<ZENV_TASK_COLOUR_MATCH>, grid, block, lds, s, p, policy,
-                           policy_seed, env_index0, step_index, out);
-        break;
+    case ZENV_TASK_TSP: hipLaunchKernelGGL(k_policy_lane<ZENV_TASK_TSP>, grid, block, lds, s, p, pol); break;
+    case ZENV_TASK_TIMED_TSP: hipLaunchKernelGGL(k_policy_lane<ZENV_TASK_TIMED_TSP>, grid, block, lds, s, p, pol); break;
+    default: hipLaunchKernelGGL(k_policy_lane<ZENV_TASK_COLOUR_MATCH>, grid, block, lds, s, p, pol); break;
     }
     return hipGetLastError();
 }

@@ -9,11 +9,21 @@
 
 namespace zenvk {
 
+// Scripted action source: policy < 0 = none.  As an argument of launch_step it asks the step
+// kernel to also write the action of the NEXT step (index step_index) into `out` (fused K3).
+struct StepPolicy {
+    int32_t policy;
+    uint32_t step_index;
+    uint64_t seed;
+    uint64_t env_index0;
+    float *out;
+};
+inline StepPolicy no_policy() { return StepPolicy{ -1, 0u, 0ull, 0ull, nullptr }; }
+
 // ev_start/ev_stop (may be null) receive the step dispatch's own begin/end timestamps
-hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset, hipStream_t s,
-                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset, const StepPolicy &pol,
+                       hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t launch_reset(const DevParams &p, const uint8_t *mask, hipStream_t s);
-hipError_t launch_policy(const DevParams &p, int policy, uint64_t policy_seed, uint64_t env_index0,
-                         uint32_t step_index, float *out, hipStream_t s);
+hipError_t launch_policy(const DevParams &p, const StepPolicy &pol, hipStream_t s);
 
 }  // namespace zenvk

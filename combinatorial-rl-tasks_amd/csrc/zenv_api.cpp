@@ -291,10 +291,9 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
     p.sched_stride = 0;
     const size_t N = n_env, Z = cfg->num_zones, F = p.F;
 
-    want(h, p.q0, N, true); want(h, p.q1, N, true); want(h, p.q2, N, true);
-    want(h, p.v0, N, true); want(h, p.v1, N, true); want(h, p.v2, N, true);
-    want(h, p.x0, N, true); want(h, p.y0, N, true); want(h, p.bq0, N, true); want(h, p.bq3, N, true);
-    want(h, p.zx, Z * N, true); want(h, p.zy, Z * N, true);
+    want(h, p.qa, N, true); want(h, p.qb, N, true); want(h, p.qc, N, true);
+    want(h, p.fa, N, true); want(h, p.fb, N, true);
+    want(h, p.zxy, Z * N, true);
     want(h, p.vis, N, true);
     want(h, p.tmax, Z * N, true);
     want(h, p.colpack, N, true);
@@ -310,6 +309,7 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
     want(h, p.obs, 8 * N, true); want(h, p.zone_obs, Z * F * N, true);
     want(h, p.reward, N, true); want(h, p.actions, 2 * N, true);
     want(h, p.done_out, N, true); want(h, p.goal_met, N, true);
+    want(h, p.dbg, 16 * ((N + 63) / 64), false);
 
     hipError_t err = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (err != hipSuccess) {
@@ -561,7 +561,7 @@ extern "C" int zenv_step(zenv_t *h, const float *actions, int actions_on_device,
                                    hipMemcpyHostToDevice, h->stream));
         }
     }
-    HIP_TRY(launch_step(h->p, d_act, auto_reset, h->stream));
+    HIP_TRY(launch_step(h->p, d_act, auto_reset, no_policy(), h->stream));
     h->step_count += 1;
     return ZENV_OK;
 }
@@ -573,13 +573,14 @@ extern "C" int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t
     if (policy != ZENV_POLICY_UNIFORM && policy != ZENV_POLICY_GREEDY) return fail(ZENV_E_ARG, "unknown policy %d", policy);
     int rc = use_device(h);
     if (rc) return rc;
-    HIP_TRY(launch_policy(h->p, policy, policy_seed, env_index0, (uint32_t)h->step_count,
-                          dst_device ? dst_device : h->p.actions, h->stream));
+    const StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0,
+                          dst_device ? dst_device : h->p.actions };
+    HIP_TRY(launch_policy(h->p, pol, h->stream));
     return ZENV_OK;
 }
 
 extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
-                            int auto_reset, float *ms_total, float *ms_step_kernel)
+                            int auto_reset, int flags, float *ms_total, float *ms_step_kernel)
 {
     if (!h) return fail(ZENV_E_ARG, "null handle");
     if (!h->was_reset) return fail(ZENV_E_STATE, "Environment must be reset before stepping");
@@ -587,6 +588,7 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     if (policy != ZENV_POLICY_UNIFORM && policy != ZENV_POLICY_GREEDY) return fail(ZENV_E_ARG, "unknown policy %d", policy);
     int rc = use_device(h);
     if (rc) return rc;
+    const bool fused = (flags & ZENV_ROLLOUT_UNFUSED) == 0;
     const bool per_kernel = ms_step_kernel != nullptr;
     const size_t need = 2 + (per_kernel ? 2 * (size_t)steps : 0);
     while (h->events.size() < need) {
@@ -596,11 +598,18 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     }
     HIP_TRY(hipEventRecord(h->events[0], h->stream));
     for (int t = 0; t < steps; ++t) {
-        HIP_TRY(launch_policy(h->p, policy, policy_seed, env_index0, (uint32_t)h->step_count, h->p.actions, h->stream));
-        if (per_kernel)
-            HIP_TRY(launch_step(h->p, h->p.actions, auto_reset, h->stream, h->events[2 + 2 * t], h->events[3 + 2 * t]));
-        else
-            HIP_TRY(launch_step(h->p, h->p.actions, auto_reset, h->stream));
+        StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };
+        // a_t = pi(obs_t, t): one stand-alone policy launch per step (unfused) or only before
+        // the first step (fused: every step kernel then leaves a_{t+1} in the action buffer)
+        if (!fused || t == 0) HIP_TRY(launch_policy(h->p, pol, h->stream));
+        StepPolicy next = no_policy();
+        if (fused) {
+            next = pol;
+            next.step_index = (uint32_t)(h->step_count + 1);
+        }
+        hipEvent_t e0 = per_kernel ? h->events[2 + 2 * t] : nullptr;
+        hipEvent_t e1 = per_kernel ? h->events[3 + 2 * t] : nullptr;
+        HIP_TRY(launch_step(h->p, h->p.actions, auto_reset, next, h->stream, e0, e1));
         h->step_count += 1;
     }
     HIP_TRY(hipEventRecord(h->events[1], h->stream));
@@ -640,6 +649,19 @@ extern "C" int zenv_device_ptr(zenv_t *h, int field, void **ptr)
     const FieldInfo f = field_info(h, field);
     if (!f.ptr) return fail(ZENV_E_ARG, "unknown field %d", field);
     *ptr = f.ptr;
+    return ZENV_OK;
+}
+
+// diagnostic: copy the per-block phase stamps of the last step launch (ZENV_STAMPS builds)
+extern "C" int zenv_debug_stamps(zenv_t *h, unsigned long long *dst, int64_t count)
+{
+    if (!h || !dst) return fail(ZENV_E_ARG, "null argument");
+    const int64_t have = 16 * (((int64_t)h->n_env + 63) / 64);
+    if (count != have) return fail(ZENV_E_ARG, "stamp buffer holds %lld entries", (long long)have);
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(dst, h->p.dbg, have * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return ZENV_OK;
 }
 
@@ -713,19 +735,14 @@ extern "C" int zenv_debug_state(zenv_t *h, double *qpos, double *qvel, int32_t *
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t N = h->n_env, Z = h->cfg.num_zones;
     const DevParams &p = h->p;
-    std::vector<double> tmp(N);
-    if (qpos) {
-        const double *src[3] = { p.q0, p.q1, p.q2 };
-        for (int k = 0; k < 3; ++k) {
-            HIP_TRY(hipMemcpy(tmp.data(), src[k], N * 8, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < N; ++i) qpos[3 * i + k] = tmp[i];
-        }
-    }
-    if (qvel) {
-        const double *src[3] = { p.v0, p.v1, p.v2 };
-        for (int k = 0; k < 3; ++k) {
-            HIP_TRY(hipMemcpy(tmp.data(), src[k], N * 8, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < N; ++i) qvel[3 * i + k] = tmp[i];
+    if (qpos || qvel) {
+        std::vector<double2> qa(N), qb(N), qc(N);
+        HIP_TRY(hipMemcpy(qa.data(), p.qa, N * sizeof(double2), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(qb.data(), p.qb, N * sizeof(double2), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(qc.data(), p.qc, N * sizeof(double2), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; ++i) {
+            if (qpos) { qpos[3 * i] = qa[i].x; qpos[3 * i + 1] = qa[i].y; qpos[3 * i + 2] = qb[i].x; }
+            if (qvel) { qvel[3 * i] = qb[i].y; qvel[3 * i + 1] = qc[i].x; qvel[3 * i + 2] = qc[i].y; }
         }
     }
     if (zone_state) {

@@ -152,10 +152,14 @@ int zenv_step(zenv_t *h, const float *actions, int actions_on_device, int auto_r
 /* Scripted action source -> internal action buffer (or dst_device if non-NULL). */
 int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0,
                 float *dst_device);
-/* K closed-loop steps {policy; step} on the handle's stream, HIP-event timed.
- * ms_total: whole loop; ms_step_kernel: sum over the K step-kernel launches only. */
+/* K closed-loop steps a_t = policy(obs_t, t); step(a_t) on the handle's stream, HIP-event
+ * timed.  Default: the step kernel of step t also emits a_{t+1} (fused action source, one
+ * launch per step); ZENV_ROLLOUT_UNFUSED runs the stand-alone policy kernel before every
+ * step instead.  Results are identical.  ms_total: whole loop; ms_step_kernel: sum of the K
+ * step-kernel dispatch durations. */
+#define ZENV_ROLLOUT_UNFUSED 1
 int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
-                 int auto_reset, float *ms_total, float *ms_step_kernel);
+                 int auto_reset, int flags, float *ms_total, float *ms_step_kernel);
 
 /* ---- results ---- */
 int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device);

@@ -1,0 +1,36 @@
+"""Diagnostic: per-phase timeline of the step kernel from in-kernel s_memrealtime stamps.
+Builds a separate -DZENV_STAMPS library (never the shipped one) and prints medians."""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import combinatorial_rl_tasks_amd.build as B
+so = os.path.join(ROOT, "gpurun_out", "libzenv_stamps.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.run([B._hipcc()] + B.FLAGS + ["-DZENV_STAMPS", "-o", so] + [os.path.join(B.CSRC, s) for s in B.SOURCES], check=True)
+import combinatorial_rl_tasks_amd._native as nat
+nat.LIB_PATH = so
+import combinatorial_rl_tasks_amd as Z
+task, zones, keep = {"tsp": (0, 25, .4), "timed": (1, 25, .4), "colour": (2, 6, .55)}[sys.argv[1] if len(sys.argv) > 1 else "tsp"]
+fused = "unfused" not in sys.argv
+n = 65536
+cfg = Z.default_config(task, zones, zones_keepout=keep)
+env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n); env.reset()
+env.rollout(30, Z.POLICY_GREEDY, fused=fused)
+L = nat.lib(); L.zenv_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+acc = []
+for it in range(20):
+    env.rollout(1, Z.POLICY_GREEDY, fused=fused)
+    buf = np.zeros((n // 64, 16), np.uint64)
+    nat.check(L.zenv_debug_stamps(env._h, buf.ctypes.data, buf.size))
+    acc.append(buf.astype(np.int64))
+a = np.stack(acc)                       # [it, block, slot], 10 ns ticks
+t0 = a[:, :, [0, 8]].min(axis=(1, 2), keepdims=True)   # first wave start of the launch
+rel = (a - t0) * 0.01                   # us
+names = {0: "Z start", 1: "Z loads landed (pose ready)", 2: "Z zone pass done", 3: "Z flush issued",
+         4: "Z past barrier", 8: "P start", 9: "P loads landed", 10: "P physics done", 11: "P past barrier",
+         12: "P obs8 stored", 13: "P end"}
+print(sys.argv[1:], "fused" if fused else "unfused")
+for k, v in names.items():
+    x = rel[:, :, k]
+    print(f"{v:32s} median {np.median(x):7.2f}  p10 {np.percentile(x,10):7.2f}  p90 {np.percentile(x,90):7.2f}  max {x.max():7.2f} us")

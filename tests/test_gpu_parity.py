@@ -81,8 +81,10 @@ def test_policy_kernels_match_oracle(zenv_mod, oracle_mod, task):
     env.close()
 
 
-@pytest.mark.parametrize("task,zones,keepout", [(0, 25, 0.40), (1, 25, 0.40), (2, 6, 0.55), (0, 5, 0.55)])
-def test_closed_loop_rollout_matches_oracle(zenv_mod, oracle_mod, task, zones, keepout):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("task,zones,keepout", [(0, 25, 0.40), (1, 25, 0.40), (2, 6, 0.55), (0, 5, 0.55),
+                                                (1, 7, 0.55)])
+def test_closed_loop_rollout_matches_oracle(zenv_mod, oracle_mod, task, zones, keepout, fused):
     """Device-resident closed loop (policy kernel + step kernel, auto-reset onto fresh seeds)
     against the oracle's batch driver: BASELINE.json configs 1-3 at reduced N."""
     Z, O = zenv_mod, oracle_mod
@@ -94,7 +96,7 @@ def test_closed_loop_rollout_matches_oracle(zenv_mod, oracle_mod, task, zones, k
     env.build_bank(1, 16 * stride)
     env.schedule_sequential(stride=stride)
     env.reset()
-    env.rollout(T, Z.POLICY_GREEDY, policy_seed=11, env_index0=0, auto_reset=True)
+    env.rollout(T, Z.POLICY_GREEDY, policy_seed=11, env_index0=0, auto_reset=True, fused=fused)
     ocfg = oracle_config_from(O, cfg)
     ref = O.rollout(ocfg, np.arange(1, 1 + n), T, O.POLICY_GREEDY, seed_stride=stride,
                     policy_seed=11, n_threads=8)
@@ -115,7 +117,8 @@ def test_uniform_policy_rollout(zenv_mod, oracle_mod):
     env.build_bank(EVAL_SEED0, n)
     env.schedule_sequential()
     env.reset()
-    env.rollout(T, Z.POLICY_UNIFORM, policy_seed=0x5EED, env_index0=123, auto_reset=True)
+    env.rollout(T // 2, Z.POLICY_UNIFORM, policy_seed=0x5EED, env_index0=123, auto_reset=True, fused=True)
+    env.rollout(T - T // 2, Z.POLICY_UNIFORM, policy_seed=0x5EED, env_index0=123, auto_reset=True, fused=False)
     ref = O.rollout(oracle_config_from(O, cfg), np.arange(EVAL_SEED0, EVAL_SEED0 + n), T,
                     O.POLICY_UNIFORM, policy_seed=0x5EED, env_index0=123, n_threads=8)
     assert np.array_equal(env.get(Z.F_OBS), ref["obs"])
