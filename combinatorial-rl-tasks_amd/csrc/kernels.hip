@@ -1,17 +1,18 @@
 // kernels.hip -- gfx950 (CDNA4, wave64) kernels of the batched zone-env hot path.
 //
-// K1  k_step_lane<TASK>   one env.step() for every env (TSP_env.py:45-72, TTSP_env.py:62-71,
-//                         colour_match_env.py:86-123, ZoneEnvBase.py:143-235 + the not-vendored
-//                         Engine.step / mj_step of xmls/point.xml), with the ParallelEnv
-//                         auto-reset of penv.py:8-11 fused in.
-// K2  k_reset_lane<TASK>  masked re-init from the HBM layout bank (Engine.reset).
-// K3  k_policy_lane<TASK> scripted action sources (the build's own).
+// K1  k_step_lane<TASK,ZT>  one env.step() for every env (TSP_env.py:45-72, TTSP_env.py:62-71,
+//                           colour_match_env.py:86-123, ZoneEnvBase.py:143-235 + the not-vendored
+//                           Engine.step / mj_step of xmls/point.xml), with the ParallelEnv
+//                           auto-reset of penv.py:8-11 and (optionally) the scripted action
+//                           source of the next step fused in.
+// K2  k_reset_lane<TASK>    masked re-init from the HBM layout bank (Engine.reset).
+// K3  k_policy_lane<TASK>   stand-alone scripted action sources (the build's own).
 //
-// Execution shape (lane-per-env): a 64-thread workgroup = one wave64 owns 64 consecutive
-// envs; lane i holds env i's dynamics in registers and streams the zone-major SoA zone
-// arrays (512 B fully-coalesced loads).  The (N,Z,F) float32 zone_obs rows are built in an
-// LDS tile [64][Z*F] and leave as one contiguous 64*Z*F*4-byte burst of dwordx4 stores.
-// No MFMA: there is no contraction anywhere on this path; the bound is HBM bytes.
+// Execution shape: a tile = 64 consecutive envs, lane i <-> env i.  State is struct-of-arrays
+// in 16-byte pairs (1 KiB per wave load), zone arrays are zone-major.  The (N,Z,F) float32
+// zone_obs rows are staged in LDS as compact 16-byte (x/3, y/3, code, aux) entries and expanded
+// to their F floats while they stream out as contiguous dwordx4 bursts.
+// No MFMA: there is no contraction anywhere on this path; the bound is memory bytes.
 // Build with -ffp-contract=off: the float64 state must match the CPU oracle bit for bit.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -25,6 +26,24 @@ namespace zenvk {
 namespace {
 
 constexpr int kWave = 64;
+
+// Diagnostic build only (-DZENV_STAMPS, never shipped): lane 0 of each wave drops
+// s_memrealtime (100 MHz) stamps into p.dbg[block][16] at phase boundaries.
+#ifdef ZENV_STAMPS
+#define ZSTAMP(slot)                                                                                        \
+    do {                                                                                                    \
+        if (p.dbg && lane == 0) p.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define ZSTAMP(slot) do { } while (0)
+#endif
+
+template <int TASK>
+struct TaskTraits {
+    static constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;        // floats per zone row
+    static constexpr int RPC = (F == 6) ? 2 : 4;                     // rows per flush chunk
+    static constexpr int G = RPC * F / 4;                            // float4 per flush chunk
+};
 
 // ---------------------------------------------------------------------------- small helpers
 __device__ __forceinline__ int hamming_to_goal(uint64_t colpack, int Z)
@@ -51,7 +70,7 @@ __device__ __forceinline__ void pcg_step_dev(uint64_t &hi, uint64_t &lo, uint64_
     lo = nlo;
 }
 
-__device__ uint32_t pcg_next32_dev(const DevParams &p, int env)
+__device__ __forceinline__ uint32_t pcg_next32_dev(const DevParams &p, int env)
 {
     uint32_t *buf = p.pcg_buf + 2 * (size_t)env;
     if (buf[0]) {
@@ -71,12 +90,13 @@ __device__ uint32_t pcg_next32_dev(const DevParams &p, int env)
     return (uint32_t)out;
 }
 
-__device__ int next_bank_slot(const DevParams &p, int env)
+// Bank slot of env's next episode (and advance the schedule).  episode index / first slot are
+// passed in when the caller has already loaded them.
+__device__ __forceinline__ int next_bank_slot(const DevParams &p, int env, int k, int first)
 {
-    const int k = p.episode_idx[env];
     p.episode_idx[env] = k + 1;
     if (p.sched_mode == SCHED_SEQUENTIAL) {
-        const long long s = (long long)p.slot_first[env] + (long long)k * (long long)p.sched_stride;
+        const long long s = (long long)first + (long long)k * (long long)p.sched_stride;
         return (int)(s % (long long)p.bank_size);
     }
     // wrappers.py:20-23: rng.integers(min_seed, max_seed + 1) -- Lemire on 32-bit draws
@@ -94,7 +114,22 @@ __device__ int next_bank_slot(const DevParams &p, int env)
     }
     return (int)(m >> 32);
 }
+__device__ __forceinline__ int next_bank_slot(const DevParams &p, int env)
+{
+    return next_bank_slot(p, env, p.episode_idx[env], p.slot_first[env]);
+}
 
+// bit i of x -> bit 2i of the result
+__device__ __forceinline__ uint64_t spread_even_bits(uint32_t x32)
+{
+    uint64_t x = x32;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
 
 // a / b for a divisor known on the host, b = 3, 1.5 or a positive integer < 2^31, with
 // inv_b = RN(1/b): q1 = RN(a*inv_b); r = a - b*q1 (exact in one fma); q = RN(q1 + r*inv_b).
@@ -178,44 +213,73 @@ __device__ __forceinline__ void store_obs8(const DevParams &p, int env, const fl
     dst[1] = make_float4(o[4], o[5], o[6], o[7]);
 }
 
-// One zone row of 'zone_obs' (TSP_env.py:31-35, TTSP_env.py:86-92, colour_match_env.py:75-80)
+// ---------------------------------------------------------------------------- zone rows
+// One zone of one env as it sits in LDS: (x/3, y/3, code, aux), 16 bytes.
+//   TSP / TimedTSP: code = visited ? 1 : 0, aux = the time feature (TimedTSP);
+//   ColourMatch:    code = colour 0 Blue / 1 Green / 2 Red, aux = cooldown / max_cd;
+//   code < 0:       an all-zero row (finished env stepped without auto-reset).
+// expand_entry() turns it into the reference's row (TSP_env.py:31-35, TTSP_env.py:86-92,
+// colour_match_env.py:75-80; colours ZoneEnvBase.py:68-77).
 template <int TASK>
-__device__ __forceinline__ void write_row(const DevParams &p, float *row, double zx, double zy,
-                                          int flag_or_colour, int aux, int k)
+__device__ __forceinline__ float4 make_entry(const DevParams &p, double zx, double zy, int code, int aux, int k)
 {
-    const float fx = (float)div_const(zx, 3.0, p.inv3);
-    const float fy = (float)div_const(zy, 3.0, p.inv3);
+    float4 en;
+    en.x = (float)div_const(zx, 3.0, p.inv3);
+    en.y = (float)div_const(zy, 3.0, p.inv3);
+    en.z = (float)code;
+    en.w = 0.f;
+    if (TASK == ZENV_TASK_COLOUR_MATCH) en.w = (float)div_const((double)(float)aux, p.d_maxcd, p.inv_maxcd);
+    if (TASK == ZENV_TASK_TIMED_TSP)
+        en.w = code ? 1.f : (float)div_const((double)(aux - k), p.d_steps, p.inv_steps);
+    return en;
+}
+
+template <int TASK>
+__device__ __forceinline__ void expand_entry(const float4 en, float *row)
+{
+    const bool zero = en.z < 0.f;
     if (TASK == ZENV_TASK_COLOUR_MATCH) {
-        row[0] = fx;
-        row[1] = fy;
-        row[2] = flag_or_colour == 2 ? 1.f : 0.f;
-        row[3] = flag_or_colour == 1 ? 1.f : 0.f;
-        row[4] = flag_or_colour == 0 ? 1.f : 0.f;
-        row[5] = 0.25f;
-        row[6] = (float)div_const((double)(float)aux, p.d_maxcd, p.inv_maxcd);
-    } else if (TASK == ZENV_TASK_TIMED_TSP) {
-        row[0] = fx;
-        row[1] = fy;
-        row[2] = flag_or_colour ? 1.f : 0.f;
-        row[3] = 1.f;
-        row[4] = flag_or_colour ? 0.f : 1.f;
-        row[5] = 0.25f;
-        row[6] = flag_or_colour ? 1.f : (float)div_const((double)(aux - k), p.d_steps, p.inv_steps);
+        row[0] = en.x;
+        row[1] = en.y;
+        row[2] = en.z == 2.f ? 1.f : 0.f;
+        row[3] = en.z == 1.f ? 1.f : 0.f;
+        row[4] = en.z == 0.f ? 1.f : 0.f;
+        row[5] = zero ? 0.f : 0.25f;
+        row[6] = en.w;
     } else {
-        // 24-byte rows: three 8-byte stores (ds_write_b64 when `row` is the LDS tile)
-        float2 *r2 = reinterpret_cast<float2 *>(row);
-        r2[0] = make_float2(fx, fy);
-        r2[1] = make_float2(flag_or_colour ? 1.f : 0.f, 1.f);
-        r2[2] = make_float2(flag_or_colour ? 0.f : 1.f, 0.25f);
+        row[0] = en.x;
+        row[1] = en.y;
+        row[2] = en.z > 0.f ? 1.f : 0.f;
+        row[3] = zero ? 0.f : 1.f;
+        row[4] = en.z == 0.f ? 1.f : 0.f;
+        row[5] = zero ? 0.f : 0.25f;
+        if (TASK == ZENV_TASK_TIMED_TSP) row[6] = en.w;
     }
 }
 
-// Engine.reset for one env from bank slot `slot`: writes the SoA zone arrays, the lane's
-// registers and the env's zone_obs rows (rows may point to LDS or to global memory).
-template <int TASK>
-__device__ void reset_env(const DevParams &p, int env, int slot, EnvRegs &e, float *rows)
+// where reset_env / the zone pass put a zone: the LDS entry array, or expanded rows in HBM
+struct EntrySink {
+    float4 *ents;   // this env's [Z] entries
+    template <int TASK>
+    __device__ __forceinline__ void put(int z, const float4 en) const { ents[z] = en; }
+};
+struct GlobalRowSink {
+    float *rows;    // this env's [Z][F] rows
+    template <int TASK>
+    __device__ __forceinline__ void put(int z, const float4 en) const
+    {
+        float r[7];
+        expand_entry<TASK>(en, r);
+        for (int f = 0; f < TaskTraits<TASK>::F; ++f) rows[z * TaskTraits<TASK>::F + f] = r[f];
+    }
+};
+
+// Engine.reset for one env from bank slot `slot`: writes the zone arrays, the lane's registers
+// and the env's zone rows / entries.
+template <int TASK, typename Sink>
+__device__ __forceinline__ void reset_env(const DevParams &p, int env, int slot, EnvRegs &e, const Sink &sink)
 {
-    const int Z = p.Z, N = p.N, F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
+    const int Z = p.Z, N = p.N;
     const double *br = p.bank_robot + 4 * (size_t)slot;
     e.x0 = br[0]; e.y0 = br[1]; e.bq0 = br[2]; e.bq3 = br[3];
     e.q0 = e.q1 = e.q2 = 0.0;
@@ -230,16 +294,16 @@ __device__ void reset_env(const DevParams &p, int env, int slot, EnvRegs &e, flo
         const double zx = bz[2 * z], zy = bz[2 * z + 1];
         const size_t zi = (size_t)z * N + env;
         p.zxy[zi] = make_double2(zx, zy);
-        int flag = 0, aux = 0;
+        int code = 0, aux = 0;
         if (TASK == ZENV_TASK_TIMED_TSP) {
             aux = ba[z];
             p.tmax[zi] = aux;
         } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
-            flag = ba[z];
-            e.colpack |= (uint64_t)flag << (2 * z);
+            code = ba[z];
+            e.colpack |= (uint64_t)code << (2 * z);
             p.cooldown[zi] = 0;
         }
-        write_row<TASK>(p, rows + z * F, zx, zy, flag, aux, 0);
+        sink.template put<TASK>(z, make_entry<TASK>(p, zx, zy, code, aux, 0));
     }
     if (TASK == ZENV_TASK_COLOUR_MATCH) e.goal_dist = hamming_to_goal(e.colpack, Z);
     p.seed[env] = p.bank_seed[slot];
@@ -258,11 +322,8 @@ __device__ __forceinline__ void store_frame(const DevParams &p, int env, const E
     p.fb[env] = make_double2(e.bq0, e.bq3);
 }
 
-__device__ __forceinline__ void store_regs(const DevParams &p, int env, int task, const EnvRegs &e,
-                                           bool frame_too)
+__device__ __forceinline__ void store_counters(const DevParams &p, int env, int task, const EnvRegs &e)
 {
-    store_dyn(p, env, e);
-    if (frame_too) store_frame(p, env, e);
     p.steps[env] = e.steps;
     if (task == ZENV_TASK_COLOUR_MATCH) {
         p.colpack[env] = e.colpack;
@@ -301,20 +362,73 @@ __device__ __forceinline__ void mj_substep(const DevParams &p, EnvRegs &e, doubl
     e.q2 = e.q2 + p.h * e.v2;
 }
 
-// Contiguous LDS tile -> HBM burst: [n_env_blk][ZF] floats, 16 B per lane per store
-__device__ __forceinline__ void flush_tile(const float *tile, float *dst, int n_floats, int lane)
+__device__ __forceinline__ void wave_lds_fence()
 {
-    const int n4 = n_floats >> 2;
-    const float4 *s4 = reinterpret_cast<const float4 *>(tile);
+    // Cross-lane hand-off through LDS inside ONE wave.  The LDS executes a wave's instructions
+    // in order, so program order is all that is needed: stop the compiler from moving LDS
+    // accesses across this point, and emit no s_waitcnt (a fence builtin would also drain the
+    // wave's outstanding global stores here, once per flush iteration).
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Expand the wave's n_rows compact entries into their F floats and stream them to `dst`
+// (the tile's contiguous [n_rows][F] block of zone_obs) as dwordx4 bursts.  Each lane
+// expands RPC consecutive rows = G whole float4 into the wave-private staging slab, which
+// is then read back lane-linear so that one store instruction covers 1 KiB of contiguous HBM.
+template <int TASK>
+__device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage, float *dst, int n_rows,
+                                              int lane)
+{
+    constexpr int F = TaskTraits<TASK>::F, RPC = TaskTraits<TASK>::RPC, G = TaskTraits<TASK>::G;
+    const int n_chunks = n_rows / RPC;
     float4 *d4 = reinterpret_cast<float4 *>(dst);
-    int i = lane;
-    // four ds_read_b128 in flight per lane before the four dwordx4 stores
-    for (; i + 3 * kWave < n4; i += 4 * kWave) {
-        const float4 a = s4[i], b = s4[i + kWave], c = s4[i + 2 * kWave], d = s4[i + 3 * kWave];
-        d4[i] = a; d4[i + kWave] = b; d4[i + 2 * kWave] = c; d4[i + 3 * kWave] = d;
+    int c0 = 0;
+    // full iterations: 64 chunks = 64*G float4, no guards
+    for (; c0 + kWave <= n_chunks; c0 += kWave) {
+        const int c = c0 + lane;
+        float v[RPC * F];
+#pragma unroll
+        for (int j = 0; j < RPC; ++j) expand_entry<TASK>(ents[c * RPC + j], v + j * F);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            stage[lane * G + g] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        wave_lds_fence();
+        float4 t[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) t[g] = stage[g * kWave + lane];
+#pragma unroll
+        for (int g = 0; g < G; ++g) d4[(size_t)c0 * G + g * kWave + lane] = t[g];
+        wave_lds_fence();
     }
-    for (; i < n4; i += kWave) d4[i] = s4[i];
-    for (int j = (n4 << 2) + lane; j < n_floats; j += kWave) dst[j] = tile[j];
+    // last, partial iteration
+    if (c0 < n_chunks) {
+        const int c = c0 + lane;
+        if (c < n_chunks) {
+            float v[RPC * F];
+#pragma unroll
+            for (int j = 0; j < RPC; ++j) expand_entry<TASK>(ents[c * RPC + j], v + j * F);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                stage[lane * G + g] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        }
+        wave_lds_fence();
+        const int n4 = (n_chunks - c0) * G;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i = g * kWave + lane;
+            if (i < n4) d4[(size_t)c0 * G + i] = stage[i];
+        }
+        wave_lds_fence();
+    }
+    // ragged tail (n_rows not a multiple of RPC): one row per lane, scalar stores
+    const int r = n_chunks * RPC + lane;
+    if (r < n_rows) {
+        float v[F];
+        expand_entry<TASK>(ents[r], v);
+        for (int f = 0; f < F; ++f) dst[(size_t)r * F + f] = v[f];
+    }
 }
 
 // =========================================================================== K3: policies
@@ -342,13 +456,51 @@ __device__ __forceinline__ float2 uniform_action(uint64_t global_env, uint32_t s
     return a;
 }
 
-// Steer towards the nearest eligible zone.  rows: this env's [Z][F] float32 zone_obs rows
-// (LDS or global); (opx, opy, ohx, ohy) = obs[1..4].
-template <int TASK, int ZT = 0>
-__device__ __forceinline__ float2 greedy_action(const float *rows, int Zrt, float opx, float opy, float ohx,
+// What the greedy policy reads of a zone row: (x/3, y/3, colour or visited flag, aux column)
+struct ZoneView {
+    float x, y;
+    int code;     // TSP/Timed: 1 = visited; ColourMatch: colour 0/1/2
+    float aux;    // row[6]
+};
+template <int TASK>
+struct FullRows {      // the reference layout [Z][F] (global zone_obs or an LDS copy of it)
+    const float *rows;
+    __device__ __forceinline__ ZoneView get(int z) const
+    {
+        constexpr int F = TaskTraits<TASK>::F;
+        const float *row = rows + z * F;
+        ZoneView v;
+        v.x = row[0];
+        v.y = row[1];
+        if (TASK == ZENV_TASK_COLOUR_MATCH) v.code = row[4] != 0.f ? 0 : (row[3] != 0.f ? 1 : 2);
+        else v.code = row[2] == 0.f ? 0 : 1;
+        v.aux = F == 7 ? row[F - 1] : 0.f;
+        return v;
+    }
+};
+template <int TASK>
+struct EntryRows {     // compact LDS entries
+    const float4 *ents;
+    __device__ __forceinline__ ZoneView get(int z) const
+    {
+        const float4 en = ents[z];
+        ZoneView v;
+        v.x = en.x;
+        v.y = en.y;
+        // an all-zero row (code < 0) reads like the reference row of zeros: TSP "unvisited",
+        // ColourMatch "Red" (row[4] == row[3] == 0)
+        if (TASK == ZENV_TASK_COLOUR_MATCH) v.code = en.z < 0.f ? 2 : (int)en.z;
+        else v.code = en.z > 0.f ? 1 : 0;
+        v.aux = en.w;
+        return v;
+    }
+};
+
+// Steer towards the nearest eligible zone; (opx, opy, ohx, ohy) = obs[1..4].
+template <int TASK, int ZT, typename Rows>
+__device__ __forceinline__ float2 greedy_action(const Rows rows, int Zrt, float opx, float opy, float ohx,
                                                 float ohy)
 {
-    constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
     const int Z = ZT > 0 ? ZT : Zrt;
     const double px = 3.0 * (double)opx, py = 3.0 * (double)opy;
     const double hx = (double)ohx, hy = (double)ohy;
@@ -357,8 +509,7 @@ __device__ __forceinline__ float2 greedy_action(const float *rows, int Zrt, floa
         int cb = 0, cg = 0, cr = 0;
 #pragma unroll
         for (int z = 0; z < Z; ++z) {
-            const float *row = rows + z * F;
-            const int col = row[4] != 0.f ? 0 : (row[3] != 0.f ? 1 : 2);
+            const int col = rows.get(z).code;
             cb += col == 0; cg += col == 1; cr += col == 2;
         }
         target_colour = 0;
@@ -377,15 +528,10 @@ __device__ __forceinline__ float2 greedy_action(const float *rows, int Zrt, floa
         int idx[ZP];
 #pragma unroll
         for (int z = 0; z < ZP; ++z) {
-            const float *row = rows + z * F;
-            bool eligible;
-            if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                const int col = row[4] != 0.f ? 0 : (row[3] != 0.f ? 1 : 2);
-                eligible = (row[6] == 0.f) && (col != target_colour);
-            } else {
-                eligible = row[2] == 0.f;
-            }
-            const double dx = 3.0 * (double)row[0] - px, dy = 3.0 * (double)row[1] - py;
+            const ZoneView v = rows.get(z);
+            const bool eligible = (TASK == ZENV_TASK_COLOUR_MATCH) ? (v.aux == 0.f && v.code != target_colour)
+                                                                    : (v.code == 0);
+            const double dx = 3.0 * (double)v.x - px, dy = 3.0 * (double)v.y - py;
             const double d2 = dx * dx + dy * dy;
             d2s[z] = eligible ? d2 : __builtin_inf();
             idx[z] = z;
@@ -402,22 +548,17 @@ __device__ __forceinline__ float2 greedy_action(const float *rows, int Zrt, floa
         }
         if (d2s[0] < __builtin_inf()) {
             best = idx[0];
-            const float *row = rows + best * F;
-            bdx = 3.0 * (double)row[0] - px;
-            bdy = 3.0 * (double)row[1] - py;
+            const ZoneView v = rows.get(best);
+            bdx = 3.0 * (double)v.x - px;
+            bdy = 3.0 * (double)v.y - py;
             bd2 = bdx * bdx + bdy * bdy;
         }
     } else {
         for (int z = 0; z < Z; ++z) {
-            const float *row = rows + z * F;
-            bool eligible;
-            if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                const int col = row[4] != 0.f ? 0 : (row[3] != 0.f ? 1 : 2);
-                eligible = (row[6] == 0.f) && (col != target_colour);
-            } else {
-                eligible = row[2] == 0.f;
-            }
-            const double dx = 3.0 * (double)row[0] - px, dy = 3.0 * (double)row[1] - py;
+            const ZoneView v = rows.get(z);
+            const bool eligible = (TASK == ZENV_TASK_COLOUR_MATCH) ? (v.aux == 0.f && v.code != target_colour)
+                                                                    : (v.code == 0);
+            const double dx = 3.0 * (double)v.x - px, dy = 3.0 * (double)v.y - py;
             const double d2 = dx * dx + dy * dy;
             if (eligible && (best < 0 || d2 < bd2)) { best = z; bd2 = d2; bdx = dx; bdy = dy; }
         }
@@ -435,19 +576,19 @@ __device__ __forceinline__ float2 greedy_action(const float *rows, int Zrt, floa
 }
 
 template <int TASK, int ZT>
-__device__ __forceinline__ float2 scripted_action(const StepPolicy &pol, int env, const float *rows, int Z,
+__device__ __forceinline__ float2 scripted_action(const StepPolicy &pol, int env, const float4 *ents, int Z,
                                                   const float *o)
 {
     if (pol.policy == ZENV_POLICY_UNIFORM)
         return uniform_action(pol.env_index0 + (uint64_t)env, pol.step_index, pol.seed);
-    return greedy_action<TASK, ZT>(rows, Z, o[1], o[2], o[3], o[4]);
+    return greedy_action<TASK, ZT>(EntryRows<TASK>{ ents }, Z, o[1], o[2], o[3], o[4]);
 }
 
 template <int TASK>
 __global__ __launch_bounds__(kWave) void k_policy_lane(DevParams p, StepPolicy pol)
 {
     extern __shared__ __align__(16) float tile[];
-    constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
+    constexpr int F = TaskTraits<TASK>::F;
     const int lane = threadIdx.x;
     const int env0 = blockIdx.x * kWave;
     const int env = env0 + lane;
@@ -473,48 +614,39 @@ __global__ __launch_bounds__(kWave) void k_policy_lane(DevParams p, StepPolicy p
     if (env >= N) return;
     const float4 *ob = reinterpret_cast<const float4 *>(p.obs + (size_t)env * 8);
     const float4 oa = ob[0], obb = ob[1];
-    reinterpret_cast<float2 *>(pol.out)[env] = greedy_action<TASK>(tile + lane * ZF, Z, oa.y, oa.z, oa.w, obb.x);
+    reinterpret_cast<float2 *>(pol.out)[env] =
+        greedy_action<TASK, 0>(FullRows<TASK>{ tile + lane * ZF }, Z, oa.y, oa.z, oa.w, obb.x);
 }
 
 // =========================================================================== K1: step
 // A 128-thread workgroup (two wave64) owns a tile of 64 consecutive envs, lane i <-> env i in
 // BOTH waves, with the work split by what it is bound by:
-//   wave 0, "zone wave"   (memory):  streams the zone-major zone arrays, runs set_mocaps(),
+//   wave 0, "zone wave"   (memory):  streams the zone-major zone array, runs set_mocaps(),
 //       reward / goal / termination / auto-reset (none of which needs this step's physics:
-//       set_mocaps() sees the PRE-physics pose), builds the 64 x Z x F float32 tile in LDS
-//       and flushes it as one contiguous burst of dwordx4 stores;
-//   wave 1, "physics wave" (latency): the 10 serial MuJoCo substeps and the 8-float obs.
-// The two meet once (one s_barrier): the zone wave tells the physics wave per env whether
-// its result is observable (mode 0) or superseded by a reset / masked no-op (mode 1) and
-// what the new step count is.  On different SIMDs the ~5 us serial fp64 chain of the physics
-// wave runs underneath the zone wave's load->LDS->store stream instead of after it.
+//       set_mocaps() sees the PRE-physics pose), leaves one 16-byte entry per zone in LDS and,
+//       after the rendezvous, expands + flushes the 64 x Z x F float32 tile as dwordx4 bursts;
+//   wave 1, "physics wave" (latency): the 10 serial MuJoCo substeps, the 8-float obs and, when
+//       asked, the scripted action of the NEXT step from that obs and the LDS entries.
+// The two meet once (one s_barrier): the zone wave tells the physics wave per env whether its
+// result is observable (mode 0) or superseded by a reset / masked no-op (mode 1) and what the
+// new step count is.  On different SIMDs the serial fp64 chain of the physics wave runs
+// underneath the zone wave's load -> LDS -> store stream instead of after it.
 //
-// ZT > 0: zone count known at compile time -> the zone loop is fully unrolled and every
-// zone load of the wave (2*Z x 512 B, + Z x 256 B tmax / Z x 64 B cooldown) is issued up
-// front.  ZT == 0: generic runtime-Z fallback with the loads inside the loop.
+// ZT > 0: zone count known at compile time -> the zone loop is fully unrolled and every zone
+// load of the wave (Z x 1 KiB, + Z x 256 B tmax / Z x 64 B cooldown) is issued up front, in
+// consumption order.  ZT == 0: generic runtime-Z fallback with the loads inside the loop.
 constexpr int kStepThreads = 2 * kWave;
-
-// Diagnostic build only (-DZENV_STAMPS, never shipped): lane 0 of each wave drops
-// s_memrealtime (100 MHz) stamps into p.dbg[block][16] at phase boundaries.
-#ifdef ZENV_STAMPS
-#define ZSTAMP(slot)                                                                      \
-    do {                                                                                  \
-        if (p.dbg && lane == 0) p.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#else
-#define ZSTAMP(slot) do { } while (0)
-#endif
 
 // amdgpu_waves_per_eu(2, 2): the grid needs exactly two waves per SIMD (4 tiles x 2 waves per
 // CU), so the scheduler may spend up to 256 VGPRs to keep every zone load in flight at once
 // instead of sinking loads to save registers for an occupancy the launch never uses.
 template <int TASK, int ZT>
 __global__ __launch_bounds__(kStepThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_step_lane(DevParams p, const float *__restrict__ actions,
-                                                            int auto_reset, StepPolicy pol)
+void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset, StepPolicy pol)
 {
-    extern __shared__ __align__(16) float tile[];
-    constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
+    extern __shared__ __align__(16) float4 lds4[];
+    constexpr int F = TaskTraits<TASK>::F;
+    constexpr int G = TaskTraits<TASK>::G;
     constexpr int ZR = ZT > 0 ? ZT : 1;
     const int lane = threadIdx.x & (kWave - 1);
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
@@ -522,10 +654,11 @@ void k_step_lane(DevParams p, const float *__restrict__ actions,
     const int env = env0 + lane;
     const int N = p.N;
     const int Z = ZT > 0 ? ZT : p.Z;
-    const int ZF = Z * F;
-    float *rows = tile + lane * ZF;
-    int *xmode = reinterpret_cast<int *>(tile + kWave * ZF);   // zone wave -> physics wave
+    float4 *ents = lds4;                                  // [64][Z] compact entries
+    float4 *stage = lds4 + kWave * Z;                     // [64*G]  flush staging slab
+    int *xmode = reinterpret_cast<int *>(stage + kWave * G);   // zone wave -> physics wave
     int *xstep = xmode + kWave;
+    float4 *my_ents = ents + lane * Z;
 
     EnvRegs e;
     e.steps = 0;
@@ -534,9 +667,15 @@ void k_step_lane(DevParams p, const float *__restrict__ actions,
     if (role == 0) {
         // =================================================================== zone wave
         ZSTAMP(0);
-        if (env < N) {
+        const bool valid = env < N;
+        uint8_t was_done = 0;
+        double ep_ret = 0.0;
+        double zxr[ZR], zyr[ZR];
+        int auxr[ZR];
+        int epi_idx = 0, slot_first = 0;
+        if (valid) {
             // ---- issue every load of this env first
-            const uint8_t was_done = p.done_state[env];
+            was_done = p.done_state[env];
             {
                 const double2 qa = p.qa[env], fa = p.fa[env], fb = p.fb[env];
                 e.q0 = qa.x; e.q1 = qa.y;
@@ -550,9 +689,9 @@ void k_step_lane(DevParams p, const float *__restrict__ actions,
             } else {
                 e.vis = p.vis[env];
             }
-            double ep_ret = p.ep_return[env];
-            double zxr[ZR], zyr[ZR];
-            int auxr[ZR];
+            ep_ret = p.ep_return[env];
+            epi_idx = p.episode_idx[env];     // the bank slot of a reset is known before it happens
+            slot_first = p.slot_first[env];
             if (ZT > 0) {
                 // issue order = consumption order: pose first, then zone 0, 1, ... so the
                 // in-order vmcnt waits of the zone pass release one zone at a time
@@ -570,127 +709,173 @@ void k_step_lane(DevParams p, const float *__restrict__ actions,
                 // nothing below may be scheduled above this point, nor any load below it
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
 
-            float rew_out = 0.f;
-            uint8_t done_out = 1, goal_out = 0;
-            int mode = 1;
-            if (was_done) {
-                // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
-                for (int i = 0; i < ZF; ++i) rows[i] = 0.f;
-                for (int i = 0; i < 8; ++i) o[i] = 0.f;
-                store_obs8(p, env, o);
-                if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = make_float2(0.f, 0.f);
-            } else {
-                const int k = e.steps + 1;   // step index after this call
-                double rx, ry;               // pre-physics pose: what set_mocaps() sees
-                world_pos(e, rx, ry);
-                ZSTAMP(1);
+        float rew_out = 0.f;
+        uint8_t done_out = 1, goal_out = 0;
+        int mode = 1;
+        bool need_reset = false;
+        if (valid && was_done) {
+            // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
+            for (int z = 0; z < Z; ++z) my_ents[z] = make_float4(0.f, 0.f, -1.f, 0.f);
+            for (int i = 0; i < 8; ++i) o[i] = 0.f;
+            store_obs8(p, env, o);
+            if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = make_float2(0.f, 0.f);
+        } else if (valid) {
+            const int k = e.steps + 1;   // step index after this call
+            double rx, ry;               // pre-physics pose: what set_mocaps() sees
+            world_pos(e, rx, ry);
+            ZSTAMP(1);
 
-                // ---- zone pass: set_mocaps() of the first substep
-                int first = -1;
-                bool timed_out = false;
+            // ---- zone pass: set_mocaps() of the first substep
+            int first = -1;
+            bool timed_out = false;
 #pragma unroll
-                for (int z = 0; z < (ZT > 0 ? ZT : Z); ++z) {
-                    const size_t zi = (size_t)z * N + env;
-                    double zx, zy;
+            for (int z = 0; z < (ZT > 0 ? ZT : Z); ++z) {
+                const size_t zi = (size_t)z * N + env;
+                double zx, zy;
+                int aux = 0;
+                if (ZT > 0) {
+                    zx = zxr[z]; zy = zyr[z]; aux = auxr[z];
+                } else {
+                    const double2 zz = p.zxy[zi];
+                    zx = zz.x; zy = zz.y;
+                    if (TASK == ZENV_TASK_TIMED_TSP) aux = p.tmax[zi];
+                    if (TASK == ZENV_TASK_COLOUR_MATCH) aux = p.cooldown[zi];
+                }
+                const double dx = zx - rx, dy = zy - ry;
+                const double d2 = dx * dx + dy * dy;
+                const bool inside = d2 <= p.hit_d2;
+                if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                    int cd = aux;
+                    if (cd > 0) cd -= 1;                       // colour_match_env.py:98-100
+                    int col = (int)((e.colpack >> (2 * z)) & 3ull);
+                    if (first < 0 && cd == 0 && inside) {       // :106-120, lowest index wins
+                        first = z;
+                        col = (col == 2) ? 0 : col + 1;         // Blue->Green->Red->Blue
+                        e.colpack = (e.colpack & ~(3ull << (2 * z))) | ((uint64_t)col << (2 * z));
+                        cd = p.max_cd;
+                    }
+                    p.cooldown[zi] = (uint8_t)cd;
+                    my_ents[z] = make_entry<TASK>(p, zx, zy, col, cd, k);
+                } else {
+                    bool vis = (e.vis >> z) & 1u;
+                    if (first < 0 && !vis && inside) {          // TSP_env.py:54-69
+                        first = z;
+                        vis = true;
+                        e.vis |= 1u << z;
+                    }
+                    if (TASK == ZENV_TASK_TIMED_TSP) {
+                        if (!vis && (aux - k) <= 0) timed_out = true;   // TTSP_env.py:67
+                    }
+                    my_ents[z] = make_entry<TASK>(p, zx, zy, vis ? 1 : 0, aux, k);
+                }
+            }
+
+            // ---- reward / goal / termination (Engine.step order; none of it needs the physics)
+            double r = 0.0;
+            bool goal;
+            if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                if (first >= 0) {
+                    const int nd = hamming_to_goal(e.colpack, Z);
+                    r = (double)(e.goal_dist - nd);
+                    e.goal_dist = nd;
+                }
+                goal = e.goal_dist == 0;
+            } else {
+                r = first >= 0 ? 1.0 : 0.0;
+                const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
+                goal = e.vis == full;
+            }
+            bool done = false;
+            if (goal) {
+                r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
+                done = true;
+                goal_out = 1;
+            }
+            e.steps = k;
+            if (k >= p.num_steps) done = true;
+            if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
+
+            ep_ret = ep_ret + r;
+            rew_out = (float)r;
+            done_out = done ? 1 : 0;
+            p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
+
+            mode = 0;
+            if (done) {
+                p.last_return[env] = ep_ret;
+                p.last_len[env] = k;
+                p.episodes[env] += 1;
+                if (auto_reset) need_reset = true;
+                else p.done_state[env] = 1;
+            }
+        }
+
+        // ---- auto-reset (penv.py:8-11), wave-cooperative: for each finished env of the tile,
+        // lane z fetches zone z of the new layout (one 400-byte coalesced burst from the bank
+        // instead of Z dependent round trips in one lane) and writes it to the zone array and to
+        // the env's LDS entries.  This step's physics result is never observed (mode 1).
+        unsigned long long pending = __ballot(need_reset);
+        if (pending) {
+            int my_slot = 0;
+            if (need_reset) my_slot = next_bank_slot(p, env, epi_idx, slot_first);
+            while (pending) {
+                const int j = __ffsll((long long)pending) - 1;   // wave-uniform
+                pending &= pending - 1;
+                const int slot = __shfl(my_slot, j);
+                const int env_j = env0 + j;
+                const double *br = p.bank_robot + 4 * (size_t)slot;
+                const double b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];   // same address in every lane
+                int code = 0;
+                if (lane < Z) {
+                    const size_t bi = (size_t)slot * Z + lane;
+                    const double2 zz = reinterpret_cast<const double2 *>(p.bank_zone)[bi];
+                    const size_t zi = (size_t)lane * N + env_j;
+                    p.zxy[zi] = zz;
                     int aux = 0;
-                    if (ZT > 0) {
-                        zx = zxr[z]; zy = zyr[z]; aux = auxr[z];
-                    } else {
-                        const double2 zz = p.zxy[zi];
-                        zx = zz.x; zy = zz.y;
-                        if (TASK == ZENV_TASK_TIMED_TSP) aux = p.tmax[zi];
-                        if (TASK == ZENV_TASK_COLOUR_MATCH) aux = p.cooldown[zi];
+                    if (TASK == ZENV_TASK_TIMED_TSP) {
+                        aux = p.bank_aux[bi];
+                        p.tmax[zi] = aux;
+                    } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                        code = p.bank_aux[bi];
+                        p.cooldown[zi] = 0;
                     }
-                    const double dx = zx - rx, dy = zy - ry;
-                    const double d2 = dx * dx + dy * dy;
-                    const bool inside = d2 <= p.hit_d2;
-                    if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                        int cd = aux;
-                        if (cd > 0) cd -= 1;                       // colour_match_env.py:98-100
-                        int col = (int)((e.colpack >> (2 * z)) & 3ull);
-                        if (first < 0 && cd == 0 && inside) {       // :106-120, lowest index wins
-                            first = z;
-                            col = (col == 2) ? 0 : col + 1;         // Blue->Green->Red->Blue
-                            e.colpack = (e.colpack & ~(3ull << (2 * z))) | ((uint64_t)col << (2 * z));
-                            cd = p.max_cd;
-                        }
-                        p.cooldown[zi] = (uint8_t)cd;
-                        write_row<TASK>(p, rows + z * F, zx, zy, col, cd, k);
-                    } else {
-                        bool vis = (e.vis >> z) & 1u;
-                        if (first < 0 && !vis && inside) {          // TSP_env.py:54-69
-                            first = z;
-                            vis = true;
-                            e.vis |= 1u << z;
-                        }
-                        if (TASK == ZENV_TASK_TIMED_TSP) {
-                            if (!vis && (aux - k) <= 0) timed_out = true;   // TTSP_env.py:67
-                        }
-                        write_row<TASK>(p, rows + z * F, zx, zy, vis ? 1 : 0, aux, k);
-                    }
+                    ents[j * Z + lane] = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
                 }
-
-                // ---- reward / goal / termination (Engine.step order; none of it needs the physics)
-                double r = 0.0;
-                bool goal;
+                uint64_t colpack = 0ull;
                 if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                    if (first >= 0) {
-                        const int nd = hamming_to_goal(e.colpack, Z);
-                        r = (double)(e.goal_dist - nd);
-                        e.goal_dist = nd;
-                    }
-                    goal = e.goal_dist == 0;
-                } else {
-                    r = first >= 0 ? 1.0 : 0.0;
-                    const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
-                    goal = e.vis == full;
+                    const unsigned long long m0 = __ballot(lane < Z && (code & 1));
+                    const unsigned long long m1 = __ballot(lane < Z && (code & 2));
+                    colpack = spread_even_bits((uint32_t)m0) | (spread_even_bits((uint32_t)m1) << 1);
                 }
-                bool done = false;
-                if (goal) {
-                    r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
-                    done = true;
-                    goal_out = 1;
+                wave_lds_fence();   // lane j reads the entries its neighbours just wrote
+                if (lane == j) {
+                    e.x0 = b0; e.y0 = b1; e.bq0 = b2; e.bq3 = b3;
+                    e.q0 = e.q1 = e.q2 = 0.0;
+                    e.v0 = e.v1 = e.v2 = 0.0;
+                    e.vis = 0u;
+                    e.colpack = colpack;
+                    e.goal_dist = (TASK == ZENV_TASK_COLOUR_MATCH) ? hamming_to_goal(colpack, Z) : 0;
+                    e.steps = 0;
+                    ep_ret = 0.0;
+                    mode = 1;
+                    p.seed[env] = p.bank_seed[slot];
+                    store_frame(p, env, e);
+                    store_dyn(p, env, e);
+                    emit_obs8(p, e, o);   // the first obs of the next episode
+                    store_obs8(p, env, o);
+                    if (pol.policy >= 0)
+                        reinterpret_cast<float2 *>(pol.out)[env] =
+                            scripted_action<TASK, ZT>(pol, env, my_ents, Z, o);
                 }
-                e.steps = k;
-                if (k >= p.num_steps) done = true;
-                if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
+            }
+        }
 
-                ep_ret = ep_ret + r;
-                rew_out = (float)r;
-                done_out = done ? 1 : 0;
-                p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
-
-                mode = 0;
-                if (done) {
-                    p.last_return[env] = ep_ret;
-                    p.last_len[env] = k;
-                    p.episodes[env] += 1;
-                    if (auto_reset) {
-                        // penv.py:8-11: the returned obs is the first obs of the next episode;
-                        // this step's physics result is never observed (mode 1 discards it)
-                        const int slot = next_bank_slot(p, env);
-                        reset_env<TASK>(p, env, slot, e, rows);
-                        ep_ret = 0.0;
-                        mode = 1;
-                        store_frame(p, env, e);
-                        store_dyn(p, env, e);   // reset_env zeroed q, v
-                        emit_obs8(p, e, o);
-                        store_obs8(p, env, o);
-                        if (pol.policy >= 0)   // next action from the new episode's first obs
-                            reinterpret_cast<float2 *>(pol.out)[env] = scripted_action<TASK, ZT>(pol, env, rows, Z, o);
-                    } else {
-                        p.done_state[env] = 1;
-                    }
-                }
+        if (valid) {
+            if (!was_done) {
                 p.ep_return[env] = ep_ret;
-                p.steps[env] = e.steps;
-                if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                    p.colpack[env] = e.colpack;
-                    p.goal_dist[env] = e.goal_dist;
-                } else {
-                    p.vis[env] = e.vis;
-                }
+                store_counters(p, env, TASK, e);
             }
             xmode[lane] = mode;
             xstep[lane] = e.steps;
@@ -721,14 +906,16 @@ void k_step_lane(DevParams p, const float *__restrict__ actions,
         ZSTAMP(10);
     }
 
-    // The one rendezvous of the two waves: the tile rows + per-env mode / step count are in
+    // The one rendezvous of the two waves: the zone entries + per-env mode / step count are in
     // LDS.  After it the zone wave streams the tile out while the physics wave finishes.
     __syncthreads();
     if (role == 0) ZSTAMP(4); else ZSTAMP(11);
 
     if (role == 0) {
         const int n_blk = min(kWave, N - env0);
-        flush_tile(tile, p.zone_obs + (size_t)env0 * ZF, n_blk * ZF, lane);
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 1)   // diagnostic builds only: ZENV_EXP bit 0 drops the flush
+        flush_entries<TASK>(ents, stage, p.zone_obs + (size_t)env0 * Z * F, n_blk * Z, lane);
+#endif
         ZSTAMP(3);
     } else if (env < N) {
         if (xmode[lane] == 0) {
@@ -736,10 +923,10 @@ void k_step_lane(DevParams p, const float *__restrict__ actions,
             store_dyn(p, env, e);
             o[0] = (float)(1.0 - div_const((double)e.steps, p.d_steps, p.inv_steps));
             store_obs8(p, env, o);
-            // fused K3: the action of the NEXT step, from this step's obs and the tile in LDS
             ZSTAMP(12);
+            // fused K3: the action of the NEXT step, from this step's obs and the entries in LDS
             if (pol.policy >= 0)
-                reinterpret_cast<float2 *>(pol.out)[env] = scripted_action<TASK, ZT>(pol, env, rows, Z, o);
+                reinterpret_cast<float2 *>(pol.out)[env] = scripted_action<TASK, ZT>(pol, env, my_ents, Z, o);
         }
         ZSTAMP(13);
     }
@@ -749,14 +936,16 @@ void k_step_lane(DevParams p, const float *__restrict__ actions,
 template <int TASK>
 __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t *__restrict__ mask)
 {
-    constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;
+    constexpr int F = TaskTraits<TASK>::F;
     const int env = blockIdx.x * kWave + threadIdx.x;
     if (env >= p.N) return;
     if (mask && !mask[env]) return;
     EnvRegs e;
     const int slot = next_bank_slot(p, env);
-    reset_env<TASK>(p, env, slot, e, p.zone_obs + (size_t)env * p.Z * F);
-    store_regs(p, env, TASK, e, true);
+    reset_env<TASK>(p, env, slot, e, GlobalRowSink{ p.zone_obs + (size_t)env * p.Z * F });
+    store_dyn(p, env, e);
+    store_frame(p, env, e);
+    store_counters(p, env, TASK, e);
     p.done_state[env] = 0;
     p.ep_return[env] = 0.0;
     p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : 0;
@@ -772,8 +961,12 @@ __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t
 
 // ---------------------------------------------------------------------------- launchers
 static inline int n_blocks(int n) { return (n + kWave - 1) / kWave; }
-static inline size_t tile_bytes(const DevParams &p) { return (size_t)kWave * p.Z * p.F * sizeof(float); }
-static inline size_t step_lds_bytes(const DevParams &p) { return tile_bytes(p) + 2 * kWave * sizeof(int); }
+static inline size_t full_tile_bytes(const DevParams &p) { return (size_t)kWave * p.Z * p.F * sizeof(float); }
+static inline size_t step_lds_bytes(const DevParams &p)
+{
+    const int G = p.F == 6 ? 3 : 7;
+    return (size_t)kWave * p.Z * sizeof(float4) + (size_t)kWave * G * sizeof(float4) + 2 * kWave * sizeof(int);
+}
 
 template <int TASK>
 static void launch_step_task(const DevParams &p, const float *actions, int auto_reset, const StepPolicy &pol,
@@ -782,7 +975,7 @@ static void launch_step_task(const DevParams &p, const float *actions, int auto_
     const dim3 grid(n_blocks(p.N)), block(kStepThreads);
     const size_t lds = step_lds_bytes(p);
     // hipExtLaunchKernelGGL stamps ev_start/ev_stop with the dispatch's own begin/end
-#define ZENV_LAUNCH(ZT)                                                                                 \
+#define ZENV_LAUNCH(ZT)                                                                                   \
     hipExtLaunchKernelGGL((k_step_lane<TASK, ZT>), grid, block, lds, s, ev_start, ev_stop, 0, p, actions, \
                           auto_reset, pol)
     switch (p.Z) {
@@ -826,7 +1019,7 @@ hipError_t launch_reset(const DevParams &p, const uint8_t *mask, hipStream_t s)
 hipError_t launch_policy(const DevParams &p, const StepPolicy &pol, hipStream_t s)
 {
     const dim3 grid(n_blocks(p.N)), block(kWave);
-    const size_t lds = pol.policy == ZENV_POLICY_GREEDY ? tile_bytes(p) : 0;
+    const size_t lds = pol.policy == ZENV_POLICY_GREEDY ? full_tile_bytes(p) : 0;
     switch (p.task) {
     case ZENV_TASK_TSP: hipLaunchKernelGGL(k_policy_lane<ZENV_TASK_TSP>, grid, block, lds, s, p, pol); break;
     case ZENV_TASK_TIMED_TSP: hipLaunchKernelGGL(k_policy_lane<ZENV_TASK_TIMED_TSP>, grid, block, lds, s, p, pol); break;

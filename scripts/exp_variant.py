@@ -1,0 +1,20 @@
+"""Diagnostic: time the step kernel of a -D<flags> variant build (never the shipped library)."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import combinatorial_rl_tasks_amd.build as B
+flags = [a for a in sys.argv[1:] if a.startswith("-D")]
+wl = [a for a in sys.argv[1:] if not a.startswith("-D")]
+so = os.path.join(ROOT, "gpurun_out", "libzenv_exp.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.run([B._hipcc()] + B.FLAGS + flags + ["-o", so] + [os.path.join(B.CSRC, s) for s in B.SOURCES], check=True)
+import combinatorial_rl_tasks_amd._native as nat
+nat.LIB_PATH = so
+import combinatorial_rl_tasks_amd as Z
+task, zones, keep = {"tsp": (0, 25, .4), "timed": (1, 25, .4), "colour": (2, 6, .55), "tsp15": (0, 15, .55)}[wl[0] if wl else "tsp"]
+n = 65536
+cfg = Z.default_config(task, zones, zones_keepout=keep)
+env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n); env.reset()
+env.rollout(30, Z.POLICY_GREEDY)
+tot, k = env.rollout(300, Z.POLICY_GREEDY, time_step_kernel=True)
+print(flags, wl, "kernel avg us %.2f  loop us/step %.2f" % (k / 300 * 1e3, tot / 300 * 1e3))

@@ -34,3 +34,18 @@ print(sys.argv[1:], "fused" if fused else "unfused")
 for k, v in names.items():
     x = rel[:, :, k]
     print(f"{v:32s} median {np.median(x):7.2f}  p10 {np.percentile(x,10):7.2f}  p90 {np.percentile(x,90):7.2f}  max {x.max():7.2f} us")
+if "blocks" in sys.argv:
+    late_mask = rel[:, :, 2] > 12
+    for k in (0, 1, 5, 6, 7, 2):
+        print("late blocks: slot", k, "median", round(float(np.median(rel[:, :, k][late_mask])), 2),
+              " normal median", round(float(np.median(rel[:, :, k][~late_mask])), 2))
+    zp = rel[:, :, 2] - rel[:, :, 1]          # zone pass duration per block
+    m = np.median(zp, axis=0)
+    order = np.argsort(-m)
+    print("slowest blocks (zone pass us):", [(int(b), round(float(m[b]), 2)) for b in order[:24]])
+    print("zone pass by block%8:", [round(float(np.median(m[i::8])), 2) for i in range(8)])
+    print("zone pass by (block//8)%32 first 8:", [round(float(np.median(m[(np.arange(len(m)) // 8) % 32 == i])), 2) for i in range(8)])
+    late = rel[:, :, 2].max(axis=0)
+    print("count blocks with zone-pass-done > 12us in any iter:", int((late > 12).sum()), "of", len(late))
+    it_late = (rel[:, :, 2] > 12).sum(axis=1)
+    print("per-iteration count of late blocks:", it_late.tolist())
