@@ -58,6 +58,7 @@ _PROTOTYPES = {
     "zenv_config_for_id": (C.c_int, [C.c_char_p, C.POINTER(Config)]),
     "zenv_default_config": (C.c_int, [C.c_int, C.c_int, C.POINTER(Config)]),
     "zenv_zone_feat": (C.c_int, [C.POINTER(Config)]),
+    "zenv_config_size": (C.c_int, []),
     "zenv_sample_layout": (C.c_int, [C.POINTER(Config), C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.POINTER(C.c_int32)]),
     "zenv_fixed_seed_sequence": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
@@ -108,6 +109,8 @@ def lib():
         fn = getattr(L, name)   # AttributeError if the ABI is incomplete
         fn.restype = restype
         fn.argtypes = argtypes
+    if L.zenv_config_size() != C.sizeof(Config):
+        raise ImportError("zenv_config layout mismatch between include/zenv.h and _native.Config")
     _lib = L
     return L
 

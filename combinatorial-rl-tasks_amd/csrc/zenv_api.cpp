@@ -165,6 +165,8 @@ extern "C" int zenv_zone_feat(const zenv_config *cfg)
     return cfg->task == ZENV_TASK_TSP ? 6 : 7;   // TSP_env.py:27-29, TTSP_env.py:78-84, colour_match_env.py:70-73
 }
 
+extern "C" int zenv_config_size(void) { return (int)sizeof(zenv_config); }
+
 extern "C" int zenv_default_config(int task, int num_zones, zenv_config *c)
 {
     if (!c) return fail(ZENV_E_ARG, "null config");

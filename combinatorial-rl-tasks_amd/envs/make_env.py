@@ -1,0 +1,29 @@
+"""main/envs/make_env.py: make_train_env / make_test_env / make_fixed_env (same signatures)."""
+from .registry import OUT_OF_SCOPE, REGISTRY, make
+from .wrappers import FixedSeedsWrapper, WaitWrapper, ZoneWrapper
+
+_ZONE_IDS = tuple(REGISTRY) + OUT_OF_SCOPE
+
+
+def make_train_env(env_name, hier=False, num_training_tasks=100, rng_seed=0):
+    if env_name not in _ZONE_IDS:
+        raise RuntimeError("Unknown environment")          # make_env.py:18
+    env = make(env_name)
+    env = ZoneWrapper(FixedSeedsWrapper(env, min_seed=1, max_seed=num_training_tasks, rng_seed=rng_seed))
+    return WaitWrapper(env) if hier else env
+
+
+def make_test_env(env_name, hier=False, seed=1000):
+    if env_name not in _ZONE_IDS:
+        raise RuntimeError("Unknown environment")          # make_env.py:34
+    env = make(env_name)
+    env.seed(seed)
+    return ZoneWrapper(env)
+
+
+def make_fixed_env(env_name, hier=False, seed=1000, env_seed=0):
+    if env_name not in _ZONE_IDS:
+        raise RuntimeError("Unknown environment")          # make_env.py:51
+    env = make(env_name)
+    env.seed(seed)
+    return ZoneWrapper(FixedSeedsWrapper(env, min_seed=env_seed, max_seed=env_seed, rng_seed=seed))

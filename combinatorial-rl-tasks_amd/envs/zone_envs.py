@@ -1,0 +1,201 @@
+"""Single-environment facades with the reference's gym.Env surface.
+
+Mirrors main/envs/zone_envs/ZoneEnvBase.py (ZoneEnvBase, zone), main/envs/TSP_env.py
+(TSPEnv), main/envs/TTSP_env.py (TimedTSPEnv) and main/envs/colour_match_env.py
+(ColourMatchEnv): same constructor ``config`` dicts (main/envs/__init__.py:7-50), same
+``seed / reset / step / observation_space / action_space`` behaviour, same raw observation
+dict (keys and order of ZoneEnvBase.obs(), ZoneEnvBase.py:190-224) so that the reference's
+ZoneWrapper logic applies unchanged.  All arithmetic runs in the HIP library through one
+device handle of N = 1 env; nothing is computed in Python.
+"""
+import copy
+import enum
+
+import numpy as np
+
+from .. import _native as nat
+from ..vec_env import ZoneVecEnv, default_config
+from .spaces import Box, Dict
+
+
+class zone(enum.Enum):          # ZoneEnvBase.py:13-30
+    JetBlack = 0
+    White = 1
+    Blue = 2
+    Green = 3
+    Red = 4
+    Yellow = 5
+    Cyan = 6
+    Magenta = 7
+
+    def __lt__(self, sth):
+        return self.value < sth.value
+
+    def __str__(self):
+        return self.name[0]
+
+    def __repr__(self):
+        return self.name
+
+
+visited = zone.Yellow       # TSP_env.py:9-10
+unvisited = zone.Cyan
+colours = [zone.Blue, zone.Green, zone.Red]    # colour_match_env.py:9
+
+
+class ZoneEnvBase:
+    """Common part of the three task envs (Engine + ZoneEnvBase of the reference)."""
+
+    _TASK = None
+    metadata = {"render.modes": []}
+    reward_range = (-float("inf"), float("inf"))
+
+    def __init__(self, config, device=0, **native_overrides):
+        config = copy.deepcopy(config)
+        self.time_saved_reward = config.pop("time_saved_reward", 0.01)   # TSP_env.py:15
+        self.num_cities = config.pop("num_cities")                        # TSP_env.py:16
+        if config.get("walled", False):
+            raise NotImplementedError("walled arenas are outside the MI355X hot path")
+        robot_base = config.get("robot_base", "xmls/point.xml")
+        if robot_base != "xmls/point.xml":
+            raise NotImplementedError(f"only the Point robot is implemented, not {robot_base}")
+        if config.get("observation_flatten", False):
+            raise NotImplementedError("observation_flatten=True is not used by the zone envs")
+        self.num_steps = int(config.get("num_steps", 1000))               # ZoneEnvBase.py:86
+        self.zones_num = self.num_cities
+        self.zones_size = 0.2
+        self.zones_keepout = 0.55
+        self.config = config
+        self._cfg = default_config(self._TASK, self.num_cities, num_steps=self.num_steps,
+                                   time_saved_reward=float(self.time_saved_reward),
+                                   **self._native_overrides(), **native_overrides)
+        self._vec = ZoneVecEnv(self._cfg, 1, device=device)
+        self._seed = None
+        self.done = True      # Engine: must reset before the first step
+        self.steps = 0
+        self.action_space = Box(-1, 1, (2,), dtype=np.float32)
+        self.build_observation_space()
+
+    def _native_overrides(self):
+        return {}
+
+    # ------------------------------------------------------------------ gym.Env surface
+    @property
+    def unwrapped(self):
+        return self
+
+    def seed(self, seed=None):
+        """Engine.seed: remember the seed for the next reset()."""
+        self._seed = np.random.randint(2 ** 32) if seed is None else seed
+
+    def reset(self):
+        """Engine.reset: task randomness from RandomState(_seed), then _seed += 1 and the
+        layout from RandomState(_seed) (TTSP_env.py:73-76, colour_match_env.py:125-127)."""
+        if self._seed is None:
+            self.seed(None)
+        s = int(self._seed)
+        self._vec.build_bank(s, 1, n_threads=1)
+        self._vec.schedule_sequential()
+        self._vec.reset()
+        self._seed = s + 1
+        self.done = False
+        self.steps = 0
+        return self.obs()
+
+    def step(self, action):
+        assert not self.done, "Environment must be reset before stepping"   # Engine.step
+        a = np.asarray(action, dtype=np.float32).reshape(1, 2)
+        self._vec.step(a, auto_reset=False)
+        reward = float(self._vec.get(nat.F_REWARD)[0])
+        self.done = bool(self._vec.get(nat.F_DONE)[0])
+        self.steps += 1
+        info = {"cost": 0}
+        if self._vec.get(nat.F_GOAL_MET)[0]:
+            info["goal_met"] = True
+        return self.obs(), reward, self.done, info
+
+    def close(self):
+        self._vec.close()
+
+    def render(self, *args, **kwargs):
+        raise NotImplementedError("rendering (mujoco-py viewers) is outside the hot path")
+
+    # ------------------------------------------------------------------ observations
+    def build_observation_space(self):
+        d = {"remaining": Box(0.0, 1.0, (1,), dtype=np.float32)}
+        F = self._vec.zone_feat
+        for i in range(self.num_cities):
+            d[f"zones_lidar_{i}"] = Box(-np.inf, np.inf, (F,), dtype=np.float32)
+        d["robot_pos"] = Box(-np.inf, np.inf, (2,), dtype=np.float32)
+        d["robot_dir"] = Box(-np.inf, np.inf, (2,), dtype=np.float32)
+        d["robot_velp"] = Box(-np.inf, np.inf, (2,), dtype=np.float32)
+        d["robot_velr"] = Box(-np.inf, np.inf, (1,), dtype=np.float32)
+        self.obs_space_dict = d
+        self.observation_space = Dict(d)
+
+    def obs(self):
+        """ZoneEnvBase.obs(): the raw dict, float64 like the reference's numpy arrays."""
+        o = self._vec.get(nat.F_OBS)[0].astype(np.float64)
+        zo = self._vec.get(nat.F_ZONE_OBS)[0].astype(np.float64)
+        out = {"remaining": o[0:1]}
+        for i in range(self.num_cities):
+            out[f"zones_lidar_{i}"] = zo[i]
+        out["robot_pos"] = o[1:3]
+        out["robot_dir"] = o[3:5]
+        out["robot_velp"] = o[5:7]
+        out["robot_velr"] = o[7:8]
+        return out
+
+    # ------------------------------------------------------------------ state views
+    @property
+    def zones(self):
+        raise NotImplementedError
+
+    def goal_met(self):
+        return bool(self._vec.get(nat.F_GOAL_MET)[0])
+
+
+class TSPEnv(ZoneEnvBase):
+    """PointTSP (main/envs/TSP_env.py)."""
+    _TASK = nat.TASK_TSP
+
+    @property
+    def zones(self):
+        st = self._vec.debug_state()["zone_state"][0]
+        return [visited if v else unvisited for v in st]
+
+
+class TimedTSPEnv(TSPEnv):
+    """TimedTSP (main/envs/TTSP_env.py)."""
+    _TASK = nat.TASK_TIMED_TSP
+
+    def __init__(self, config, beta_a=3, beta_b=1.5, **kw):
+        self.beta_a, self.beta_b = beta_a, beta_b
+        super().__init__(config, **kw)
+        self.max_steps = self.num_steps
+
+    def _native_overrides(self):
+        return {"beta_a": float(self.beta_a), "beta_b": float(self.beta_b)}
+
+    @property
+    def zone_times(self):
+        return self._vec.get(nat.F_ZONE_OBS)[0][:, 6].astype(np.float64)
+
+
+class ColourMatchEnv(ZoneEnvBase):
+    """ColourMatch (main/envs/colour_match_env.py)."""
+    _TASK = nat.TASK_COLOUR_MATCH
+    max_cd = 150
+
+    @property
+    def zones(self):
+        st = self._vec.debug_state()["zone_state"][0]
+        return [colours[int(c)] for c in st]
+
+    @property
+    def zone_cooldowns(self):
+        return [int(c) for c in self._vec.debug_state()["cooldown"][0]]
+
+    @property
+    def goal_dist(self):
+        return int(self._vec.get(nat.F_VISIT_COUNT)[0])

@@ -1,0 +1,51 @@
+"""The reference's evaluation protocol (main/scripts/evaluate.py:22-25,47-78) on one device.
+
+100 maps (env seeds 1000000..1000099) x 5 runs per map, undiscounted episodic return,
+result layout ``{"return": [[r_run0..r_run4] for each map]}`` -- but all maps and runs are
+stepped together as one batch of n_maps*n_runs envs instead of 500 sequential episodes.
+"""
+import pickle
+
+import numpy as np
+
+from . import _native as nat
+from .vec_env import ZoneVecEnv, config_for_id
+
+EVAL_SEED0 = 1000000     # evaluate.py:47
+
+
+def evaluate(env_id, policy, n_maps=100, n_runs_per_map=5, env_seed0=EVAL_SEED0, device=0,
+             policy_seed=0, pkl_path=None, max_steps=None):
+    """policy: ZENV_POLICY_* (on-device scripted policy) or a callable
+    ``policy(obs (B,8) float32, zone_obs (B,Z,F) float32) -> actions (B,2)`` running on the host
+    (e.g. the reference's ``Agent.get_actions`` behind a small adapter).
+
+    Returns ``{"return": [[...]], "length": [[...]], "goal_met": [[...]]}``."""
+    cfg = config_for_id(env_id) if isinstance(env_id, str) else env_id
+    n = n_maps * n_runs_per_map
+    env = ZoneVecEnv(cfg, n, device=device)
+    env.build_bank(env_seed0, n_maps)
+    env.schedule_sequential(first=np.repeat(np.arange(n_maps, dtype=np.int32), n_runs_per_map), stride=0)
+    env.reset()
+    goal = np.zeros(n, bool)
+    horizon = cfg.num_steps if max_steps is None else max_steps
+    for t in range(horizon):
+        if callable(policy):
+            o, zo = env.observations()
+            env.step(np.asarray(policy(o, zo), np.float32), auto_reset=False)
+        else:
+            env.policy(int(policy), policy_seed=policy_seed)
+            env.step(None, auto_reset=False)
+        goal |= env.get(nat.F_GOAL_MET).astype(bool)
+        if env.get(nat.F_DONE).all():      # every episode finished (evaluate.py:64-72)
+            break
+    out = {
+        "return": env.get(nat.F_LAST_RETURN).reshape(n_maps, n_runs_per_map).tolist(),
+        "length": env.get(nat.F_LAST_LEN).reshape(n_maps, n_runs_per_map).tolist(),
+        "goal_met": goal.reshape(n_maps, n_runs_per_map).tolist(),
+    }
+    env.close()
+    if pkl_path:
+        with open(pkl_path, "wb") as f:       # evaluate.py:76-78 writes {"return": record_returns}
+            pickle.dump({"return": out["return"]}, f)
+    return out

@@ -1,0 +1,118 @@
+"""ParallelEnv -- drop-in for main/src/torch_ac/torch_utils/penv.py:26-66.
+
+The reference runs one OS process per env and ships pickled ``(obs, reward, done, info)``
+tuples over Pipes.  Here the same constructor argument (a list of wrapped single envs, as
+built by ``make_train_env`` / ``make_fixed_env``) is folded into ONE device handle of
+``len(envs)`` envs: ``step`` is one kernel launch, auto-reset (penv.py:7-11) happens inside
+it, and each env keeps its own FixedSeedsWrapper seed stream (wrappers.py:10-23) on the device.
+``reset/step/step_no_reset`` return exactly the reference's shapes; ``step_arrays`` returns the
+struct-of-arrays results without building P Python dicts.
+"""
+import numpy as np
+
+from . import _native as nat
+from .envs.wrappers import FixedSeedsWrapper, WaitWrapper, ZoneWrapper
+from .envs.zone_envs import ZoneEnvBase
+from .vec_env import ZoneVecEnv
+
+_PLAIN_EPISODES = 256   # bank depth for envs that are not behind a FixedSeedsWrapper
+
+
+def _unwrap(env):
+    fixed, chain = None, env
+    while not isinstance(chain, ZoneEnvBase):
+        if isinstance(chain, FixedSeedsWrapper):
+            fixed = chain
+        elif not isinstance(chain, (ZoneWrapper, WaitWrapper)):
+            raise TypeError(f"ParallelEnv cannot batch {type(chain).__name__}")
+        chain = chain.env
+    return chain, fixed
+
+
+class ParallelEnv:
+    """A batch of zone envs stepped by one MI355X kernel launch."""
+
+    def __init__(self, envs, device=0):
+        assert len(envs) >= 1, "No environment given."
+        self.envs = envs
+        self.observation_space = envs[0].observation_space
+        self.action_space = envs[0].action_space
+        bases, fixed = zip(*[_unwrap(e) for e in envs])
+        cfg = bases[0]._cfg
+        for b in bases[1:]:
+            if bytes(b._cfg) != bytes(cfg):
+                raise ValueError("all envs of a ParallelEnv must share one configuration")
+        self.num_envs = len(envs)
+        self._vec = ZoneVecEnv(cfg, self.num_envs, device=device)
+        if all(f is not None for f in fixed):
+            lo, hi = fixed[0].min_seed, fixed[0].max_seed
+            if any((f.min_seed, f.max_seed) != (lo, hi) for f in fixed):
+                raise ValueError("all FixedSeedsWrappers must share [min_seed, max_seed]")
+            for f in fixed:   # the device stream starts where default_rng(rng_seed) starts
+                fresh = np.random.default_rng(seed=f.rng_seed).bit_generator.state
+                if f.rng.bit_generator.state != fresh:
+                    raise NotImplementedError("wrap fresh envs: a FixedSeedsWrapper already drew seeds")
+            self._vec.build_bank(int(lo), int(hi) - int(lo) + 1)
+            self._vec.schedule_fixed_seeds(np.array([f.rng_seed for f in fixed], np.uint64), int(lo), int(hi))
+        elif all(f is None for f in fixed):
+            # Engine semantics: reset k of env i plays seed _seed_i + k (reset() does _seed += 1)
+            seeds = []
+            for b in bases:
+                if b._seed is None:
+                    b.seed(None)
+                seeds.append(int(b._seed) + np.arange(_PLAIN_EPISODES, dtype=np.int64))
+            self._vec.build_bank_seeds(np.concatenate(seeds))
+            self._vec.schedule_sequential(first=np.arange(self.num_envs, dtype=np.int32) * _PLAIN_EPISODES,
+                                          stride=1)
+        else:
+            raise ValueError("mixing seeded and FixedSeedsWrapper envs is not supported")
+
+    # ------------------------------------------------------------------ reference surface
+    def reset(self):
+        self._vec.reset()
+        self._finished = np.zeros(self.num_envs, bool)
+        return self._obs_list()
+
+    def step(self, actions):
+        return self._step(actions, True)
+
+    def step_no_reset(self, actions):
+        return self._step(actions, False)
+
+    def render(self):
+        raise NotImplementedError
+
+    def close(self):
+        self._vec.close()
+
+    # ------------------------------------------------------------------ array surface
+    def step_arrays(self, actions, auto_reset=True):
+        """(obs (P,8), zone_obs (P,Z,F), reward (P,), done (P,), goal_met (P,)) float32/bool."""
+        self._vec.step(np.asarray(actions, np.float32).reshape(self.num_envs, 2), auto_reset=auto_reset)
+        return self._vec.results()
+
+    @property
+    def vec(self):
+        """The underlying ZoneVecEnv (device pointers, counters, rollouts)."""
+        return self._vec
+
+    # ------------------------------------------------------------------ helpers
+    def _obs_list(self):
+        o, zo = self._vec.observations()
+        o = o.astype(np.float64)
+        zo = zo.astype(np.float64)
+        return [{"zone_obs": zo[i], "obs": o[i]} for i in range(self.num_envs)]
+
+    def _step(self, actions, auto_reset):
+        o, zo, r, d, g = self.step_arrays(actions, auto_reset)
+        o = o.astype(np.float64)
+        zo = zo.astype(np.float64)
+        was_finished = getattr(self, "_finished", np.zeros(self.num_envs, bool))
+        results = []
+        for i in range(self.num_envs):
+            info = {} if was_finished[i] else {"cost": 0}   # WaitWrapper no-op: info = {}
+            if g[i]:
+                info["goal_met"] = True
+            results.append(({"zone_obs": zo[i], "obs": o[i]}, float(r[i]), bool(d[i]), info))
+        self._finished = np.zeros(self.num_envs, bool) if auto_reset else (was_finished | d)
+        return zip(*results)

@@ -102,6 +102,7 @@ const char *zenv_version(void);
 int zenv_config_for_id(const char *env_id, zenv_config *out);
 int zenv_default_config(int task, int num_zones, zenv_config *out);
 int zenv_zone_feat(const zenv_config *cfg);   /* F: 6 (TSP) or 7 */
+int zenv_config_size(void);                   /* sizeof(zenv_config): lets a binding check its mirror */
 
 /* Host layout sampler = Engine.reset()'s random half for env.seed(seed); reset():
  * aux from RandomState(seed) (TTSP_env.py:19-21 tmax / colour_match_env.py:57-68 colours),

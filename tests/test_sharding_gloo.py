@@ -1,0 +1,70 @@
+"""N > 1 path on CPU: world_size-2 gloo.  The env compute of each rank is stood in for by the
+oracle (tests may call it); what is under test is the product's sharding plumbing --
+global env indexing, per-rank bank seeds, shard invariance of results and the ordering of the
+one collective (all-gather of episodic returns)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist      # noqa: E402
+import torch.multiprocessing as mp    # noqa: E402
+
+N_PER_RANK, T = 24, 450
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _reference(O, cfg, world):
+    n = N_PER_RANK * world
+    return O.rollout(cfg, 1 + np.arange(n), T, O.POLICY_GREEDY, seed_stride=n, policy_seed=7, n_threads=2)
+
+
+def _worker(rank, world, port, policy):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from combinatorial_rl_tasks_amd.sharding import EnvShard
+        cfg = O.default_config(O.TASK_TSP, 5, num_steps=200)
+        shard = EnvShard(rank, world, N_PER_RANK)
+        assert shard.env_index0 == rank * N_PER_RANK and shard.seed_stride == world * N_PER_RANK
+        # slot i + k*n of the rank's bank holds the seed of local env i's k-th episode
+        bank = shard.bank_seeds(3).reshape(3, N_PER_RANK)
+        for k in range(3):
+            assert np.array_equal(bank[k], 1 + shard.env_index0 + np.arange(N_PER_RANK) + k * shard.seed_stride)
+        mine = O.rollout(cfg, shard.first_seeds(), T, policy, seed_stride=shard.seed_stride, policy_seed=7,
+                         env_index0=shard.env_index0, n_threads=1)
+        gathered = shard.all_gather(torch.from_numpy(mine["last_return"].astype(np.float32)))
+        episodes = shard.all_gather(torch.from_numpy(mine["episodes"]))
+        n = world * N_PER_RANK
+        whole = O.rollout(cfg, 1 + np.arange(n), T, policy, seed_stride=n, policy_seed=7, n_threads=1)
+        assert gathered.shape == (n,)
+        assert np.array_equal(gathered.numpy(), whole["last_return"].astype(np.float32)), "shard variance"
+        assert np.array_equal(episodes.numpy(), whole["episodes"])
+        assert whole["episodes"].sum() >= n          # every env finished at least one episode
+        # rank r's block sits at [r*n_per, (r+1)*n_per) on every rank
+        lo = rank * N_PER_RANK
+        assert np.array_equal(gathered.numpy()[lo:lo + N_PER_RANK], mine["last_return"].astype(np.float32))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("policy", [0, 1])
+def test_two_rank_gloo_shard_invariance(oracle_mod, policy):
+    mp.spawn(_worker, args=(2, _free_port(), policy), nprocs=2, join=True)
+
+
+def test_single_rank_gather_is_identity():
+    from combinatorial_rl_tasks_amd.sharding import EnvShard
+    shard = EnvShard(0, 1, 8)
+    t = torch.arange(8, dtype=torch.float32)
+    assert torch.equal(shard.all_gather(t), t)
+    with pytest.raises(ValueError):
+        EnvShard(2, 2, 8)
