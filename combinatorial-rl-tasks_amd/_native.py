@@ -75,7 +75,7 @@ _PROTOTYPES = {
     "zenv_reset": (C.c_int, [_H, C.c_void_p]),
     "zenv_step": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
     "zenv_policy": (C.c_int, [_H, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
-    "zenv_rollout": (C.c_int, [_H, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int,
+    "zenv_rollout": (C.c_int, [_H, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "zenv_get": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int]),
     "zenv_device_ptr": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),

@@ -575,6 +575,52 @@ __device__ __forceinline__ float2 greedy_action(const Rows rows, int Zrt, float 
     return a;
 }
 
+// The same policy evaluated by a whole wave for ONE env: lane z holds zone z (lanes >= Z
+// idle), a butterfly arg-min replaces the Z-long scan.  Used on the auto-reset path, where a
+// single lane would otherwise run the full scan on the zone wave's critical path.  Every lane
+// returns the action.  Ties go to the lowest zone index, like the sequential scan.
+template <int TASK>
+__device__ __forceinline__ float2 greedy_action_coop(int lane, int Z, float zx3, float zy3, int code, float aux,
+                                                     float opx, float opy, float ohx, float ohy)
+{
+    const bool live = lane < Z;
+    const double px = 3.0 * (double)opx, py = 3.0 * (double)opy;
+    const double hx = (double)ohx, hy = (double)ohy;
+    bool eligible = live && code == 0;
+    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+        const int cb = __popcll(__ballot(live && code == 0));
+        const int cg = __popcll(__ballot(live && code == 1));
+        const int cr = __popcll(__ballot(live && code == 2));
+        int target = 0, best_cnt = cb;
+        if (cg > best_cnt) { target = 1; best_cnt = cg; }
+        if (cr > best_cnt) { target = 2; }
+        eligible = live && aux == 0.f && code != target;
+    }
+    const double dx = 3.0 * (double)zx3 - px, dy = 3.0 * (double)zy3 - py;
+    double d2 = eligible ? dx * dx + dy * dy : __builtin_inf();
+    int idx = lane;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double d2o = __shfl_xor(d2, off);
+        const int io = __shfl_xor(idx, off);
+        const bool take = d2o < d2 || (d2o == d2 && io < idx);
+        d2 = take ? d2o : d2;
+        idx = take ? io : idx;
+    }
+    float2 a = make_float2(0.f, 0.f);
+    const double bdx = __shfl(dx, idx), bdy = __shfl(dy, idx);
+    const double bd2 = bdx * bdx + bdy * bdy;
+    if (d2 < __builtin_inf() && bd2 > 1e-18) {
+        const double n = sqrt(bd2);
+        const double cs = (hx * bdx + hy * bdy) / n;
+        const double sn = (hx * bdy - hy * bdx) / n;
+        if (cs < 0.0) a.y = sn >= 0.0 ? 1.f : -1.f;
+        else a.y = (float)det_clamp(4.0 * sn, -1.0, 1.0);
+        a.x = cs > 0.8 ? 1.f : 0.f;
+    }
+    return a;
+}
+
 template <int TASK, int ZT>
 __device__ __forceinline__ float2 scripted_action(const StepPolicy &pol, int env, const float4 *ents, int Z,
                                                   const float *o)
@@ -711,6 +757,35 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             }
         }
 
+        // ---- reset prefetch.  An episode can only end this step on the time limit or when at
+        // most one zone is still open (ColourMatch: Hamming distance <= 2).  For those few envs
+        // request every cache line of the next episode's bank rows now, behind the zone loads:
+        // they land during the zone pass, so the cooperative reset below (which only learns
+        // about the termination after the zone pass) finds them on chip instead of paying a
+        // cold HBM round trip at the end of this wave's critical path.  Nothing is consumed
+        // here; the registers are only kept alive until the end of the wave.
+        int pf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (valid && !was_done && auto_reset && p.sched_mode == SCHED_SEQUENTIAL) {
+            const int open_zones = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : Z - (int)__popc(e.vis);
+            if (e.steps + 1 >= p.num_steps || open_zones <= (TASK == ZENV_TASK_COLOUR_MATCH ? 2 : 1)) {
+                const long long sl = ((long long)slot_first + (long long)epi_idx * (long long)p.sched_stride) %
+                                     (long long)p.bank_size;
+                const int *bz = reinterpret_cast<const int *>(p.bank_zone + 2 * (size_t)sl * Z);
+                pf[0] = bz[0];                                   // 128-B lines of the 16*Z-byte zone block
+                if (4 * Z > 32) pf[1] = bz[32];
+                if (4 * Z > 64) pf[2] = bz[64];
+                if (4 * Z > 96) pf[3] = bz[96];
+                pf[4] = bz[4 * Z - 1];
+                pf[5] = reinterpret_cast<const int *>(p.bank_robot + 4 * (size_t)sl)[0];
+                if (TASK != ZENV_TASK_TSP) {
+                    const int *ba = p.bank_aux + (size_t)sl * Z;
+                    pf[6] = ba[0];
+                    pf[7] = ba[Z - 1];
+                }
+                pf[8] = (int)p.bank_seed[sl];
+            }
+        }
+
         float rew_out = 0.f;
         uint8_t done_out = 1, goal_out = 0;
         int mode = 1;
@@ -818,6 +893,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         // the env's LDS entries.  This step's physics result is never observed (mode 1).
         unsigned long long pending = __ballot(need_reset);
         if (pending) {
+            ZSTAMP(5);
             int my_slot = 0;
             if (need_reset) my_slot = next_bank_slot(p, env, epi_idx, slot_first);
             while (pending) {
@@ -828,6 +904,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 const double *br = p.bank_robot + 4 * (size_t)slot;
                 const double b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];   // same address in every lane
                 int code = 0;
+                float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (lane < Z) {
                     const size_t bi = (size_t)slot * Z + lane;
                     const double2 zz = reinterpret_cast<const double2 *>(p.bank_zone)[bi];
@@ -841,34 +918,45 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                         code = p.bank_aux[bi];
                         p.cooldown[zi] = 0;
                     }
-                    ents[j * Z + lane] = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
+                    en = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
+                    ents[j * Z + lane] = en;
                 }
+                ZSTAMP(6);
                 uint64_t colpack = 0ull;
                 if (TASK == ZENV_TASK_COLOUR_MATCH) {
                     const unsigned long long m0 = __ballot(lane < Z && (code & 1));
                     const unsigned long long m1 = __ballot(lane < Z && (code & 2));
                     colpack = spread_even_bits((uint32_t)m0) | (spread_even_bits((uint32_t)m1) << 1);
                 }
-                wave_lds_fence();   // lane j reads the entries its neighbours just wrote
+                // The fresh episode's state is wave-uniform: every lane builds the first obs and
+                // the wave evaluates the scripted policy together (lane z <-> zone z), so the
+                // reset adds a few hundred ns to this wave instead of a serial Z-long scan.
+                EnvRegs fresh;
+                fresh.x0 = b0; fresh.y0 = b1; fresh.bq0 = b2; fresh.bq3 = b3;
+                fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
+                fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
+                fresh.vis = 0u;
+                fresh.colpack = colpack;
+                fresh.goal_dist = (TASK == ZENV_TASK_COLOUR_MATCH) ? hamming_to_goal(colpack, Z) : 0;
+                fresh.steps = 0;
+                float of[8];
+                emit_obs8(p, fresh, of);   // the first obs of the next episode
+                float2 next_act = make_float2(0.f, 0.f);
+                if (pol.policy == ZENV_POLICY_UNIFORM)
+                    next_act = uniform_action(pol.env_index0 + (uint64_t)env_j, pol.step_index, pol.seed);
+                else if (pol.policy == ZENV_POLICY_GREEDY)
+                    next_act = greedy_action_coop<TASK>(lane, Z, en.x, en.y, code, en.w, of[1], of[2], of[3], of[4]);
                 if (lane == j) {
-                    e.x0 = b0; e.y0 = b1; e.bq0 = b2; e.bq3 = b3;
-                    e.q0 = e.q1 = e.q2 = 0.0;
-                    e.v0 = e.v1 = e.v2 = 0.0;
-                    e.vis = 0u;
-                    e.colpack = colpack;
-                    e.goal_dist = (TASK == ZENV_TASK_COLOUR_MATCH) ? hamming_to_goal(colpack, Z) : 0;
-                    e.steps = 0;
+                    e = fresh;
                     ep_ret = 0.0;
                     mode = 1;
                     p.seed[env] = p.bank_seed[slot];
                     store_frame(p, env, e);
                     store_dyn(p, env, e);
-                    emit_obs8(p, e, o);   // the first obs of the next episode
-                    store_obs8(p, env, o);
-                    if (pol.policy >= 0)
-                        reinterpret_cast<float2 *>(pol.out)[env] =
-                            scripted_action<TASK, ZT>(pol, env, my_ents, Z, o);
+                    store_obs8(p, env, of);
+                    if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = next_act;
                 }
+                ZSTAMP(7);
             }
         }
 
@@ -883,6 +971,8 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             p.done_out[env] = done_out;
             p.goal_met[env] = goal_out;
         }
+        asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]),
+                     "v"(pf[7]), "v"(pf[8]));
         ZSTAMP(2);
     } else {
         // =================================================================== physics wave

@@ -582,7 +582,7 @@ extern "C" int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t
 }
 
 extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
-                            int auto_reset, int flags, float *ms_total, float *ms_step_kernel)
+                            int auto_reset, int flags, int event_stride, float *ms_total, float *ms_step_kernel_avg)
 {
     if (!h) return fail(ZENV_E_ARG, "null handle");
     if (!h->was_reset) return fail(ZENV_E_STATE, "Environment must be reset before stepping");
@@ -591,8 +591,10 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     int rc = use_device(h);
     if (rc) return rc;
     const bool fused = (flags & ZENV_ROLLOUT_UNFUSED) == 0;
-    const bool per_kernel = ms_step_kernel != nullptr;
-    const size_t need = 2 + (per_kernel ? 2 * (size_t)steps : 0);
+    const bool per_kernel = ms_step_kernel_avg != nullptr && steps > 0;
+    if (event_stride < 1) event_stride = 1;
+    const int n_sampled = per_kernel ? (steps + event_stride - 1) / event_stride : 0;
+    const size_t need = 2 + 2 * (size_t)n_sampled;
     while (h->events.size() < need) {
         hipEvent_t ev;
         HIP_TRY(hipEventCreate(&ev));
@@ -609,8 +611,9 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
             next = pol;
             next.step_index = (uint32_t)(h->step_count + 1);
         }
-        hipEvent_t e0 = per_kernel ? h->events[2 + 2 * t] : nullptr;
-        hipEvent_t e1 = per_kernel ? h->events[3 + 2 * t] : nullptr;
+        const bool sampled = per_kernel && (t % event_stride == 0);
+        hipEvent_t e0 = sampled ? h->events[2 + 2 * (t / event_stride)] : nullptr;
+        hipEvent_t e1 = sampled ? h->events[3 + 2 * (t / event_stride)] : nullptr;
         HIP_TRY(launch_step(h->p, h->p.actions, auto_reset, next, h->stream, e0, e1));
         h->step_count += 1;
     }
@@ -619,12 +622,14 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     if (ms_total) HIP_TRY(hipEventElapsedTime(ms_total, h->events[0], h->events[1]));
     if (per_kernel) {
         double sum = 0.0;
-        for (int t = 0; t < steps; ++t) {
+        for (int i = 0; i < n_sampled; ++i) {
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, h->events[2 + 2 * t], h->events[3 + 2 * t]));
+            HIP_TRY(hipEventElapsedTime(&ms, h->events[2 + 2 * i], h->events[3 + 2 * i]));
             sum += ms;
         }
-        *ms_step_kernel = (float)sum;
+        *ms_step_kernel_avg = (float)(sum / n_sampled);
+    } else if (ms_step_kernel_avg) {
+        *ms_step_kernel_avg = 0.f;
     }
     return ZENV_OK;
 }
@@ -664,6 +669,7 @@ extern "C" int zenv_debug_stamps(zenv_t *h, unsigned long long *dst, int64_t cou
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(dst, h->p.dbg, have * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(h->p.dbg, 0, have * sizeof(unsigned long long)));
     return ZENV_OK;
 }
 

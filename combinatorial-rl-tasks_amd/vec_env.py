@@ -173,18 +173,19 @@ class ZoneVecEnv:
                                 None if dst_ptr is None else C.c_void_p(int(dst_ptr))))
 
     def rollout(self, steps, policy, policy_seed=0x5EED, env_index0=0, auto_reset=True,
-                time_step_kernel=False, fused=True):
+                time_step_kernel=False, fused=True, event_stride=1):
         """K closed-loop steps a_t = policy(obs_t, t); step(a_t) on the handle's stream.
 
         fused=True: the step kernel also emits the next action (one launch per step);
         fused=False: a stand-alone policy kernel runs before every step.  Same results.
 
-        Returns (ms_total, ms_step_kernel or None), both from HIP events on that stream."""
+        Returns (ms_total, ms_step_kernel_avg or None), both from HIP events on that stream;
+        the kernel figure is the mean dispatch duration over every event_stride-th launch."""
         total = C.c_float(0)
         kern = C.c_float(0)
         check(lib().zenv_rollout(self._h, int(steps), int(policy), int(policy_seed),
                                  int(env_index0), int(bool(auto_reset)),
-                                 0 if fused else nat.ROLLOUT_UNFUSED, C.byref(total),
+                                 0 if fused else nat.ROLLOUT_UNFUSED, int(event_stride), C.byref(total),
                                  C.byref(kern) if time_step_kernel else None))
         return total.value, (kern.value if time_step_kernel else None)
 

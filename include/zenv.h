@@ -156,11 +156,13 @@ int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0
 /* K closed-loop steps a_t = policy(obs_t, t); step(a_t) on the handle's stream, HIP-event
  * timed.  Default: the step kernel of step t also emits a_{t+1} (fused action source, one
  * launch per step); ZENV_ROLLOUT_UNFUSED runs the stand-alone policy kernel before every
- * step instead.  Results are identical.  ms_total: whole loop; ms_step_kernel: sum of the K
- * step-kernel dispatch durations. */
+ * step instead.  Results are identical.  ms_total: whole loop (events on the stream);
+ * ms_step_kernel_avg (may be NULL): mean duration of the step-kernel dispatch, from the
+ * begin/end events of every event_stride-th launch of the loop. */
 #define ZENV_ROLLOUT_UNFUSED 1
 int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
-                 int auto_reset, int flags, float *ms_total, float *ms_step_kernel);
+                 int auto_reset, int flags, int event_stride, float *ms_total,
+                 float *ms_step_kernel_avg);
 
 /* ---- results ---- */
 int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device);

@@ -17,4 +17,4 @@ cfg = Z.default_config(task, zones, zones_keepout=keep)
 env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n); env.reset()
 env.rollout(30, Z.POLICY_GREEDY)
 tot, k = env.rollout(300, Z.POLICY_GREEDY, time_step_kernel=True)
-print(flags, wl, "kernel avg us %.2f  loop us/step %.2f" % (k / 300 * 1e3, tot / 300 * 1e3))
+print(flags, wl, "kernel avg us %.2f  loop us/step %.2f" % (k * 1e3, tot / 300 * 1e3))

@@ -16,7 +16,9 @@ fused = "unfused" not in sys.argv
 n = 65536
 cfg = Z.default_config(task, zones, zones_keepout=keep)
 env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n); env.reset()
-env.rollout(30, Z.POLICY_GREEDY, fused=fused)
+warm = int([a for a in sys.argv if a.startswith('warm=')][0][5:]) if any(a.startswith('warm=') for a in sys.argv) else 30
+env.build_bank_seeds(np.concatenate([1 + np.arange(n) + k * n for k in range(3)])); env.schedule_sequential(first=np.arange(n, dtype=np.int32), stride=n); env.reset()
+env.rollout(warm, Z.POLICY_GREEDY, fused=fused)
 L = nat.lib(); L.zenv_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 acc = []
 for it in range(20):
@@ -30,7 +32,17 @@ rel = (a - t0) * 0.01                   # us
 names = {0: "Z start", 1: "Z loads landed (pose ready)", 2: "Z zone pass done", 3: "Z flush issued",
          4: "Z past barrier", 8: "P start", 9: "P loads landed", 10: "P physics done", 11: "P past barrier",
          12: "P obs8 stored", 13: "P end"}
-print(sys.argv[1:], "fused" if fused else "unfused")
+print(sys.argv[1:], "fused" if fused else "unfused", "episodes so far", int(env.get(Z.F_EPISODES).sum()))
+ends = np.maximum(rel[:, :, 3], rel[:, :, 13])
+print("block end: median %.2f p90 %.2f p99 %.2f max %.2f" % (np.median(ends), np.percentile(ends, 90), np.percentile(ends, 99), ends.max()))
+slow = ends > np.percentile(ends, 99)
+rs = a[:, :, 5] > 0
+print("blocks with a reset this step: %.1f per launch" % (rs.sum() / a.shape[0]))
+if rs.any():
+    for k, nm in ((1, "pose"), (5, "reset loop entry"), (6, "bank rows landed, entries written"), (7, "reset done (last)"), (2, "zone wave at barrier")):
+        print("   reset blocks: %-34s median %.2f p90 %.2f" % (nm, np.median(rel[:, :, k][rs]), np.percentile(rel[:, :, k][rs], 90)))
+for k in (1, 2, 4, 3, 10, 12, 13):
+    print("  slot", k, "all median %.2f   slowest-1%% median %.2f" % (np.median(rel[:, :, k]), np.median(rel[:, :, k][slow])))
 for k, v in names.items():
     x = rel[:, :, k]
     print(f"{v:32s} median {np.median(x):7.2f}  p10 {np.percentile(x,10):7.2f}  p90 {np.percentile(x,90):7.2f}  max {x.max():7.2f} us")
