@@ -156,14 +156,20 @@ def main():
         value = total_env_steps / elapsed
         alg = algorithmic_bytes(task, zones)
         roofline = None
-        if ms_kernel is not None and args.steps > 0:
-            k_avg_s = ms_kernel / 1e3
+        if args.steps > 0 and (ms_kernel is not None or not args.unfused):
+            # Fused mode: the timed region is K back-to-back dispatches of ONE kernel, so the HIP
+            # events that bracket the loop on the kernel's stream give its average launch-to-launch
+            # duration (an upper bound of the dispatch duration: it includes the ~0.5 us gaps).
+            # The begin/end events of every event_stride-th dispatch are reported beside it.
+            k_avg_s = ms_total / 1e3 / args.steps if not args.unfused else ms_kernel / 1e3
             achieved = alg * n_env / k_avg_s / 1e9
             roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": load_traffic(args.workload, n_env),
                         "kernel": "k_step_lane", "kernel_avg_us": round(k_avg_s * 1e6, 2),
-                        "kernel_launches_timed": (args.steps + args.event_stride - 1) // args.event_stride,
+                        "kernel_launches_timed": args.steps if not args.unfused else
+                        (args.steps + args.event_stride - 1) // args.event_stride,
+                        "sampled_dispatch_avg_us": None if ms_kernel is None else round(ms_kernel * 1e3, 2),
                         "algorithmic_bytes_per_env_step": alg, "env_steps_per_launch": n_env}
         cpu = None
         if not args.no_cpu_baseline:

@@ -16,7 +16,7 @@ for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == key:
-                agg[r["Kernel_Name"].split("(")[0][-40:]].append(float(r["Counter_Value"]))
+                agg["k_step_lane" if "k_step_lane" in r["Kernel_Name"] else ("k_policy_lane" if "k_policy_lane" in r["Kernel_Name"] else ("k_reset_lane" if "k_reset_lane" in r["Kernel_Name"] else r["Kernel_Name"][:40]))].append(float(r["Counter_Value"]))
         summary[key] = {k: {"n": len(v), "mean_KiB": sum(v) / len(v)} for k, v in agg.items()}
 step = [k for k in summary.get("FETCH_SIZE", {}) if "k_step_lane" in k]
 if step and any("k_step_lane" in k for k in summary.get("WRITE_SIZE", {})):
