@@ -96,14 +96,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    distributed = world > 1 or os.environ.get("ZENV_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank rehearsal
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
-    if world > 1:
+    if distributed:
         dist.barrier()
     import combinatorial_rl_tasks_amd as Z
     from combinatorial_rl_tasks_amd import sharding
@@ -130,7 +131,7 @@ def main():
     def fence():
         env.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -145,7 +146,7 @@ def main():
 
     # rank-local results, then the one collective of the job: all-gather of episodic returns
     returns = shard.gather_returns(env)          # float32 [world * n_env] on every rank
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -197,7 +198,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     env.close()
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
     return out

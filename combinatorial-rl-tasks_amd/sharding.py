@@ -37,7 +37,7 @@ class EnvShard:
         ordered by global env index."""
         import torch
         import torch.distributed as dist
-        if self.world == 1 or not dist.is_initialized():
+        if not dist.is_initialized():
             return local.clone()
         out = torch.empty(self.world * self.n, dtype=local.dtype, device=local.device)
         if dist.get_backend() == "nccl":
@@ -51,7 +51,8 @@ class EnvShard:
         """Episodic return of each env's last finished episode, float32, all ranks."""
         from . import _native as nat
         import torch
-        if self.world == 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
             return env.get(nat.F_LAST_RETURN).astype(np.float32)
         buf = torch.empty(self.n, dtype=torch.float64, device=f"cuda:{env.device}")
         env.get_into_device(nat.F_LAST_RETURN, buf.data_ptr())
