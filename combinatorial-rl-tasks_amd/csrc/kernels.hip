@@ -709,6 +709,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
     EnvRegs e;
     e.steps = 0;
     float o[8];   // physics wave: this step's obs
+    int pf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // zone wave: reset prefetch, one dword per cache line
 
     if (role == 0) {
         // =================================================================== zone wave
@@ -757,39 +758,11 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             }
         }
 
-        // ---- reset prefetch.  An episode can only end this step on the time limit or when at
-        // most one zone is still open (ColourMatch: Hamming distance <= 2).  For those few envs
-        // request every cache line of the next episode's bank rows now, behind the zone loads:
-        // they land during the zone pass, so the cooperative reset below (which only learns
-        // about the termination after the zone pass) finds them on chip instead of paying a
-        // cold HBM round trip at the end of this wave's critical path.  Nothing is consumed
-        // here; the registers are only kept alive until the end of the wave.
-        int pf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        if (valid && !was_done && auto_reset && p.sched_mode == SCHED_SEQUENTIAL) {
-            const int open_zones = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : Z - (int)__popc(e.vis);
-            if (e.steps + 1 >= p.num_steps || open_zones <= (TASK == ZENV_TASK_COLOUR_MATCH ? 2 : 1)) {
-                const long long sl = ((long long)slot_first + (long long)epi_idx * (long long)p.sched_stride) %
-                                     (long long)p.bank_size;
-                const int *bz = reinterpret_cast<const int *>(p.bank_zone + 2 * (size_t)sl * Z);
-                pf[0] = bz[0];                                   // 128-B lines of the 16*Z-byte zone block
-                if (4 * Z > 32) pf[1] = bz[32];
-                if (4 * Z > 64) pf[2] = bz[64];
-                if (4 * Z > 96) pf[3] = bz[96];
-                pf[4] = bz[4 * Z - 1];
-                pf[5] = reinterpret_cast<const int *>(p.bank_robot + 4 * (size_t)sl)[0];
-                if (TASK != ZENV_TASK_TSP) {
-                    const int *ba = p.bank_aux + (size_t)sl * Z;
-                    pf[6] = ba[0];
-                    pf[7] = ba[Z - 1];
-                }
-                pf[8] = (int)p.bank_seed[sl];
-            }
-        }
-
         float rew_out = 0.f;
         uint8_t done_out = 1, goal_out = 0;
         int mode = 1;
         bool need_reset = false;
+        bool ends_soon = false;   // may terminate at the NEXT step: its bank rows get prefetched below
         if (valid && was_done) {
             // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
             for (int z = 0; z < Z; ++z) my_ents[z] = make_float4(0.f, 0.f, -1.f, 0.f);
@@ -842,6 +815,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                     }
                     if (TASK == ZENV_TASK_TIMED_TSP) {
                         if (!vis && (aux - k) <= 0) timed_out = true;   // TTSP_env.py:67
+                        if (!vis && (aux - k) <= 1) ends_soon = true;
                     }
                     my_ents[z] = make_entry<TASK>(p, zx, zy, vis ? 1 : 0, aux, k);
                 }
@@ -885,6 +859,34 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 if (auto_reset) need_reset = true;
                 else p.done_state[env] = 1;
             }
+            // next step ends the episode for sure (time limit / a deadline) or possibly (one zone
+            // left; ColourMatch: one cycle from the goal)
+            const int open_zones = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : Z - (int)__popc(e.vis);
+            ends_soon = !done && (ends_soon || k + 1 >= p.num_steps ||
+                                  open_zones <= (TASK == ZENV_TASK_COLOUR_MATCH ? 2 : 1));
+        }
+
+        // ---- reset prefetch, one step ahead.  For the few envs that can terminate at the next
+        // step, request every cache line of their next episode's bank rows now: they are on chip
+        // (L2 / Infinity Cache) when the cooperative reset of the next launch asks for them,
+        // instead of costing it a cold HBM round trip at the end of its critical path.  Nothing
+        // is consumed here; the registers are only kept alive until the end of the wave.
+        if (ends_soon && auto_reset && p.sched_mode == SCHED_SEQUENTIAL) {
+            const long long sl = ((long long)slot_first + (long long)epi_idx * (long long)p.sched_stride) %
+                                 (long long)p.bank_size;
+            const int *bz = reinterpret_cast<const int *>(p.bank_zone + 2 * (size_t)sl * Z);
+            pf[0] = bz[0];                                   // 128-B lines of the 16*Z-byte zone block
+            if (4 * Z > 32) pf[1] = bz[32];
+            if (4 * Z > 64) pf[2] = bz[64];
+            if (4 * Z > 96) pf[3] = bz[96];
+            pf[4] = bz[4 * Z - 1];
+            pf[5] = reinterpret_cast<const int *>(p.bank_robot + 4 * (size_t)sl)[0];
+            if (TASK != ZENV_TASK_TSP) {
+                const int *ba = p.bank_aux + (size_t)sl * Z;
+                pf[6] = ba[0];
+                pf[7] = ba[Z - 1];
+            }
+            pf[8] = (int)p.bank_seed[sl];
         }
 
         // ---- auto-reset (penv.py:8-11), wave-cooperative: for each finished env of the tile,
@@ -971,8 +973,6 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             p.done_out[env] = done_out;
             p.goal_met[env] = goal_out;
         }
-        asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]),
-                     "v"(pf[7]), "v"(pf[8]));
         ZSTAMP(2);
     } else {
         // =================================================================== physics wave
@@ -1006,6 +1006,8 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 1)   // diagnostic builds only: ZENV_EXP bit 0 drops the flush
         flush_entries<TASK>(ents, stage, p.zone_obs + (size_t)env0 * Z * F, n_blk * Z, lane);
 #endif
+        asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]),
+                     "v"(pf[7]), "v"(pf[8]));
         ZSTAMP(3);
     } else if (env < N) {
         if (xmode[lane] == 0) {
