@@ -29,6 +29,7 @@ struct DevParams {
     double b0, b1, b2;
     double A22, inv00, inv11;
     double hit_d2;        // largest d2 with sqrt(d2) <= zones_size
+    float d2_lo, d2_hi;   // float32 prefilter shell around zones_size^2 (see kernels.hip)
     double tsr;           // time_saved_reward
     double inv3, inv1_5;  // RN(1/3), RN(1/1.5)
     double d_steps, inv_steps;   // (double)num_steps and RN(1/num_steps)
@@ -36,7 +37,8 @@ struct DevParams {
     // state
     double2 *qa, *qb, *qc;   // (q0,q1) (q2,v0) (v1,v2): 16 B/lane accesses
     double2 *fa, *fb;        // (x0,y0) (bq0,bq3)
-    double2 *zxy;            // [Z][N] (zone x, zone y)
+    double2 *zxy;            // [Z][N] (zone x, zone y): exact centres (rim test, resets)
+    float4 *zpf;             // [ceil(Z/2)][N] float32 (x/3, y/3) of zones 2h and 2h+1
     uint32_t *vis;
     int32_t *tmax;
     uint64_t *colpack;

@@ -30,9 +30,13 @@ constexpr int kWave = 64;
 // Diagnostic build only (-DZENV_STAMPS, never shipped): lane 0 of each wave drops
 // s_memrealtime (100 MHz) stamps into p.dbg[block][16] at phase boundaries.
 #ifdef ZENV_STAMPS
-#define ZSTAMP(slot)                                                                                        \
-    do {                                                                                                    \
-        if (p.dbg && lane == 0) p.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+#define ZSTAMP(slot)                                                                                  \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (p.dbg && lane == 0) p.dbg[(size_t)blockIdx.x * 16 + (slot)] = t_;                         \
     } while (0)
 #else
 #define ZSTAMP(slot) do { } while (0)
@@ -290,6 +294,7 @@ __device__ __forceinline__ void reset_env(const DevParams &p, int env, int slot,
     e.steps = 0;
     const double *bz = p.bank_zone + 2 * (size_t)slot * Z;
     const int32_t *ba = p.bank_aux + (size_t)slot * Z;
+    float4 pair = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int z = 0; z < Z; ++z) {
         const double zx = bz[2 * z], zy = bz[2 * z + 1];
         const size_t zi = (size_t)z * N + env;
@@ -303,7 +308,10 @@ __device__ __forceinline__ void reset_env(const DevParams &p, int env, int slot,
             e.colpack |= (uint64_t)code << (2 * z);
             p.cooldown[zi] = 0;
         }
-        sink.template put<TASK>(z, make_entry<TASK>(p, zx, zy, code, aux, 0));
+        const float4 en = make_entry<TASK>(p, zx, zy, code, aux, 0);
+        sink.template put<TASK>(z, en);
+        if (z & 1) { pair.z = en.x; pair.w = en.y; } else { pair = make_float4(en.x, en.y, 0.f, 0.f); }
+        if ((z & 1) || z == Z - 1) p.zpf[(size_t)(z >> 1) * N + env] = pair;
     }
     if (TASK == ZENV_TASK_COLOUR_MATCH) e.goal_dist = hamming_to_goal(e.colpack, Z);
     p.seed[env] = p.bank_seed[slot];
@@ -694,6 +702,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
     constexpr int F = TaskTraits<TASK>::F;
     constexpr int G = TaskTraits<TASK>::G;
     constexpr int ZR = ZT > 0 ? ZT : 1;
+    constexpr int ZH = ZT > 0 ? (ZT + 1) / 2 : 1;
     const int lane = threadIdx.x & (kWave - 1);
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
     const int env0 = blockIdx.x * kWave;
@@ -717,7 +726,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         const bool valid = env < N;
         uint8_t was_done = 0;
         double ep_ret = 0.0;
-        double zxr[ZR], zyr[ZR];
+        float4 zp[ZH];      // float32 zone positions (x/3, y/3), two zones per 16-byte load
         int auxr[ZR];
         int epi_idx = 0, slot_first = 0;
         if (valid) {
@@ -737,18 +746,15 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 e.vis = p.vis[env];
             }
             ep_ret = p.ep_return[env];
-            epi_idx = p.episode_idx[env];     // the bank slot of a reset is known before it happens
-            slot_first = p.slot_first[env];
             if (ZT > 0) {
-                // issue order = consumption order: pose first, then zone 0, 1, ... so the
-                // in-order vmcnt waits of the zone pass release one zone at a time
+                // issue order = consumption order: pose first, then zone pairs 0, 1, ... so the
+                // in-order vmcnt waits of the zone pass release one pair at a time
                 __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h = 0; h < ZH; ++h) zp[h] = p.zpf[(size_t)h * N + env];   // 1 KiB per wave
 #pragma unroll
                 for (int z = 0; z < ZR; ++z) {
                     const size_t zi = (size_t)z * N + env;
-                    const double2 zz = p.zxy[zi];   // one 16 B/lane load: 1 KiB per wave
-                    zxr[z] = zz.x;
-                    zyr[z] = zz.y;
                     auxr[z] = 0;
                     if (TASK == ZENV_TASK_TIMED_TSP) auxr[z] = p.tmax[zi];
                     if (TASK == ZENV_TASK_COLOUR_MATCH) auxr[z] = p.cooldown[zi];
@@ -756,6 +762,9 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 // nothing below may be scheduled above this point, nor any load below it
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // only needed at the very end (reset / prefetch): requested behind the zone loads
+            epi_idx = p.episode_idx[env];     // the bank slot of a reset is known before it happens
+            slot_first = p.slot_first[env];
         }
 
         float rew_out = 0.f;
@@ -763,6 +772,10 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         int mode = 1;
         bool need_reset = false;
         bool ends_soon = false;   // may terminate at the NEXT step: its bank rows get prefetched below
+        bool timed_out = false;
+        int first = -1;
+        const int k = e.steps + 1;   // step index after this call
+        const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
         if (valid && was_done) {
             // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
             for (int z = 0; z < Z; ++z) my_ents[z] = make_float4(0.f, 0.f, -1.f, 0.f);
@@ -770,57 +783,95 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             store_obs8(p, env, o);
             if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = make_float2(0.f, 0.f);
         } else if (valid) {
-            const int k = e.steps + 1;   // step index after this call
             double rx, ry;               // pre-physics pose: what set_mocaps() sees
             world_pos(e, rx, ry);
             ZSTAMP(1);
 
-            // ---- zone pass: set_mocaps() of the first substep
-            int first = -1;
-            bool timed_out = false;
+            // ---- zone pass: set_mocaps() of the first substep (TSP_env.py:54-69,
+            // colour_match_env.py:98-120).  "Inside" is decided per zone from the float32 zone
+            // positions the obs rows need anyway: d2f differs from the exact float64 d2 by
+            // < 2.1e-7 near the rim (float rounding of x/3, y/3 and of the pose), so outside the
+            // shell [d2_lo, d2_hi] (+-8e-7 around r^2) the float verdict IS the exact verdict;
+            // inside the shell (about once per 10^7 env-steps) the exact float64 test below
+            // decides.  Everything is collected in bit masks; the lowest set bit wins.
+            const float rxf = (float)rx, ryf = (float)ry;
+            uint32_t in_mask = 0u, amb_mask = 0u, elig_mask = 0u, expired = 0u, expiring = 0u;
 #pragma unroll
             for (int z = 0; z < (ZT > 0 ? ZT : Z); ++z) {
                 const size_t zi = (size_t)z * N + env;
-                double zx, zy;
                 int aux = 0;
+                float4 pr;
                 if (ZT > 0) {
-                    zx = zxr[z]; zy = zyr[z]; aux = auxr[z];
+                    pr = zp[z >> 1];
+                    aux = auxr[z];
                 } else {
-                    const double2 zz = p.zxy[zi];
-                    zx = zz.x; zy = zz.y;
+                    pr = p.zpf[(size_t)(z >> 1) * N + env];
                     if (TASK == ZENV_TASK_TIMED_TSP) aux = p.tmax[zi];
                     if (TASK == ZENV_TASK_COLOUR_MATCH) aux = p.cooldown[zi];
                 }
-                const double dx = zx - rx, dy = zy - ry;
-                const double d2 = dx * dx + dy * dy;
-                const bool inside = d2 <= p.hit_d2;
+                const float x3 = (z & 1) ? pr.z : pr.x, y3 = (z & 1) ? pr.w : pr.y;
+                const float dxf = __builtin_fmaf(3.f, x3, -rxf), dyf = __builtin_fmaf(3.f, y3, -ryf);
+                const float d2f = __builtin_fmaf(dxf, dxf, dyf * dyf);
+                const bool in_sure = d2f < p.d2_lo, out_sure = d2f > p.d2_hi;
+                in_mask |= (in_sure ? 1u : 0u) << z;
+                amb_mask |= ((in_sure || out_sure) ? 0u : 1u) << z;
+                float4 en = make_float4(x3, y3, 0.f, 0.f);
                 if (TASK == ZENV_TASK_COLOUR_MATCH) {
                     int cd = aux;
-                    if (cd > 0) cd -= 1;                       // colour_match_env.py:98-100
-                    int col = (int)((e.colpack >> (2 * z)) & 3ull);
-                    if (first < 0 && cd == 0 && inside) {       // :106-120, lowest index wins
-                        first = z;
-                        col = (col == 2) ? 0 : col + 1;         // Blue->Green->Red->Blue
-                        e.colpack = (e.colpack & ~(3ull << (2 * z))) | ((uint64_t)col << (2 * z));
-                        cd = p.max_cd;
-                    }
+                    if (cd > 0) cd -= 1;                        // colour_match_env.py:98-100
+                    elig_mask |= (cd == 0 ? 1u : 0u) << z;
                     p.cooldown[zi] = (uint8_t)cd;
-                    my_ents[z] = make_entry<TASK>(p, zx, zy, col, cd, k);
+                    en.z = (float)(int)((e.colpack >> (2 * z)) & 3ull);
+                    en.w = (float)div_const((double)(float)cd, p.d_maxcd, p.inv_maxcd);
                 } else {
-                    bool vis = (e.vis >> z) & 1u;
-                    if (first < 0 && !vis && inside) {          // TSP_env.py:54-69
-                        first = z;
-                        vis = true;
-                        e.vis |= 1u << z;
-                    }
+                    const bool vis = (e.vis >> z) & 1u;
+                    en.z = vis ? 1.f : 0.f;
                     if (TASK == ZENV_TASK_TIMED_TSP) {
-                        if (!vis && (aux - k) <= 0) timed_out = true;   // TTSP_env.py:67
-                        if (!vis && (aux - k) <= 1) ends_soon = true;
+                        expired |= ((aux - k) <= 0 ? 1u : 0u) << z;     // TTSP_env.py:67
+                        expiring |= ((aux - k) <= 1 ? 1u : 0u) << z;
+                        en.w = vis ? 1.f : (float)div_const((double)(aux - k), p.d_steps, p.inv_steps);
                     }
-                    my_ents[z] = make_entry<TASK>(p, zx, zy, vis ? 1 : 0, aux, k);
+                }
+                my_ents[z] = en;
+            }
+            if (amb_mask & full) {
+                // the rim: exact float64 test on the float64 zone centres (rare, divergent)
+                uint32_t m = amb_mask & full;
+                while (m) {
+                    const int z = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const double2 zz = p.zxy[(size_t)z * N + env];
+                    const double dx = zz.x - rx, dy = zz.y - ry;
+                    if (dx * dx + dy * dy <= p.hit_d2) in_mask |= 1u << z;
                 }
             }
+            if (TASK != ZENV_TASK_COLOUR_MATCH) elig_mask = ~e.vis;
+            const uint32_t hits = in_mask & elig_mask & full;
+            first = hits ? __ffs((int)hits) - 1 : -1;                // lowest index wins, one per step
+            if (first >= 0) {
+                if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                    int col = (int)((e.colpack >> (2 * first)) & 3ull);
+                    col = (col == 2) ? 0 : col + 1;                  // Blue->Green->Red->Blue
+                    e.colpack = (e.colpack & ~(3ull << (2 * first))) | ((uint64_t)col << (2 * first));
+                    p.cooldown[(size_t)first * N + env] = (uint8_t)p.max_cd;
+                    float *slot = reinterpret_cast<float *>(my_ents + first);
+                    slot[2] = (float)col;
+                    slot[3] = (float)div_const((double)(float)p.max_cd, p.d_maxcd, p.inv_maxcd);
+                } else {
+                    e.vis |= 1u << first;
+                    float *slot = reinterpret_cast<float *>(my_ents + first);
+                    slot[2] = 1.f;
+                    if (TASK == ZENV_TASK_TIMED_TSP) slot[3] = 1.f;
+                }
+            }
+            if (TASK == ZENV_TASK_TIMED_TSP) {
+                timed_out = (expired & ~e.vis & full) != 0u;
+                ends_soon = (expiring & ~e.vis & full) != 0u;
+            }
+        }
 
+        ZSTAMP(14);
+        if (valid && !was_done) {
             // ---- reward / goal / termination (Engine.step order; none of it needs the physics)
             double r = 0.0;
             bool goal;
@@ -833,8 +884,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 goal = e.goal_dist == 0;
             } else {
                 r = first >= 0 ? 1.0 : 0.0;
-                const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
-                goal = e.vis == full;
+                goal = (e.vis & full) == full;
             }
             bool done = false;
             if (goal) {
@@ -866,6 +916,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                                   open_zones <= (TASK == ZENV_TASK_COLOUR_MATCH ? 2 : 1));
         }
 
+        ZSTAMP(6);
         // ---- reset prefetch, one step ahead.  For the few envs that can terminate at the next
         // step, request every cache line of their next episode's bank rows now: they are on chip
         // (L2 / Infinity Cache) when the cooperative reset of the next launch asks for them,
@@ -889,6 +940,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             pf[8] = (int)p.bank_seed[sl];
         }
 
+        ZSTAMP(15);
         // ---- auto-reset (penv.py:8-11), wave-cooperative: for each finished env of the tile,
         // lane z fetches zone z of the new layout (one 400-byte coalesced burst from the bank
         // instead of Z dependent round trips in one lane) and writes it to the zone array and to
@@ -922,6 +974,13 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                     }
                     en = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
                     ents[j * Z + lane] = en;
+                }
+                {
+                    // float32 positions, two zones per float4: even lanes pick up their odd neighbour
+                    const float nx = __shfl_down(en.x, 1), ny = __shfl_down(en.y, 1);
+                    if (lane < Z && !(lane & 1))
+                        p.zpf[(size_t)(lane >> 1) * N + env_j] =
+                            make_float4(en.x, en.y, lane + 1 < Z ? nx : 0.f, lane + 1 < Z ? ny : 0.f);
                 }
                 ZSTAMP(6);
                 uint64_t colpack = 0ull;

@@ -104,6 +104,12 @@ void derive_constants(const zenv_config &c, DevParams &p)
     p.inv00 = 1.0 / A00;
     p.inv11 = 1.0 / A11;
     p.hit_d2 = sqrt_threshold(c.zones_size);
+    {
+        // prefilter shell: +-2e-6 on the radius, i.e. +-8e-7 on r^2 at r = 0.2 (4x the float error bound)
+        const double lo = (c.zones_size - 2e-6) * (c.zones_size - 2e-6), hi = (c.zones_size + 2e-6) * (c.zones_size + 2e-6);
+        p.d2_lo = std::nextafterf((float)lo, 0.f);
+        p.d2_hi = std::nextafterf((float)hi, INFINITY);
+    }
     p.tsr = c.time_saved_reward;
     p.inv3 = 1.0 / 3.0;
     p.inv1_5 = 1.0 / 1.5;
@@ -296,6 +302,7 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
     want(h, p.qa, N, true); want(h, p.qb, N, true); want(h, p.qc, N, true);
     want(h, p.fa, N, true); want(h, p.fb, N, true);
     want(h, p.zxy, Z * N, true);
+    want(h, p.zpf, ((Z + 1) / 2) * N, true);
     want(h, p.vis, N, true);
     want(h, p.tmax, Z * N, true);
     want(h, p.colpack, N, true);

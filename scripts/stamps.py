@@ -29,7 +29,7 @@ for it in range(20):
 a = np.stack(acc)                       # [it, block, slot], 10 ns ticks
 t0 = a[:, :, [0, 8]].min(axis=(1, 2), keepdims=True)   # first wave start of the launch
 rel = (a - t0) * 0.01                   # us
-names = {0: "Z start", 1: "Z loads landed (pose ready)", 2: "Z zone pass done", 3: "Z flush issued",
+names = {0: "Z start", 1: "Z pose ready", 14: "Z zone loop done", 6: "Z finalize math done", 15: "Z prefetch issued", 2: "Z at barrier (finalize+reset done)", 3: "Z flush issued",
          4: "Z past barrier", 8: "P start", 9: "P loads landed", 10: "P physics done", 11: "P past barrier",
          12: "P obs8 stored", 13: "P end"}
 print(sys.argv[1:], "fused" if fused else "unfused", "episodes so far", int(env.get(Z.F_EPISODES).sum()))

@@ -193,3 +193,56 @@ def test_fixed_seeds_schedule_on_device(zenv_mod):
         want = [int(g.integers(low=lo, high=hi + 1, size=1)[0]) for _ in range(5)]
         assert seen[i].tolist() == want
     env.close()
+
+
+@pytest.mark.parametrize("task", [0, 1, 2])
+def test_rim_zones_take_the_exact_path(zenv_mod, oracle_mod, task):
+    """Zones placed within +-3e-6 of the 0.2 rim (inside the float32 prefilter's ambiguous shell,
+    and just outside it on both sides): the device verdicts must be the oracle's float64
+    sqrt(dx^2+dy^2) <= 0.2 verdicts, zone by zone, step by step."""
+    Z, O = zenv_mod, oracle_mod
+    n_zone, n = 15, 70
+    cfg = Z.default_config(task, n_zone)
+    ocfg = oracle_config_from(O, cfg)
+    rng = np.random.RandomState(123)
+    robots, zones, auxs, refs = [], [], [], []
+    offsets = np.array([0.0, 1e-12, -1e-12, 1e-9, -1e-9, 3e-8, -3e-8, 2e-7, -2e-7, 9e-7, -9e-7,
+                        1.9e-6, -1.9e-6, 3e-6, -3e-6])
+    for i in range(n):
+        ref = O.OracleEnv(ocfg)
+        ref.reset(500 + i)                      # gives rot / colours / tmax of a real reset
+        rx, ry = rng.uniform(-2.5, 2.5, 2)
+        ang = rng.uniform(0, 2 * np.pi, n_zone)
+        zxy = np.stack([rx + (0.2 + offsets) * np.cos(ang), ry + (0.2 + offsets) * np.sin(ang)], 1)
+        ref.e.x0, ref.e.y0 = rx, ry
+        ref.e.xpos[0], ref.e.xpos[1] = rx, ry
+        for z in range(n_zone):
+            ref.e.zone_xy[z][0], ref.e.zone_xy[z][1] = zxy[z]
+        robots.append([rx, ry, ref.e.rot]); zones.append(zxy)
+        auxs.append(ref.state()["tmax"] if task == 1 else ref.state()["colour"])
+        refs.append(ref)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.set_bank(np.array(robots), np.array(zones), np.array(auxs, np.int32), np.arange(n))
+    env.schedule_sequential()
+    env.reset()
+    a = np.zeros((n, 2), np.float32)
+    seen_inside = 0
+    for t in range(n_zone + 2):
+        env.step(a, auto_reset=False)
+        st = env.debug_state()
+        r = env.get(Z.F_REWARD)
+        for i, ref in enumerate(refs):
+            if ref.e.done:
+                continue
+            rr, d, g = ref.step(a[i])
+            key = "colour" if task == 2 else "visited"
+            assert np.array_equal(st["zone_state"][i], ref.state()[key]), (i, t)
+            assert r[i] == np.float32(rr)
+            seen_inside += int(rr != 0)
+        o, zo = env.observations()
+        for i in (0, n // 2, n - 1):
+            if not refs[i].e.done:
+                o_ref, zo_ref = refs[i].obs()
+                assert np.array_equal(zo[i], zo_ref) and np.array_equal(o[i], o_ref)
+    assert seen_inside > 4 * n        # about half of the rim zones are inside
+    env.close()
