@@ -1,0 +1,131 @@
+"""GPU edge cases: smallest / largest zone counts (runtime-Z kernel path), ragged and tiny batches,
+argument validation, out-of-range actions, a large batch."""
+import numpy as np
+import pytest
+
+from tests.helpers import OracleBatch, oracle_config_from
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("task,zones,keepout,n", [(0, 1, 0.55, 1), (0, 32, 0.30, 67), (1, 32, 0.30, 63),
+                                                  (2, 32, 0.30, 65), (2, 1, 0.55, 5), (1, 2, 0.55, 129)])
+def test_zone_count_extremes_lockstep(zenv_mod, oracle_mod, task, zones, keepout, n):
+    Z, O = zenv_mod, oracle_mod
+    cfg = Z.default_config(task, zones, zones_keepout=keepout, num_steps=300)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(77, n)
+    env.schedule_sequential()
+    env.reset()
+    ob = OracleBatch(O, oracle_config_from(O, cfg), range(77, 77 + n))
+    o_ref, zo_ref = ob.reset()
+    o, zo = env.observations()
+    assert np.array_equal(o, o_ref) and np.array_equal(zo, zo_ref)
+    for t in range(420):
+        a = ob.policy(O.POLICY_GREEDY if t % 5 else O.POLICY_UNIFORM, o_ref, zo_ref, t)
+        env.step(a, auto_reset=True)
+        r_ref, d_ref, g_ref = ob.step(a)
+        o_ref, zo_ref = ob.obs()
+        o, zo, r, d, g = env.results()
+        assert np.array_equal(d, d_ref) and np.array_equal(g, g_ref), t
+        assert np.array_equal(r, r_ref.astype(np.float32)), t
+        assert np.array_equal(o, o_ref) and np.array_equal(zo, zo_ref), t
+    env.close()
+
+
+def test_fused_rollout_runtime_zone_count(zenv_mod, oracle_mod):
+    """Z = 32 / 9 have no compile-time instantiation: the generic kernel + fused policy path."""
+    Z, O = zenv_mod, oracle_mod
+    for task, zones in ((0, 32), (2, 9), (1, 11)):
+        n, T = 200, 350
+        cfg = Z.default_config(task, zones, zones_keepout=0.30, num_steps=150)
+        env = Z.ZoneVecEnv(cfg, n)
+        env.build_bank(1, 24 * n)
+        env.schedule_sequential(stride=n)
+        env.reset()
+        env.rollout(T, Z.POLICY_GREEDY, policy_seed=3)
+        ref = O.rollout(oracle_config_from(O, cfg), 1 + np.arange(n), T, O.POLICY_GREEDY, seed_stride=n,
+                        policy_seed=3, n_threads=8)
+        assert 0 < ref["episodes"].max() < 24
+        assert np.array_equal(env.get(Z.F_EPISODES), ref["episodes"])
+        assert np.array_equal(env.get(Z.F_OBS), ref["obs"])
+        assert np.array_equal(env.get(Z.F_ZONE_OBS), ref["zone_obs"])
+        assert np.array_equal(env.get(Z.F_LAST_RETURN), ref["last_return"])
+        env.close()
+
+
+def test_out_of_range_and_nonfinite_actions(zenv_mod, oracle_mod):
+    """Engine.step clips to the actuator ctrlrange; NaN propagates identically on both sides."""
+    Z, O = zenv_mod, oracle_mod
+    cfg = Z.config_for_id("PointTSP-v1")
+    n = 8
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(5, n)
+    env.reset()
+    ob = OracleBatch(O, oracle_config_from(O, cfg), range(5, 5 + n))
+    ob.reset()
+    a = np.array([[5.0, -7.0], [-np.inf, np.inf], [1e-30, -1e-30], [0.049, 0.9], [0.051, -0.9],
+                  [np.nan, 0.5], [1.0, np.nan], [-0.0, 0.0]], np.float32)
+    for t in range(25):
+        env.step(a, auto_reset=True)
+        ob.step(a)
+        o, zo = env.observations()
+        o_ref, zo_ref = ob.obs()
+        assert np.array_equal(o, o_ref, equal_nan=True) and np.array_equal(zo, zo_ref)
+    assert np.isnan(o[5]).any() and not np.isnan(o[:5]).any()
+    env.close()
+
+
+def test_argument_validation(zenv_mod):
+    Z = zenv_mod
+    E = Z._native
+    with pytest.raises(Z.ZenvError) as ei:
+        Z.ZoneVecEnv(Z.default_config(0, 15), 0)
+    assert ei.value.code == E.E_ARG
+    for bad in (dict(num_zones=33), dict(num_zones=0), dict(num_steps=0), dict(max_cd=256), dict(frameskip=0),
+                dict(kernel=E.KERNEL_WAVE_PER_ENV), dict(task=3)):
+        cfg = Z.default_config(0, 15)
+        for k, v in bad.items():
+            setattr(cfg, k, v)
+        with pytest.raises(Z.ZenvError):
+            Z.ZoneVecEnv(cfg, 4)
+    with pytest.raises(Z.ZenvError):
+        Z.ZoneVecEnv(Z.default_config(0, 15), 4, device=99)
+    env = Z.ZoneVecEnv("PointTSP-v1", 4)
+    with pytest.raises(Z.ZenvError) as ei:
+        env.reset()                                   # no bank yet
+    assert ei.value.code == E.E_STATE
+    with pytest.raises(Z.ZenvError) as ei:
+        env.step(np.zeros((4, 2), np.float32))        # 'Environment must be reset before stepping'
+    assert ei.value.code == E.E_STATE
+    env.build_bank(1, 3)
+    with pytest.raises(Z.ZenvError):
+        env.schedule_sequential(first=np.array([0, 1, 2, 3], np.int32))   # slot 3 outside the bank
+    with pytest.raises(Z.ZenvError):
+        env.schedule_fixed_seeds(np.zeros(4, np.uint64), 1, 100)          # bank holds 3 seeds, not 100
+    with pytest.raises(ValueError):
+        env.reset(np.zeros(3, np.uint8))
+    env.reset()
+    with pytest.raises(ValueError):
+        env.step(np.zeros((5, 2), np.float32))
+    with pytest.raises(Z.ZenvError):
+        env.set_state(np.zeros(10, np.uint8))         # wrong blob size
+    env.close()
+    env.close()                                       # idempotent
+
+
+def test_large_batch_runs(zenv_mod, oracle_mod):
+    """1 M envs in one handle (the 8-GPU config's per-node total): state + bank stay under 2 GB."""
+    Z, O = zenv_mod, oracle_mod
+    n = 1 << 20
+    cfg = Z.default_config(0, 25, zones_keepout=0.40)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(1, 4096, n_threads=16)
+    env.schedule_sequential()
+    env.reset()
+    env.rollout(30, Z.POLICY_GREEDY)
+    ref = O.rollout(oracle_config_from(O, cfg), 1 + (np.arange(4096 * 3, 4096 * 3 + 64) % 4096), 30,
+                    O.POLICY_GREEDY, env_index0=4096 * 3)
+    assert np.array_equal(env.get(Z.F_OBS)[4096 * 3:4096 * 3 + 64], ref["obs"])
+    assert np.array_equal(env.get(Z.F_ZONE_OBS)[-64:], env.get(Z.F_ZONE_OBS)[4096 - 64:4096])   # same maps
+    env.close()
