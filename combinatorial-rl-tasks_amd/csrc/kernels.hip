@@ -385,13 +385,25 @@ __device__ __forceinline__ void wave_lds_fence()
 // (the tile's contiguous [n_rows][F] block of zone_obs) as dwordx4 bursts.  Each lane
 // expands RPC consecutive rows = G whole float4 into the wave-private staging slab, which
 // is then read back lane-linear so that one store instruction covers 1 KiB of contiguous HBM.
+// Cache policy of the tile stores (buffer_store aux bits: 1 = sc0, 2 = nt, 16 = sc1).
+// zone_obs is write-once, read-by-nobody-in-this-launch streaming output (39 MB per step at
+// N = 65 536, more than the aggregate L2): marking it non-temporal keeps it from pushing the
+// step's re-read state (zone positions, joint state: 24 MB) out of the XCD L2s.  Measured on
+// PointTSP-25: plain 14.0 us, sc1 12.8 us, nt 12.65 us per launch.
+#ifndef ZENV_STORE_AUX
+#define ZENV_STORE_AUX 2
+#endif
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
 template <int TASK>
 __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage, float *dst, int n_rows,
                                               int lane)
 {
     constexpr int F = TaskTraits<TASK>::F, RPC = TaskTraits<TASK>::RPC, G = TaskTraits<TASK>::G;
     const int n_chunks = n_rows / RPC;
-    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    // dst is wave-uniform: one buffer descriptor for the tile's [n_rows][F] block
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(dst, 0, n_rows * F * (int)sizeof(float), 0x00020000);
     int c0 = 0;
     // full iterations: 64 chunks = 64*G float4, no guards
     for (; c0 + kWave <= n_chunks; c0 += kWave) {
@@ -407,7 +419,10 @@ __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage,
 #pragma unroll
         for (int g = 0; g < G; ++g) t[g] = stage[g * kWave + lane];
 #pragma unroll
-        for (int g = 0; g < G; ++g) d4[(size_t)c0 * G + g * kWave + lane] = t[g];
+        for (int g = 0; g < G; ++g) {
+            const v4f_t val = { t[g].x, t[g].y, t[g].z, t[g].w };
+            __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + g * kWave + lane) * 16, 0, ZENV_STORE_AUX);
+        }
         wave_lds_fence();
     }
     // last, partial iteration
@@ -426,7 +441,11 @@ __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage,
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int i = g * kWave + lane;
-            if (i < n4) d4[(size_t)c0 * G + i] = stage[i];
+            if (i < n4) {
+                const float4 tv = stage[i];
+                const v4f_t val = { tv.x, tv.y, tv.z, tv.w };
+                __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + i) * 16, 0, ZENV_STORE_AUX);
+            }
         }
         wave_lds_fence();
     }
