@@ -32,7 +32,8 @@ def build_library(force=False, verbose=False):
         if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in _deps()):
             return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("ZENV_EXTRA_FLAGS", "").split()      # experiments only (e.g. -DZENV_STORE_AUX=16)
+    cmd = [_hipcc()] + FLAGS + extra + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

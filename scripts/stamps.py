@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import combinatorial_rl_tasks_amd.build as B
 so = os.path.join(ROOT, "gpurun_out", "libzenv_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.run([B._hipcc()] + B.FLAGS + ["-DZENV_STAMPS", "-o", so] + [os.path.join(B.CSRC, s) for s in B.SOURCES], check=True)
+subprocess.run([B._hipcc()] + B.FLAGS + ["-DZENV_STAMPS"] + os.environ.get("ZENV_EXTRA_FLAGS", "").split() + ["-o", so] + [os.path.join(B.CSRC, s) for s in B.SOURCES], check=True)
 import combinatorial_rl_tasks_amd._native as nat
 nat.LIB_PATH = so
 import combinatorial_rl_tasks_amd as Z
