@@ -56,13 +56,14 @@ def algorithmic_bytes(task, Z):
     return reads + writes
 
 
-def load_traffic(workload, n_env):
-    """Measured HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes."""
+def load_traffic(workload, n_env, mode="per_step"):
+    """Measured HBM bytes per kernel launch from the committed rocprofv3 PMC passes."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        ent = t.get(f"{workload}@{n_env}")
+        key = f"{workload}@{n_env}" + ("" if mode != "persistent" else "@persistent")
+        ent = t.get(key)
         return None if ent is None else ent["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         return None
@@ -78,6 +79,10 @@ def main():
     ap.add_argument("--policy", default="greedy", choices=["greedy", "uniform"])
     ap.add_argument("--override", action="append", default=[],
                     help="experiment only: config key=value (e.g. frameskip=1); marks the run invalid")
+    ap.add_argument("--mode", choices=["persistent", "per_step", "unfused"], default="persistent",
+                    help="persistent: one launch per 64 steps, env state in registers, every step's outputs "
+                         "still written; per_step: one step-kernel launch per step (also emits the next "
+                         "action); unfused: per-step launches + a policy kernel before each")
     ap.add_argument("--unfused", action="store_true",
                     help="run the stand-alone policy kernel before every step instead of the fused action source")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,6 +92,9 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the per-launch HIP events around the step kernel")
     args = ap.parse_args()
+    if args.unfused:
+        args.mode = "unfused"
+    args.unfused = args.mode == "unfused"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,7 +134,7 @@ def main():
     t_bank = time.perf_counter() - t_bank
     env.reset()
     env.rollout(args.warmup, policy, policy_seed=0x5EED, env_index0=shard.env_index0,
-                fused=not args.unfused)
+                mode=args.mode)
 
     def fence():
         env.sync()
@@ -140,7 +148,7 @@ def main():
     ms_total, ms_kernel = env.rollout(args.steps, policy, policy_seed=0x5EED,
                                       env_index0=shard.env_index0, auto_reset=True,
                                       time_step_kernel=not args.no_kernel_events,
-                                      fused=not args.unfused, event_stride=args.event_stride)
+                                      mode=args.mode, event_stride=args.event_stride)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -158,17 +166,24 @@ def main():
         alg = algorithmic_bytes(task, zones)
         roofline = None
         if args.steps > 0 and (ms_kernel is not None or not args.unfused):
-            # Fused mode: the timed region is K back-to-back dispatches of ONE kernel, so the HIP
-            # events that bracket the loop on the kernel's stream give its average launch-to-launch
-            # duration (an upper bound of the dispatch duration: it includes the ~0.5 us gaps).
-            # The begin/end events of every event_stride-th dispatch are reported beside it.
+            # persistent / per_step: the timed region is back-to-back dispatches of ONE kernel, so the
+            # HIP events that bracket the loop on the kernel's stream give its duration per step (an
+            # upper bound of the dispatch duration: it includes the ~0.5 us gaps between launches).
+            # The begin/end events of the dispatches themselves are reported beside it: persistent --
+            # every launch (64 steps each), summed / steps; per_step -- every event_stride-th launch.
             k_avg_s = ms_total / 1e3 / args.steps if not args.unfused else ms_kernel / 1e3
             achieved = alg * n_env / k_avg_s / 1e9
+            persistent = args.mode == "persistent" and zones in (5, 6, 15, 25)
+            chunk = 64
             roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": load_traffic(args.workload, n_env),
-                        "kernel": "k_step_lane", "kernel_avg_us": round(k_avg_s * 1e6, 2),
-                        "kernel_launches_timed": args.steps if not args.unfused else
+                        "traffic": load_traffic(args.workload, n_env, args.mode),
+                        "kernel": "k_rollout_lane" if persistent else "k_step_lane",
+                        "kernel_avg_us": round(k_avg_s * 1e6 * (chunk if persistent else 1), 2),
+                        "steps_per_launch": chunk if persistent else 1,
+                        "kernel_us_per_step": round(k_avg_s * 1e6, 3),
+                        "kernel_launches_timed": (args.steps + chunk - 1) // chunk if persistent else
+                        args.steps if not args.unfused else
                         (args.steps + args.event_stride - 1) // args.event_stride,
                         "sampled_dispatch_avg_us": None if ms_kernel is None else round(ms_kernel * 1e3, 2),
                         "algorithmic_bytes_per_env_step": alg, "env_steps_per_launch": n_env}
@@ -184,7 +199,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}, N_env={n_env} per GPU, num_steps=2000, "
                                    f"zones_keepout={keepout}, policy=pi_{args.policy} (on-device, "
-                                   f"{'own kernel' if args.unfused else 'fused into the step launch'}), "
+                                   f"launch mode {args.mode}), "
                                    "auto-reset on" + (f" EXPERIMENT {args.override}" if args.override else ""),
                        "n_env_total": world * n_env, "zones": zones,
                        "parallelism": f"env-shard x{world}, all-gather(ep_return) after rollout"},

@@ -1102,6 +1102,443 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
     }
 }
 
+// =========================================================================== K1p: persistent rollout
+// K closed-loop steps a_t = pi(obs_t, t); step(a_t) in ONE launch, for the case the rollout API
+// exists for: the action source is on the device (zenv_rollout, fused policy).  Same tile / wave
+// roles and the same per-step arithmetic as k_step_lane, but the env state lives in registers
+// for the whole launch (zone positions: 13 float4 per lane; joint state; counters), so a step
+// reads nothing from memory (except bank rows on a reset) and only writes what a step must
+// publish: obs, zone_obs, reward, done, goal_met.  The two waves of a tile hand over through
+// monotonic LDS counters instead of barriers --
+//     pose(t)       physics -> zone   the pre-physics pose set_mocaps() needs at step t
+//     finalised(t)  zone -> physics   mode / step count / final zone entries of step t
+//     consumed(t)   physics -> zone   the policy has read the entries of step t
+// -- so the zone wave's tile flush of step t overlaps the physics of step t+1, tiles drift
+// out of lock-step, and there is no per-step launch ramp, state reload or end-of-kernel drain.
+// Needs a compile-time zone count (register arrays); zenv_rollout falls back to per-step
+// launches otherwise.
+__device__ __forceinline__ void lds_ctr_set(int *c, int v)
+{
+    asm volatile("" ::: "memory");
+    *reinterpret_cast<volatile int *>(c) = v;
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void lds_ctr_wait(const int *c, int v)
+{
+    // bounded: the producer always gets there; the bound turns a logic error into wrong output
+    // instead of a hung GPU
+    for (int spins = 0; spins < (1 << 24); ++spins) {
+        if (*reinterpret_cast<const volatile int *>(c) >= v) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
+template <int TASK, int ZT>
+__global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
+{
+    static_assert(ZT > 0, "the persistent kernel keeps the zone arrays in registers");
+    extern __shared__ __align__(16) float4 lds4[];
+    constexpr int F = TaskTraits<TASK>::F;
+    constexpr int G = TaskTraits<TASK>::G;
+    constexpr int RPC = TaskTraits<TASK>::RPC;
+    constexpr int Z = ZT;
+    constexpr int ZH = (ZT + 1) / 2;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
+    const int env0 = blockIdx.x * kWave;
+    const int env = env0 + lane;
+    const int N = p.N;
+    const bool valid = env < N;
+    float4 *ents = lds4;                                         // [64][Z] compact entries
+    float4 *stage = lds4 + kWave * Z;                            // [64*G]  flush staging slab
+    double2 *xpose = reinterpret_cast<double2 *>(stage + kWave * G);     // [64] physics -> zone
+    double2 *xframe = xpose + kWave;                             // [64][2] zone -> physics on reset
+    float2 *xact = reinterpret_cast<float2 *>(xframe + 2 * kWave);       // [64] next action of a reset env
+    int *xmode = reinterpret_cast<int *>(xact + kWave);          // [64] zone -> physics
+    int *xstep = xmode + kWave;
+    int *xaux = xstep + kWave;                                   // [64] scratch of the cooperative reset
+    int *ctr = xaux + kWave;                                     // [0] finalised, [1] consumed, [2] pose
+    float4 *my_ents = ents + lane * Z;
+    const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
+    const int n_blk = min(kWave, N - env0);
+    const int n_rows = n_blk * Z, n_chunks = n_rows / RPC;
+    float *tile_dst = p.zone_obs + (size_t)env0 * Z * F;
+
+    if (role == 0) {
+        // =================================================================== zone wave
+        EnvRegs e;
+        uint8_t was_done = 0;
+        double ep_ret = 0.0;
+        int epi_idx = 0, slot_first = 0;
+        float4 zp[ZH];
+        int auxr[ZT];
+        e.steps = 0; e.vis = 0u; e.colpack = 0ull; e.goal_dist = 0;
+        if (valid) {
+            was_done = p.done_state[env];
+            e.steps = p.steps[env];
+            if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                e.colpack = p.colpack[env];
+                e.goal_dist = p.goal_dist[env];
+            } else {
+                e.vis = p.vis[env];
+            }
+            ep_ret = p.ep_return[env];
+            epi_idx = p.episode_idx[env];
+            slot_first = p.slot_first[env];
+#pragma unroll
+            for (int h = 0; h < ZH; ++h) zp[h] = p.zpf[(size_t)h * N + env];
+#pragma unroll
+            for (int z = 0; z < ZT; ++z) {
+                const size_t zi = (size_t)z * N + env;
+                auxr[z] = 0;
+                if (TASK == ZENV_TASK_TIMED_TSP) auxr[z] = p.tmax[zi];
+                if (TASK == ZENV_TASK_COLOUR_MATCH) auxr[z] = p.cooldown[zi];
+            }
+        }
+        if (lane < 4) ctr[lane] = 0;
+        __syncthreads();   // the only barrier: publishes the cleared counters
+
+        for (int t = 0; t < n_steps; ++t) {
+            StepPolicy polt = pol;
+            polt.step_index = pol.step_index + (uint32_t)t;
+            lds_ctr_wait(ctr + 2, t + 1);                 // pre-physics pose of step t
+            const double2 pose = xpose[lane];
+            if (t > 0) lds_ctr_wait(ctr + 1, t);          // entries of step t-1 fully read by the policy
+
+            float rew_out = 0.f;
+            uint8_t done_out = 1, goal_out = 0;
+            int mode = 1;
+            bool need_reset = false, ends_soon = false;
+            int first = -1;
+            const int k = e.steps + 1;
+            float o[8];
+            if (valid && was_done) {
+                // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
+                for (int z = 0; z < Z; ++z) my_ents[z] = make_float4(0.f, 0.f, -1.f, 0.f);
+                for (int i = 0; i < 8; ++i) o[i] = 0.f;
+                store_obs8(p, env, o);
+            } else if (valid) {
+                const double rx = pose.x, ry = pose.y;
+                const float rxf = (float)rx, ryf = (float)ry;
+                uint32_t in_mask = 0u, amb_mask = 0u, elig_mask = 0u, expired = 0u, expiring = 0u;
+#pragma unroll
+                for (int z = 0; z < ZT; ++z) {
+                    const float4 pr = zp[z >> 1];
+                    const float x3 = (z & 1) ? pr.z : pr.x, y3 = (z & 1) ? pr.w : pr.y;
+                    const float dxf = __builtin_fmaf(3.f, x3, -rxf), dyf = __builtin_fmaf(3.f, y3, -ryf);
+                    const float d2f = __builtin_fmaf(dxf, dxf, dyf * dyf);
+                    const bool in_sure = d2f < p.d2_lo, out_sure = d2f > p.d2_hi;
+                    in_mask |= (in_sure ? 1u : 0u) << z;
+                    amb_mask |= ((in_sure || out_sure) ? 0u : 1u) << z;
+                    float4 en = make_float4(x3, y3, 0.f, 0.f);
+                    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                        int cd = auxr[z];
+                        if (cd > 0) cd -= 1;                        // colour_match_env.py:98-100
+                        auxr[z] = cd;
+                        elig_mask |= (cd == 0 ? 1u : 0u) << z;
+                        en.z = (float)(int)((e.colpack >> (2 * z)) & 3ull);
+                        en.w = (float)div_const((double)(float)cd, p.d_maxcd, p.inv_maxcd);
+                    } else {
+                        const bool vis = (e.vis >> z) & 1u;
+                        en.z = vis ? 1.f : 0.f;
+                        if (TASK == ZENV_TASK_TIMED_TSP) {
+                            const int aux = auxr[z];
+                            expired |= ((aux - k) <= 0 ? 1u : 0u) << z;     // TTSP_env.py:67
+                            expiring |= ((aux - k) <= 1 ? 1u : 0u) << z;
+                            en.w = vis ? 1.f : (float)div_const((double)(aux - k), p.d_steps, p.inv_steps);
+                        }
+                    }
+                    my_ents[z] = en;
+                }
+                while (amb_mask & full) {
+                    // the rim: exact float64 test on the float64 zone centres (rare, divergent)
+                    const int z = __ffs((int)(amb_mask & full)) - 1;
+                    amb_mask &= ~(1u << z);
+                    const double2 zz = p.zxy[(size_t)z * N + env];
+                    const double dx = zz.x - rx, dy = zz.y - ry;
+                    if (dx * dx + dy * dy <= p.hit_d2) in_mask |= 1u << z;
+                }
+                if (TASK != ZENV_TASK_COLOUR_MATCH) elig_mask = ~e.vis;
+                const uint32_t hits = in_mask & elig_mask & full;
+                first = hits ? __ffs((int)hits) - 1 : -1;                // lowest index wins, one per step
+                if (first >= 0) {
+                    float *slot = reinterpret_cast<float *>(my_ents + first);
+                    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                        int col = (int)((e.colpack >> (2 * first)) & 3ull);
+                        col = (col == 2) ? 0 : col + 1;                  // Blue->Green->Red->Blue
+                        e.colpack = (e.colpack & ~(3ull << (2 * first))) | ((uint64_t)col << (2 * first));
+#pragma unroll
+                        for (int z = 0; z < ZT; ++z)
+                            if (z == first) auxr[z] = p.max_cd;
+                        slot[2] = (float)col;
+                        slot[3] = (float)div_const((double)(float)p.max_cd, p.d_maxcd, p.inv_maxcd);
+                    } else {
+                        e.vis |= 1u << first;
+                        slot[2] = 1.f;
+                        if (TASK == ZENV_TASK_TIMED_TSP) slot[3] = 1.f;
+                    }
+                }
+                bool timed_out = false;
+                if (TASK == ZENV_TASK_TIMED_TSP) {
+                    timed_out = (expired & ~e.vis & full) != 0u;
+                    ends_soon = (expiring & ~e.vis & full) != 0u;
+                }
+                // ---- reward / goal / termination (Engine.step order)
+                double r = 0.0;
+                bool goal;
+                if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                    if (first >= 0) {
+                        const int nd = hamming_to_goal(e.colpack, Z);
+                        r = (double)(e.goal_dist - nd);
+                        e.goal_dist = nd;
+                    }
+                    goal = e.goal_dist == 0;
+                } else {
+                    r = first >= 0 ? 1.0 : 0.0;
+                    goal = (e.vis & full) == full;
+                }
+                bool done = false;
+                if (goal) {
+                    r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
+                    done = true;
+                    goal_out = 1;
+                }
+                e.steps = k;
+                if (k >= p.num_steps) done = true;
+                if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
+                ep_ret = ep_ret + r;
+                rew_out = (float)r;
+                done_out = done ? 1 : 0;
+                p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
+                mode = 0;
+                if (done) {
+                    p.last_return[env] = ep_ret;
+                    p.last_len[env] = k;
+                    p.episodes[env] += 1;
+                    if (auto_reset) {
+                        need_reset = true;
+                    } else {
+                        p.done_state[env] = 1;
+                        was_done = 1;
+                        mode = 3;     // observable, and the env is frozen from the next step on
+                    }
+                }
+                const int open_zones = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : Z - (int)__popc(e.vis);
+                ends_soon = !done && (ends_soon || k + 1 >= p.num_steps ||
+                                      open_zones <= (TASK == ZENV_TASK_COLOUR_MATCH ? 2 : 1));
+            }
+
+            // ---- reset prefetch, one step ahead (see k_step_lane)
+            int pf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            if (ends_soon && auto_reset && p.sched_mode == SCHED_SEQUENTIAL) {
+                const long long sl = ((long long)slot_first + (long long)epi_idx * (long long)p.sched_stride) %
+                                     (long long)p.bank_size;
+                const int *bz = reinterpret_cast<const int *>(p.bank_zone + 2 * (size_t)sl * Z);
+                pf[0] = bz[0];
+                if (4 * Z > 32) pf[1] = bz[32];
+                if (4 * Z > 64) pf[2] = bz[64];
+                if (4 * Z > 96) pf[3] = bz[96];
+                pf[4] = bz[4 * Z - 1];
+                pf[5] = reinterpret_cast<const int *>(p.bank_robot + 4 * (size_t)sl)[0];
+                if (TASK != ZENV_TASK_TSP) {
+                    const int *ba = p.bank_aux + (size_t)sl * Z;
+                    pf[6] = ba[0];
+                    pf[7] = ba[Z - 1];
+                }
+                pf[8] = (int)p.bank_seed[sl];
+            }
+
+            // ---- auto-reset (penv.py:8-11), wave-cooperative (see k_step_lane); additionally the
+            // finished lane refreshes its register copy of the zone arrays from LDS
+            unsigned long long pending = __ballot(need_reset);
+            if (pending) {
+                int my_slot = 0;
+                if (need_reset) {
+                    my_slot = next_bank_slot(p, env, epi_idx, slot_first);
+                    epi_idx += 1;
+                }
+                while (pending) {
+                    const int j = __ffsll((long long)pending) - 1;   // wave-uniform
+                    pending &= pending - 1;
+                    const int slot = __shfl(my_slot, j);
+                    const int env_j = env0 + j;
+                    const double *br = p.bank_robot + 4 * (size_t)slot;
+                    const double b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];
+                    int code = 0, aux = 0;
+                    float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (lane < Z) {
+                        const size_t bi = (size_t)slot * Z + lane;
+                        const double2 zz = reinterpret_cast<const double2 *>(p.bank_zone)[bi];
+                        const size_t zi = (size_t)lane * N + env_j;
+                        p.zxy[zi] = zz;
+                        if (TASK == ZENV_TASK_TIMED_TSP) {
+                            aux = p.bank_aux[bi];
+                            p.tmax[zi] = aux;
+                        } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                            code = p.bank_aux[bi];
+                        }
+                        en = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
+                        ents[j * Z + lane] = en;
+                        xaux[lane] = aux;
+                    }
+                    {
+                        const float nx = __shfl_down(en.x, 1), ny = __shfl_down(en.y, 1);
+                        if (lane < Z && !(lane & 1))
+                            p.zpf[(size_t)(lane >> 1) * N + env_j] =
+                                make_float4(en.x, en.y, lane + 1 < Z ? nx : 0.f, lane + 1 < Z ? ny : 0.f);
+                    }
+                    uint64_t colpack = 0ull;
+                    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                        const unsigned long long m0 = __ballot(lane < Z && (code & 1));
+                        const unsigned long long m1 = __ballot(lane < Z && (code & 2));
+                        colpack = spread_even_bits((uint32_t)m0) | (spread_even_bits((uint32_t)m1) << 1);
+                    }
+                    EnvRegs fresh;
+                    fresh.x0 = b0; fresh.y0 = b1; fresh.bq0 = b2; fresh.bq3 = b3;
+                    fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
+                    fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
+                    fresh.vis = 0u;
+                    fresh.colpack = colpack;
+                    fresh.goal_dist = (TASK == ZENV_TASK_COLOUR_MATCH) ? hamming_to_goal(colpack, Z) : 0;
+                    fresh.steps = 0;
+                    float of[8];
+                    emit_obs8(p, fresh, of);   // the first obs of the next episode
+                    float2 next_act = make_float2(0.f, 0.f);
+                    if (pol.policy == ZENV_POLICY_UNIFORM)
+                        next_act = uniform_action(polt.env_index0 + (uint64_t)env_j, polt.step_index, polt.seed);
+                    else if (pol.policy == ZENV_POLICY_GREEDY)
+                        next_act = greedy_action_coop<TASK>(lane, Z, en.x, en.y, code, en.w, of[1], of[2], of[3], of[4]);
+                    wave_lds_fence();   // lane j reads back what its neighbours wrote
+                    // lane j: registers of the new episode
+#pragma unroll
+                    for (int h = 0; h < ZH; ++h) {
+                        const float4 a = ents[j * Z + 2 * h];
+                        const float4 b = (2 * h + 1 < Z) ? ents[j * Z + 2 * h + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (lane == j) zp[h] = make_float4(a.x, a.y, b.x, b.y);
+                    }
+#pragma unroll
+                    for (int z = 0; z < ZT; ++z) {
+                        const int v = (TASK == ZENV_TASK_TIMED_TSP) ? xaux[z] : 0;
+                        if (lane == j) auxr[z] = v;
+                    }
+                    if (lane == j) {
+                        e.vis = 0u;
+                        e.colpack = colpack;
+                        e.goal_dist = fresh.goal_dist;
+                        e.steps = 0;
+                        ep_ret = 0.0;
+                        mode = 2;
+                        p.seed[env] = p.bank_seed[slot];
+                        store_frame(p, env, fresh);
+                        xframe[2 * lane] = make_double2(b0, b1);
+                        xframe[2 * lane + 1] = make_double2(b2, b3);
+                        xact[lane] = next_act;
+                        store_obs8(p, env, of);
+                    }
+                    wave_lds_fence();   // xaux is reused by the next finished env
+                }
+            }
+
+            if (valid) {
+                xmode[lane] = mode;
+                xstep[lane] = e.steps;
+            }
+            lds_ctr_set(ctr + 0, t + 1);                  // finalised(t)
+            if (valid) {
+                p.reward[env] = rew_out;
+                p.done_out[env] = done_out;
+                p.goal_met[env] = goal_out;
+            }
+            wave_lds_fence();
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 1)   // diagnostic builds only: ZENV_EXP bit 0 drops the flush
+            flush_entries<TASK>(ents, stage, tile_dst, n_rows, lane);
+#endif
+            asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]),
+                         "v"(pf[7]), "v"(pf[8]));
+        }
+
+        // ---- epilogue: the registers go back to the state arrays
+        if (valid) {
+            p.ep_return[env] = ep_ret;
+            store_counters(p, env, TASK, e);
+            if (TASK == ZENV_TASK_COLOUR_MATCH) {
+#pragma unroll
+                for (int z = 0; z < ZT; ++z) p.cooldown[(size_t)z * N + env] = (uint8_t)auxr[z];
+            }
+        }
+        (void)n_chunks;
+        return;
+    }
+
+    // ======================================================================= physics wave
+    EnvRegs e;
+    e.steps = 0;
+    float2 act = make_float2(0.f, 0.f);
+    bool frozen = false;
+    if (valid) {
+        const double2 qa = p.qa[env], qb = p.qb[env], qc = p.qc[env];
+        const double2 fa = p.fa[env], fb = p.fb[env];
+        e.q0 = qa.x; e.q1 = qa.y; e.q2 = qb.x;
+        e.v0 = qb.y; e.v1 = qc.x; e.v2 = qc.y;
+        e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
+        act = reinterpret_cast<const float2 *>(p.actions)[env];
+        frozen = p.done_state[env] != 0;
+    }
+    __syncthreads();
+    {
+        double rx = 0.0, ry = 0.0;
+        if (valid) world_pos(e, rx, ry);
+        xpose[lane] = make_double2(rx, ry);
+        lds_ctr_set(ctr + 2, 1);                          // pose(0)
+    }
+    for (int t = 0; t < n_steps; ++t) {
+        StepPolicy polt = pol;
+        polt.step_index = pol.step_index + (uint32_t)t;
+        float o[8];
+        if (valid && !frozen) {
+            // Engine.step: ctrl = clip(action, ctrlrange); frameskip x mj_step
+            const double c0 = det_clamp((double)act.x, -1.0, 1.0);
+            const double c1 = det_clamp((double)act.y, -1.0, 1.0);
+            EnvRegs w = e;
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 2)   // diagnostic: bit 1 drops the physics
+            for (int i = 0; i < p.frameskip; ++i) mj_substep(p, w, c0, c1);
+#endif
+            lds_ctr_wait(ctr + 0, t + 1);                 // finalised(t)
+            const int mode = xmode[lane];
+            if (mode == 0 || mode == 3) {
+                e = w;
+                e.steps = xstep[lane];
+                emit_obs8(p, e, o);
+                store_obs8(p, env, o);
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 4)   // diagnostic: bit 2 drops the action source
+                if (pol.policy >= 0) act = scripted_action<TASK, ZT>(polt, env, my_ents, Z, o);
+#endif
+                if (mode == 3) frozen = true;
+            } else if (mode == 2) {
+                // reset: the zone wave published the new placement, first obs and next action
+                const double2 fa = xframe[2 * lane], fb = xframe[2 * lane + 1];
+                e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
+                e.q0 = e.q1 = e.q2 = 0.0;
+                e.v0 = e.v1 = e.v2 = 0.0;
+                act = xact[lane];
+            }
+        } else {
+            lds_ctr_wait(ctr + 0, t + 1);
+        }
+        lds_ctr_set(ctr + 1, t + 1);                      // consumed(t)
+        double rx = 0.0, ry = 0.0;
+        if (valid) world_pos(e, rx, ry);
+        xpose[lane] = make_double2(rx, ry);
+        lds_ctr_set(ctr + 2, t + 2);                      // pose(t+1)
+    }
+    if (valid) {
+        store_dyn(p, env, e);
+        if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = act;
+    }
+}
+
 // =========================================================================== K2: reset
 template <int TASK>
 __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t *__restrict__ mask)
@@ -1165,6 +1602,46 @@ hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset,
     case ZENV_TASK_TSP: launch_step_task<ZENV_TASK_TSP>(p, actions, auto_reset, pol, s, ev_start, ev_stop); break;
     case ZENV_TASK_TIMED_TSP: launch_step_task<ZENV_TASK_TIMED_TSP>(p, actions, auto_reset, pol, s, ev_start, ev_stop); break;
     default: launch_step_task<ZENV_TASK_COLOUR_MATCH>(p, actions, auto_reset, pol, s, ev_start, ev_stop); break;
+    }
+    return hipGetLastError();
+}
+
+static inline size_t rollout_lds_bytes(const DevParams &p)
+{
+    const int G = p.F == 6 ? 3 : 7;
+    return (size_t)kWave * p.Z * sizeof(float4) + (size_t)kWave * G * sizeof(float4)   // entries, flush slab
+           + kWave * sizeof(double2) + 2 * kWave * sizeof(double2) + kWave * sizeof(float2)   // pose, frame, action
+           + 3 * kWave * sizeof(int) + 4 * sizeof(int);                                  // mode, step, aux; counters
+}
+
+bool rollout_kernel_available(const DevParams &p) { return p.Z == 5 || p.Z == 6 || p.Z == 15 || p.Z == 25; }
+
+template <int TASK>
+static void launch_rollout_task(const DevParams &p, int n_steps, int auto_reset, const StepPolicy &pol, hipStream_t s,
+                                hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    const dim3 grid(n_blocks(p.N)), block(2 * kWave);
+    const size_t lds = rollout_lds_bytes(p);
+#define ZENV_LAUNCH(ZT)                                                                                       \
+    hipExtLaunchKernelGGL((k_rollout_lane<TASK, ZT>), grid, block, lds, s, ev_start, ev_stop, 0, p, n_steps, \
+                          auto_reset, pol)
+    switch (p.Z) {
+    case 5: ZENV_LAUNCH(5); break;
+    case 6: ZENV_LAUNCH(6); break;
+    case 15: ZENV_LAUNCH(15); break;
+    default: ZENV_LAUNCH(25); break;
+    }
+#undef ZENV_LAUNCH
+}
+
+hipError_t launch_rollout(const DevParams &p, int n_steps, int auto_reset, const StepPolicy &pol, hipStream_t s,
+                          hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    if (!rollout_kernel_available(p)) return hipErrorInvalidValue;
+    switch (p.task) {
+    case ZENV_TASK_TSP: launch_rollout_task<ZENV_TASK_TSP>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop); break;
+    case ZENV_TASK_TIMED_TSP: launch_rollout_task<ZENV_TASK_TIMED_TSP>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop); break;
+    default: launch_rollout_task<ZENV_TASK_COLOUR_MATCH>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop); break;
     }
     return hipGetLastError();
 }

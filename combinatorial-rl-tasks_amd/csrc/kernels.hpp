@@ -23,6 +23,11 @@ inline StepPolicy no_policy() { return StepPolicy{ -1, 0u, 0ull, 0ull, nullptr }
 // ev_start/ev_stop (may be null) receive the step dispatch's own begin/end timestamps
 hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset, const StepPolicy &pol,
                        hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// K closed-loop steps in one launch (persistent kernel); a_0 must be in p.actions, a_K is left there.
+// pol.step_index = index of the FIRST action the launch computes (= step count before + 1).
+bool rollout_kernel_available(const DevParams &p);
+hipError_t launch_rollout(const DevParams &p, int n_steps, int auto_reset, const StepPolicy &pol, hipStream_t s,
+                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t launch_reset(const DevParams &p, const uint8_t *mask, hipStream_t s);
 hipError_t launch_policy(const DevParams &p, const StepPolicy &pol, hipStream_t s);
 

@@ -588,6 +588,8 @@ extern "C" int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t
     return ZENV_OK;
 }
 
+static constexpr int kRolloutChunk = 64;   // steps per launch of the persistent kernel
+
 extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
                             int auto_reset, int flags, int event_stride, float *ms_total, float *ms_step_kernel_avg)
 {
@@ -598,9 +600,13 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     int rc = use_device(h);
     if (rc) return rc;
     const bool fused = (flags & ZENV_ROLLOUT_UNFUSED) == 0;
+    const bool persistent = fused && (flags & ZENV_ROLLOUT_PER_STEP) == 0 && rollout_kernel_available(h->p);
     const bool per_kernel = ms_step_kernel_avg != nullptr && steps > 0;
     if (event_stride < 1) event_stride = 1;
-    const int n_sampled = per_kernel ? (steps + event_stride - 1) / event_stride : 0;
+    // persistent: one launch covers up to kRolloutChunk steps and every launch is timed
+    const int n_sampled = !per_kernel ? 0
+                          : persistent ? (steps + kRolloutChunk - 1) / kRolloutChunk
+                                       : (steps + event_stride - 1) / event_stride;
     const size_t need = 2 + 2 * (size_t)n_sampled;
     while (h->events.size() < need) {
         hipEvent_t ev;
@@ -608,7 +614,19 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
         h->events.push_back(ev);
     }
     HIP_TRY(hipEventRecord(h->events[0], h->stream));
-    for (int t = 0; t < steps; ++t) {
+    if (persistent && steps > 0) {
+        StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };
+        HIP_TRY(launch_policy(h->p, pol, h->stream));   // a_0; every launch leaves the next action behind
+        for (int t = 0, c = 0; t < steps; t += kRolloutChunk, ++c) {
+            const int k = std::min(kRolloutChunk, steps - t);
+            pol.step_index = (uint32_t)(h->step_count + 1);
+            hipEvent_t e0 = per_kernel ? h->events[2 + 2 * c] : nullptr;
+            hipEvent_t e1 = per_kernel ? h->events[3 + 2 * c] : nullptr;
+            HIP_TRY(launch_rollout(h->p, k, auto_reset, pol, h->stream, e0, e1));
+            h->step_count += k;
+        }
+    }
+    for (int t = 0; t < steps && !persistent; ++t) {
         StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };
         // a_t = pi(obs_t, t): one stand-alone policy launch per step (unfused) or only before
         // the first step (fused: every step kernel then leaves a_{t+1} in the action buffer)
@@ -634,7 +652,8 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
             HIP_TRY(hipEventElapsedTime(&ms, h->events[2 + 2 * i], h->events[3 + 2 * i]));
             sum += ms;
         }
-        *ms_step_kernel_avg = (float)(sum / n_sampled);
+        // persistent: the launches cover all steps, so this is the per-step share of kernel time
+        *ms_step_kernel_avg = (float)(persistent ? sum / steps : sum / n_sampled);
     } else if (ms_step_kernel_avg) {
         *ms_step_kernel_avg = 0.f;
     }

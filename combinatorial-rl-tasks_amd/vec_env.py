@@ -173,19 +173,24 @@ class ZoneVecEnv:
                                 None if dst_ptr is None else C.c_void_p(int(dst_ptr))))
 
     def rollout(self, steps, policy, policy_seed=0x5EED, env_index0=0, auto_reset=True,
-                time_step_kernel=False, fused=True, event_stride=1):
+                time_step_kernel=False, fused=True, event_stride=1, mode=None):
         """K closed-loop steps a_t = policy(obs_t, t); step(a_t) on the handle's stream.
 
-        fused=True: the step kernel also emits the next action (one launch per step);
-        fused=False: a stand-alone policy kernel runs before every step.  Same results.
+        mode "persistent" (default): one launch advances every env by up to 64 steps, state in
+        registers, all per-step outputs still written on every step; "per_step": one step-kernel
+        launch per step which also emits the next action; "unfused" (or fused=False): per-step
+        launches with a stand-alone policy kernel before each.  Same results in all three.
 
         Returns (ms_total, ms_step_kernel_avg or None), both from HIP events on that stream;
-        the kernel figure is the mean dispatch duration over every event_stride-th launch."""
+        the kernel figure is kernel time per step (see include/zenv.h)."""
+        if mode is None:
+            mode = "persistent" if fused else "unfused"
+        flags = {"persistent": 0, "per_step": nat.ROLLOUT_PER_STEP, "unfused": nat.ROLLOUT_UNFUSED}[mode]
         total = C.c_float(0)
         kern = C.c_float(0)
         check(lib().zenv_rollout(self._h, int(steps), int(policy), int(policy_seed),
                                  int(env_index0), int(bool(auto_reset)),
-                                 0 if fused else nat.ROLLOUT_UNFUSED, int(event_stride), C.byref(total),
+                                 flags, int(event_stride), C.byref(total),
                                  C.byref(kern) if time_step_kernel else None))
         return total.value, (kern.value if time_step_kernel else None)
 

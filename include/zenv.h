@@ -154,12 +154,17 @@ int zenv_step(zenv_t *h, const float *actions, int actions_on_device, int auto_r
 int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0,
                 float *dst_device);
 /* K closed-loop steps a_t = policy(obs_t, t); step(a_t) on the handle's stream, HIP-event
- * timed.  Default: the step kernel of step t also emits a_{t+1} (fused action source, one
- * launch per step); ZENV_ROLLOUT_UNFUSED runs the stand-alone policy kernel before every
- * step instead.  Results are identical.  ms_total: whole loop (events on the stream);
- * ms_step_kernel_avg (may be NULL): mean duration of the step-kernel dispatch, from the
- * begin/end events of every event_stride-th launch of the loop. */
+ * timed.  Default (flags 0): the persistent rollout kernel -- one launch advances every env by
+ * up to 64 steps with the env state in registers, publishing obs / zone_obs / reward / done /
+ * goal_met to memory on every step (zone counts 5, 6, 15, 25; other counts use the next mode).
+ * ZENV_ROLLOUT_PER_STEP: one step-kernel launch per step, the kernel of step t also emitting
+ * a_{t+1} (fused action source).  ZENV_ROLLOUT_UNFUSED: per-step launches with the stand-alone
+ * policy kernel before each.  Results are identical in all three.  ms_total: whole loop (events
+ * on the stream); ms_step_kernel_avg (may be NULL): kernel time per step -- persistent: begin/end
+ * events of every launch, summed, / steps; otherwise the mean over every event_stride-th
+ * step-kernel dispatch. */
 #define ZENV_ROLLOUT_UNFUSED 1
+#define ZENV_ROLLOUT_PER_STEP 2
 int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
                  int auto_reset, int flags, int event_stride, float *ms_total,
                  float *ms_step_kernel_avg);

@@ -81,22 +81,23 @@ def test_policy_kernels_match_oracle(zenv_mod, oracle_mod, task):
     env.close()
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("mode", ["persistent", "per_step", "unfused"])
 @pytest.mark.parametrize("task,zones,keepout", [(0, 25, 0.40), (1, 25, 0.40), (2, 6, 0.55), (0, 5, 0.55),
-                                                (1, 7, 0.55)])
-def test_closed_loop_rollout_matches_oracle(zenv_mod, oracle_mod, task, zones, keepout, fused):
-    """Device-resident closed loop (policy kernel + step kernel, auto-reset onto fresh seeds)
-    against the oracle's batch driver: BASELINE.json configs 1-3 at reduced N."""
+                                                (1, 7, 0.55), (0, 15, 0.55), (2, 25, 0.40), (1, 6, 0.55)])
+def test_closed_loop_rollout_matches_oracle(zenv_mod, oracle_mod, task, zones, keepout, mode):
+    """Device-resident closed loop (persistent rollout kernel / step kernel with fused action
+    source / policy kernel + step kernel; auto-reset onto fresh seeds) against the oracle's
+    batch driver: BASELINE.json configs 1-3 at reduced N.  (Z = 7 has no persistent kernel.)"""
     Z, O = zenv_mod, oracle_mod
     n, T, stride = 1000, 400, 1000
     cfg = Z.default_config(task, zones, zones_keepout=keepout)
-    if task != 2:
-        cfg.num_steps = 400           # force time-limit resets inside the window
+    if (task, zones) != (2, 6):
+        cfg.num_steps = 400 if task != 2 else 150      # force time-limit resets inside the window
     env = Z.ZoneVecEnv(cfg, n)
     env.build_bank(1, 16 * stride)
     env.schedule_sequential(stride=stride)
     env.reset()
-    env.rollout(T, Z.POLICY_GREEDY, policy_seed=11, env_index0=0, auto_reset=True, fused=fused)
+    env.rollout(T, Z.POLICY_GREEDY, policy_seed=11, env_index0=0, auto_reset=True, mode=mode)
     ocfg = oracle_config_from(O, cfg)
     ref = O.rollout(ocfg, np.arange(1, 1 + n), T, O.POLICY_GREEDY, seed_stride=stride,
                     policy_seed=11, n_threads=8)
@@ -106,7 +107,107 @@ def test_closed_loop_rollout_matches_oracle(zenv_mod, oracle_mod, task, zones, k
     assert np.array_equal(env.get(Z.F_OBS), ref["obs"])
     assert np.array_equal(env.get(Z.F_ZONE_OBS), ref["zone_obs"])
     assert ref["episodes"].max() < 16 and ref["episodes"].sum() > 0
+    assert env.step_count == T
     env.close()
+
+
+@pytest.mark.parametrize("task,zones", [(0, 15), (1, 25), (2, 6)])
+def test_persistent_rollout_interleaves_with_steps(zenv_mod, oracle_mod, task, zones):
+    """A persistent launch starts from and leaves behind exactly the state the step API sees:
+    rollout(70) ; step(a) x 5 ; rollout(3) ; snapshot ; rollout(130) == restore ; per-step x 130,
+    all in lock-step with the oracle."""
+    Z, O = zenv_mod, oracle_mod
+    n = 193                                            # ragged last tile
+    cfg = Z.default_config(task, zones, zones_keepout=0.45, num_steps=60)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(9, n)
+    env.schedule_sequential()                          # every reset replays the env's own map
+    env.reset()
+    ob = OracleBatch(O, oracle_config_from(O, cfg), range(9, 9 + n))
+    o_ref, zo_ref = ob.reset()
+    t = 0
+
+    def oracle_greedy(k):
+        nonlocal o_ref, zo_ref, t
+        for _ in range(k):
+            ob.step(ob.policy(O.POLICY_GREEDY, o_ref, zo_ref, t))
+            o_ref, zo_ref = ob.obs()
+            t += 1
+
+    env.rollout(70, Z.POLICY_GREEDY)
+    oracle_greedy(70)
+    o, zo = env.observations()
+    assert np.array_equal(o, o_ref) and np.array_equal(zo, zo_ref)
+    rs = np.random.RandomState(4)
+    for _ in range(5):
+        a = rs.uniform(-1, 1, (n, 2)).astype(np.float32)
+        env.step(a, auto_reset=True)
+        r_ref, d_ref, g_ref = ob.step(a)
+        o_ref, zo_ref = ob.obs()
+        t += 1
+        o, zo, r, d, g = env.results()
+        assert np.array_equal(o, o_ref) and np.array_equal(zo, zo_ref)
+        assert np.array_equal(r, r_ref.astype(np.float32)) and np.array_equal(d, d_ref)
+    env.rollout(3, Z.POLICY_GREEDY)
+    oracle_greedy(3)
+    blob = env.get_state()
+    env.rollout(130, Z.POLICY_GREEDY)
+    oracle_greedy(130)
+    res_a = env.results()
+    assert np.array_equal(res_a[0], o_ref) and np.array_equal(res_a[1], zo_ref)
+    epi_a = env.get(Z.F_EPISODES)
+    env.set_state(blob)
+    env.rollout(130, Z.POLICY_GREEDY, mode="per_step")
+    for x, y in zip(res_a, env.results()):
+        assert np.array_equal(x, y)
+    assert np.array_equal(epi_a, env.get(Z.F_EPISODES)) and epi_a.sum() > 0
+    env.close()
+
+
+def test_persistent_rollout_without_auto_reset(zenv_mod):
+    """auto_reset = 0 inside a persistent launch: a finished env freezes (WaitWrapper masking),
+    its joint state stays where the episode ended -- same as per-step launches."""
+    Z = zenv_mod
+    n = 130
+    cfg = Z.default_config(1, 25, zones_keepout=0.40, num_steps=90)
+    outs = []
+    for mode in ("persistent", "per_step"):
+        env = Z.ZoneVecEnv(cfg, n)
+        env.build_bank(3, n)
+        env.reset()
+        env.rollout(20, Z.POLICY_GREEDY, auto_reset=False, mode=mode)
+        mid = env.get(Z.F_DONE).copy()
+        env.rollout(130, Z.POLICY_GREEDY, auto_reset=False, mode=mode)
+        outs.append((mid, env.results(), env.get(Z.F_LAST_LEN), env.get(Z.F_LAST_RETURN), env.get_state()))
+        env.close()
+    a, b = outs
+    assert 0 < a[0].sum() < n                      # some envs timed out early (TTSP_env.py:67), not all
+    assert a[1][3].all() and not a[1][0].any()     # everyone is done after 150 >= num_steps; zero obs
+    assert np.array_equal(a[0], b[0])
+    for x, y in zip(a[1], b[1]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert np.array_equal(a[4], b[4])              # the whole state blob, joint state included
+
+
+def test_persistent_rollout_fixed_seed_schedule(zenv_mod):
+    """FixedSeedsWrapper draws (device PCG64) made from inside the persistent kernel."""
+    Z = zenv_mod
+    n, lo, hi = 100, 1, 100
+    cfg = Z.config_for_id("PointTSP-v1", num_steps=17)
+    outs = []
+    for mode in ("persistent", "unfused"):
+        env = Z.ZoneVecEnv(cfg, n)
+        env.build_bank(lo, hi - lo + 1)
+        env.schedule_fixed_seeds(np.arange(n, dtype=np.uint64) * 10000, lo, hi)
+        env.reset()
+        env.rollout(200, Z.POLICY_UNIFORM, policy_seed=5, mode=mode)
+        outs.append((env.get(Z.F_SEED), env.get(Z.F_EPISODES), env.results()))
+        env.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1].min() == 11
+    assert len(np.unique(outs[0][0])) > 30
+    for x, y in zip(outs[0][2], outs[1][2]):
+        assert np.array_equal(x, y)
 
 
 def test_uniform_policy_rollout(zenv_mod, oracle_mod):
@@ -117,7 +218,7 @@ def test_uniform_policy_rollout(zenv_mod, oracle_mod):
     env.build_bank(EVAL_SEED0, n)
     env.schedule_sequential()
     env.reset()
-    env.rollout(T // 2, Z.POLICY_UNIFORM, policy_seed=0x5EED, env_index0=123, auto_reset=True, fused=True)
+    env.rollout(T // 2, Z.POLICY_UNIFORM, policy_seed=0x5EED, env_index0=123, auto_reset=True, mode="persistent")
     env.rollout(T - T // 2, Z.POLICY_UNIFORM, policy_seed=0x5EED, env_index0=123, auto_reset=True, fused=False)
     ref = O.rollout(oracle_config_from(O, cfg), np.arange(EVAL_SEED0, EVAL_SEED0 + n), T,
                     O.POLICY_UNIFORM, policy_seed=0x5EED, env_index0=123, n_threads=8)
