@@ -19,6 +19,7 @@ POLICY_UNIFORM, POLICY_GREEDY = 0, 1
 KERNEL_LANE_PER_ENV, KERNEL_WAVE_PER_ENV = 0, 1
 ROLLOUT_UNFUSED = 1
 ROLLOUT_PER_STEP = 2
+ROLLOUT_CHUNK = 256
 
 E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE = -1, -2, -3, -4, -5
 

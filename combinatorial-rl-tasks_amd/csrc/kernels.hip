@@ -393,6 +393,9 @@ __device__ __forceinline__ void wave_lds_fence()
 #ifndef ZENV_STORE_AUX
 #define ZENV_STORE_AUX 2
 #endif
+#ifndef ZENV_EPRIO
+#define ZENV_EPRIO 3   // wave priority of the persistent kernel's env wave (diagnostic builds vary it)
+#endif
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
 template <int TASK>
@@ -1104,379 +1107,324 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
 
 // =========================================================================== K1p: persistent rollout
 // K closed-loop steps a_t = pi(obs_t, t); step(a_t) in ONE launch, for the case the rollout API
-// exists for: the action source is on the device (zenv_rollout, fused policy).  Same tile / wave
-// roles and the same per-step arithmetic as k_step_lane, but the env state lives in registers
-// for the whole launch (zone positions: 13 float4 per lane; joint state; counters), so a step
-// reads nothing from memory (except bank rows on a reset) and only writes what a step must
-// publish: obs, zone_obs, reward, done, goal_met.  The two waves of a tile hand over through
-// monotonic LDS counters instead of barriers --
-//     pose(t)       physics -> zone   the pre-physics pose set_mocaps() needs at step t
-//     finalised(t)  zone -> physics   mode / step count / final zone entries of step t
-//     consumed(t)   physics -> zone   the policy has read the entries of step t
-// -- so the zone wave's tile flush of step t overlaps the physics of step t+1, tiles drift
-// out of lock-step, and there is no per-step launch ramp, state reload or end-of-kernel drain.
+// exists for: the action source is on the device (zenv_rollout).  Same arithmetic per step as
+// k_step_lane, different split of the tile's two waves:
+//   wave 0, "env wave":     lane i owns env i with ALL of its state in registers for the whole
+//       launch -- zone positions (ZT/2 float4), deadlines / cooldowns, joint state, counters,
+//       the pending action.  Per step: set_mocaps() zone pass on the pre-physics pose,
+//       reward / goal / termination, 10 physics substeps, obs, next action -- no LDS or global
+//       reads at all (bank rows on a reset, zone centres on a rim hit).  It publishes per env
+//       one 8-byte word of per-step zone state (visited mask [+ step count] / packed colours,
+//       + cooldown bytes for ColourMatch) into a double-buffered LDS slot.
+//   wave 1, "stream wave":  expands the tile's 64 x Z rows from the static LDS entries
+//       (x/3, y/3 [, deadline]; rewritten only on a reset) and that per-step word, and streams
+//       them to zone_obs as 1 KiB non-temporal bursts.  It runs up to two steps behind the env
+//       wave, so the env wave never waits for the store path unless that is the bottleneck.
+// Hand-over through two monotonic LDS counters (published(t): env -> stream; flushed(t):
+// stream -> env).  Per step the kernel reads nothing and writes what a step must publish: obs,
+// zone_obs, reward, done, goal_met (+ visit_count); state goes back to memory when it ends.
 // Needs a compile-time zone count (register arrays); zenv_rollout falls back to per-step
 // launches otherwise.
+// The counters are touched through explicit LDS (address space 3) pointers: through a generic
+// pointer the compiler emits FLAT loads, and a FLAT load's s_waitcnt also drains the wave's
+// outstanding global stores -- once per spin.
+typedef __attribute__((address_space(3))) volatile int lds_vint;
 __device__ __forceinline__ void lds_ctr_set(int *c, int v)
 {
     asm volatile("" ::: "memory");
-    *reinterpret_cast<volatile int *>(c) = v;
+    *(lds_vint *)c = v;
     asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void lds_ctr_wait(const int *c, int v)
 {
     // bounded: the producer always gets there; the bound turns a logic error into wrong output
     // instead of a hung GPU
+#pragma unroll 1
     for (int spins = 0; spins < (1 << 24); ++spins) {
-        if (*reinterpret_cast<const volatile int *>(c) >= v) break;
+        if (*(lds_vint *)c >= v) break;
         __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
+}
+
+// static part of a zone row in LDS: (x/3, y/3) and, for TimedTSP, the deadline (int bits)
+template <int TASK> struct StaticEnt { using type = float2; };
+template <> struct StaticEnt<ZENV_TASK_TIMED_TSP> { using type = float4; };
+template <int TASK>
+__device__ __forceinline__ typename StaticEnt<TASK>::type make_static(float x3, float y3, int aux)
+{
+    if constexpr (TASK == ZENV_TASK_TIMED_TSP) return make_float4(x3, y3, __int_as_float(aux), 0.f);
+    else return make_float2(x3, y3);
+}
+constexpr uint64_t kDynZero = 1ull << 63;   // the env's rows are all zero (finished, no auto-reset)
+
+// r / ZT for r < 64 * ZT without an integer division (checked exhaustively at compile time)
+template <int ZT> struct RowDiv {
+    static constexpr uint32_t M = (65536u + ZT - 1) / ZT;
+    static constexpr bool ok()
+    {
+        for (uint32_t r = 0; r < 64u * ZT; ++r)
+            if (((r * M) >> 16) != r / ZT) return false;
+        return true;
+    }
+    static_assert(ok(), "multiplier does not reproduce r / ZT");
+    static __device__ __forceinline__ int div(int r) { return (int)(__umul24((uint32_t)r, M) >> 16); }
+};
+
+// One reference row (TSP_env.py:31-35, TTSP_env.py:86-92, colour_match_env.py:75-80) from
+// its static entry + the env's per-step word; same values as make_entry() + expand_entry().
+template <int TASK, int ZT>
+__device__ __forceinline__ void expand_row(const DevParams &p, const typename StaticEnt<TASK>::type s, uint64_t d,
+                                           const uint8_t *cd_env, int z, float *row)
+{
+    const bool zero = (d & kDynZero) != 0ull;
+    row[0] = zero ? 0.f : s.x;
+    row[1] = zero ? 0.f : s.y;
+    row[5] = zero ? 0.f : 0.25f;
+    if constexpr (TASK == ZENV_TASK_COLOUR_MATCH) {
+        const int col = zero ? 3 : (int)((d >> (2 * z)) & 3ull);
+        row[2] = col == 2 ? 1.f : 0.f;
+        row[3] = col == 1 ? 1.f : 0.f;
+        row[4] = col == 0 ? 1.f : 0.f;
+        const int cd = zero ? 0 : (int)cd_env[z];
+        row[6] = (float)div_const((double)(float)cd, p.d_maxcd, p.inv_maxcd);
+    } else {
+        const bool vis = (((uint32_t)d >> z) & 1u) != 0u;
+        row[2] = vis ? 1.f : 0.f;
+        row[3] = zero ? 0.f : 1.f;
+        row[4] = (vis || zero) ? 0.f : 1.f;
+        if constexpr (TASK == ZENV_TASK_TIMED_TSP) {
+            const int k = (int)(uint32_t)(d >> 32) & 0x7FFFFFFF;
+            const int tmax = __float_as_int(s.z);
+            const float left = (float)div_const((double)(tmax - k), p.d_steps, p.inv_steps);
+            row[6] = zero ? 0.f : (vis ? 1.f : left);
+        }
+    }
+}
+
+// flush_entries() for the persistent kernel: rows come from static entries + per-env words
+template <int TASK, int ZT>
+__device__ __forceinline__ void flush_static(const DevParams &p, const typename StaticEnt<TASK>::type *sent,
+                                             const uint64_t *dynw, const uint8_t *cdb, float4 *stage, float *dst,
+                                             int n_rows, int lane)
+{
+    constexpr int F = TaskTraits<TASK>::F, RPC = TaskTraits<TASK>::RPC, G = TaskTraits<TASK>::G;
+    constexpr int ZB = (ZT + 3) & ~3;
+    const int n_chunks = n_rows / RPC;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(dst, 0, n_rows * F * (int)sizeof(float), 0x00020000);
+    auto expand_chunk = [&](int c, float *v) {
+#pragma unroll
+        for (int j = 0; j < RPC; ++j) {
+            const int r = c * RPC + j;
+            const int el = RowDiv<ZT>::div(r);
+            expand_row<TASK, ZT>(p, sent[r], dynw[el], cdb + el * ZB, r - el * ZT, v + j * F);
+        }
+    };
+    int c0 = 0;
+    for (; c0 + kWave <= n_chunks; c0 += kWave) {
+        float v[RPC * F];
+        expand_chunk(c0 + lane, v);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            stage[lane * G + g] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        wave_lds_fence();
+        float4 t[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) t[g] = stage[g * kWave + lane];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const v4f_t val = { t[g].x, t[g].y, t[g].z, t[g].w };
+            __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + g * kWave + lane) * 16, 0, ZENV_STORE_AUX);
+        }
+        wave_lds_fence();
+    }
+    if (c0 < n_chunks) {
+        const int c = c0 + lane;
+        if (c < n_chunks) {
+            float v[RPC * F];
+            expand_chunk(c, v);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                stage[lane * G + g] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        }
+        wave_lds_fence();
+        const int n4 = (n_chunks - c0) * G;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i = g * kWave + lane;
+            if (i < n4) {
+                const float4 tv = stage[i];
+                const v4f_t val = { tv.x, tv.y, tv.z, tv.w };
+                __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + i) * 16, 0, ZENV_STORE_AUX);
+            }
+        }
+        wave_lds_fence();
+    }
+    // ragged tail (n_rows not a multiple of RPC): one row per lane, scalar stores
+    const int r = n_chunks * RPC + lane;
+    if (r < n_rows) {
+        float v[F];
+        const int el = RowDiv<ZT>::div(r);
+        expand_row<TASK, ZT>(p, sent[r], dynw[el], cdb + el * ZB, r - el * ZT, v);
+        for (int f = 0; f < F; ++f) dst[(size_t)r * F + f] = v[f];
+    }
+}
+
+// greedy_action() on the env wave's registers (no memory behind it, so no dynamic zone index):
+// same distances, same winner -- the nearest eligible zone, lowest index on ties -- found as
+// "minimum value, then the lowest zone that attains it" instead of a (value, index) tournament.
+// Ineligible zones carry a finite sentinel >= 2^1023 in place of +inf (only the high word is
+// replaced); a NaN pose leaves no zone below the sentinel, like the scan it replaces.
+__device__ __forceinline__ double min_f64(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int TASK, int ZT>
+__device__ __forceinline__ float2 greedy_action_regs(const float4 *zp, const int *auxr, uint32_t vis, uint64_t colpack,
+                                                     float opx, float opy, float ohx, float ohy)
+{
+    const double px = 3.0 * (double)opx, py = 3.0 * (double)opy;
+    const double hx = (double)ohx, hy = (double)ohy;
+    int target_colour = -1;
+    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+        const uint64_t used = (1ull << (2 * ZT)) - 1ull, lo_bits = 0x5555555555555555ull;
+        const int cg = __popcll(colpack & lo_bits & used), cr = __popcll((colpack >> 1) & lo_bits & used);
+        const int cb = ZT - cg - cr;
+        target_colour = 0;
+        int best_cnt = cb;
+        if (cg > best_cnt) { target_colour = 1; best_cnt = cg; }
+        if (cr > best_cnt) { target_colour = 2; }
+    }
+    // two halves of the zone list, one after the other: halves the live distance array
+    double mbest = 0.0;
+    float bx = 0.f, by = 0.f;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        constexpr int ZA = (ZT + 1) / 2;
+        const int z0 = part == 0 ? 0 : ZA;
+        const int zn = part == 0 ? ZA : ZT - ZA;          // zones in this half (compile-time after unrolling)
+        double d2s[ZA];
+#pragma unroll
+        for (int i = 0; i < ZA; ++i) {
+            if (i >= zn) { d2s[i] = 0.0; continue; }
+            const int z = z0 + i;
+            const float4 pr = zp[z >> 1];
+            const float x3 = (z & 1) ? pr.z : pr.x, y3 = (z & 1) ? pr.w : pr.y;
+            bool eligible;
+            if (TASK == ZENV_TASK_COLOUR_MATCH)
+                eligible = auxr[z] == 0 && (int)((colpack >> (2 * z)) & 3ull) != target_colour;
+            else eligible = ((vis >> z) & 1u) == 0u;
+            const double dx = 3.0 * (double)x3 - px, dy = 3.0 * (double)y3 - py;
+            const double d2 = dx * dx + dy * dy;
+            d2s[i] = __hiloint2double(eligible ? __double2hiint(d2) : 0x7FE00000, __double2loint(d2));
+        }
+        constexpr int ZM = (ZA + 1) / 2;
+        double m[ZM];
+#pragma unroll
+        for (int h = 0; h < ZM; ++h) m[h] = (2 * h + 1 < zn) ? min_f64(d2s[2 * h], d2s[2 * h + 1]) : d2s[2 * h < zn ? 2 * h : 0];
+#pragma unroll
+        for (int stride = 1; stride < ZM; stride *= 2) {
+#pragma unroll
+            for (int h = 0; h + stride < ZM; h += 2 * stride)
+                if (2 * (h + stride) < zn) m[h] = min_f64(m[h], m[h + stride]);
+        }
+        float hx3 = 0.f, hy3 = 0.f;
+#pragma unroll
+        for (int i = ZA - 1; i >= 0; --i) {      // descending: the lowest zone at the minimum is written last
+            if (i >= zn) continue;
+            const int z = z0 + i;
+            const float4 pr = zp[z >> 1];
+            const bool hit = d2s[i] == m[0];
+            hx3 = hit ? ((z & 1) ? pr.z : pr.x) : hx3;
+            hy3 = hit ? ((z & 1) ? pr.w : pr.y) : hy3;
+        }
+        // the second half only wins with a strictly smaller distance (ties go to the lower index)
+        const bool take = part == 0 || m[0] < mbest;
+        mbest = take ? m[0] : mbest;
+        bx = take ? hx3 : bx;
+        by = take ? hy3 : by;
+    }
+    float2 a = make_float2(0.f, 0.f);
+    if (mbest < 1e300) {
+        const double bdx = 3.0 * (double)bx - px, bdy = 3.0 * (double)by - py;
+        const double bd2 = bdx * bdx + bdy * bdy;
+        if (bd2 > 1e-18) {
+            const double n = sqrt(bd2);
+            const double cs = (hx * bdx + hy * bdy) / n;
+            const double sn = (hx * bdy - hy * bdx) / n;
+            if (cs < 0.0) a.y = sn >= 0.0 ? 1.f : -1.f;
+            else a.y = (float)det_clamp(4.0 * sn, -1.0, 1.0);
+            a.x = cs > 0.8 ? 1.f : 0.f;
+        }
+    }
+    return a;
 }
 
 template <int TASK, int ZT>
 __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
 {
-    static_assert(ZT > 0, "the persistent kernel keeps the zone arrays in registers");
+    static_assert(ZT > 0 && ZT <= 30, "zone arrays live in registers; bit 31 / 63 of the step word are flags");
+    using SE = typename StaticEnt<TASK>::type;
     extern __shared__ __align__(16) float4 lds4[];
     constexpr int F = TaskTraits<TASK>::F;
     constexpr int G = TaskTraits<TASK>::G;
-    constexpr int RPC = TaskTraits<TASK>::RPC;
     constexpr int Z = ZT;
     constexpr int ZH = (ZT + 1) / 2;
+    constexpr int ZB = (ZT + 3) & ~3;                            // cooldown bytes per env, padded
+    constexpr bool kColour = TASK == ZENV_TASK_COLOUR_MATCH;
     const int lane = threadIdx.x & (kWave - 1);
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
     const int env0 = blockIdx.x * kWave;
     const int env = env0 + lane;
     const int N = p.N;
     const bool valid = env < N;
-    float4 *ents = lds4;                                         // [64][Z] compact entries
-    float4 *stage = lds4 + kWave * Z;                            // [64*G]  flush staging slab
-    double2 *xpose = reinterpret_cast<double2 *>(stage + kWave * G);     // [64] physics -> zone
-    double2 *xframe = xpose + kWave;                             // [64][2] zone -> physics on reset
-    float2 *xact = reinterpret_cast<float2 *>(xframe + 2 * kWave);       // [64] next action of a reset env
-    int *xmode = reinterpret_cast<int *>(xact + kWave);          // [64] zone -> physics
-    int *xstep = xmode + kWave;
-    int *xaux = xstep + kWave;                                   // [64] scratch of the cooperative reset
-    int *ctr = xaux + kWave;                                     // [0] finalised, [1] consumed, [2] pose
-    float4 *my_ents = ents + lane * Z;
-    const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
+    SE *sent = reinterpret_cast<SE *>(lds4);                     // [64][Z] static entries
+    float4 *stage = reinterpret_cast<float4 *>(sent + kWave * Z);        // [64*G] flush staging slab
+    uint64_t *dynw = reinterpret_cast<uint64_t *>(stage + kWave * G);    // [2][64] per-step words
+    uint32_t *cdw = reinterpret_cast<uint32_t *>(dynw + 2 * kWave);      // [2][64][ZB/4] cooldown bytes
+    int *ctr = reinterpret_cast<int *>(cdw + (kColour ? 2 * kWave * (ZB / 4) : 0));   // [0] published, [1] flushed
+    const uint32_t full = (1u << Z) - 1u;
     const int n_blk = min(kWave, N - env0);
-    const int n_rows = n_blk * Z, n_chunks = n_rows / RPC;
+    const int n_rows = n_blk * Z;
     float *tile_dst = p.zone_obs + (size_t)env0 * Z * F;
 
-    if (role == 0) {
-        // =================================================================== zone wave
-        EnvRegs e;
-        uint8_t was_done = 0;
-        double ep_ret = 0.0;
-        int epi_idx = 0, slot_first = 0;
-        float4 zp[ZH];
-        int auxr[ZT];
-        e.steps = 0; e.vis = 0u; e.colpack = 0ull; e.goal_dist = 0;
-        if (valid) {
-            was_done = p.done_state[env];
-            e.steps = p.steps[env];
-            if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                e.colpack = p.colpack[env];
-                e.goal_dist = p.goal_dist[env];
-            } else {
-                e.vis = p.vis[env];
-            }
-            ep_ret = p.ep_return[env];
-            epi_idx = p.episode_idx[env];
-            slot_first = p.slot_first[env];
-#pragma unroll
-            for (int h = 0; h < ZH; ++h) zp[h] = p.zpf[(size_t)h * N + env];
-#pragma unroll
-            for (int z = 0; z < ZT; ++z) {
-                const size_t zi = (size_t)z * N + env;
-                auxr[z] = 0;
-                if (TASK == ZENV_TASK_TIMED_TSP) auxr[z] = p.tmax[zi];
-                if (TASK == ZENV_TASK_COLOUR_MATCH) auxr[z] = p.cooldown[zi];
-            }
-        }
-        if (lane < 4) ctr[lane] = 0;
-        __syncthreads();   // the only barrier: publishes the cleared counters
-
+    if (role == 1) {
+        // =================================================================== stream wave
+        __syncthreads();   // static entries of the first step + cleared counters
         for (int t = 0; t < n_steps; ++t) {
-            StepPolicy polt = pol;
-            polt.step_index = pol.step_index + (uint32_t)t;
-            lds_ctr_wait(ctr + 2, t + 1);                 // pre-physics pose of step t
-            const double2 pose = xpose[lane];
-            if (t > 0) lds_ctr_wait(ctr + 1, t);          // entries of step t-1 fully read by the policy
-
-            float rew_out = 0.f;
-            uint8_t done_out = 1, goal_out = 0;
-            int mode = 1;
-            bool need_reset = false, ends_soon = false;
-            int first = -1;
-            const int k = e.steps + 1;
-            float o[8];
-            if (valid && was_done) {
-                // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
-                for (int z = 0; z < Z; ++z) my_ents[z] = make_float4(0.f, 0.f, -1.f, 0.f);
-                for (int i = 0; i < 8; ++i) o[i] = 0.f;
-                store_obs8(p, env, o);
-            } else if (valid) {
-                const double rx = pose.x, ry = pose.y;
-                const float rxf = (float)rx, ryf = (float)ry;
-                uint32_t in_mask = 0u, amb_mask = 0u, elig_mask = 0u, expired = 0u, expiring = 0u;
-#pragma unroll
-                for (int z = 0; z < ZT; ++z) {
-                    const float4 pr = zp[z >> 1];
-                    const float x3 = (z & 1) ? pr.z : pr.x, y3 = (z & 1) ? pr.w : pr.y;
-                    const float dxf = __builtin_fmaf(3.f, x3, -rxf), dyf = __builtin_fmaf(3.f, y3, -ryf);
-                    const float d2f = __builtin_fmaf(dxf, dxf, dyf * dyf);
-                    const bool in_sure = d2f < p.d2_lo, out_sure = d2f > p.d2_hi;
-                    in_mask |= (in_sure ? 1u : 0u) << z;
-                    amb_mask |= ((in_sure || out_sure) ? 0u : 1u) << z;
-                    float4 en = make_float4(x3, y3, 0.f, 0.f);
-                    if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                        int cd = auxr[z];
-                        if (cd > 0) cd -= 1;                        // colour_match_env.py:98-100
-                        auxr[z] = cd;
-                        elig_mask |= (cd == 0 ? 1u : 0u) << z;
-                        en.z = (float)(int)((e.colpack >> (2 * z)) & 3ull);
-                        en.w = (float)div_const((double)(float)cd, p.d_maxcd, p.inv_maxcd);
-                    } else {
-                        const bool vis = (e.vis >> z) & 1u;
-                        en.z = vis ? 1.f : 0.f;
-                        if (TASK == ZENV_TASK_TIMED_TSP) {
-                            const int aux = auxr[z];
-                            expired |= ((aux - k) <= 0 ? 1u : 0u) << z;     // TTSP_env.py:67
-                            expiring |= ((aux - k) <= 1 ? 1u : 0u) << z;
-                            en.w = vis ? 1.f : (float)div_const((double)(aux - k), p.d_steps, p.inv_steps);
-                        }
-                    }
-                    my_ents[z] = en;
-                }
-                while (amb_mask & full) {
-                    // the rim: exact float64 test on the float64 zone centres (rare, divergent)
-                    const int z = __ffs((int)(amb_mask & full)) - 1;
-                    amb_mask &= ~(1u << z);
-                    const double2 zz = p.zxy[(size_t)z * N + env];
-                    const double dx = zz.x - rx, dy = zz.y - ry;
-                    if (dx * dx + dy * dy <= p.hit_d2) in_mask |= 1u << z;
-                }
-                if (TASK != ZENV_TASK_COLOUR_MATCH) elig_mask = ~e.vis;
-                const uint32_t hits = in_mask & elig_mask & full;
-                first = hits ? __ffs((int)hits) - 1 : -1;                // lowest index wins, one per step
-                if (first >= 0) {
-                    float *slot = reinterpret_cast<float *>(my_ents + first);
-                    if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                        int col = (int)((e.colpack >> (2 * first)) & 3ull);
-                        col = (col == 2) ? 0 : col + 1;                  // Blue->Green->Red->Blue
-                        e.colpack = (e.colpack & ~(3ull << (2 * first))) | ((uint64_t)col << (2 * first));
-#pragma unroll
-                        for (int z = 0; z < ZT; ++z)
-                            if (z == first) auxr[z] = p.max_cd;
-                        slot[2] = (float)col;
-                        slot[3] = (float)div_const((double)(float)p.max_cd, p.d_maxcd, p.inv_maxcd);
-                    } else {
-                        e.vis |= 1u << first;
-                        slot[2] = 1.f;
-                        if (TASK == ZENV_TASK_TIMED_TSP) slot[3] = 1.f;
-                    }
-                }
-                bool timed_out = false;
-                if (TASK == ZENV_TASK_TIMED_TSP) {
-                    timed_out = (expired & ~e.vis & full) != 0u;
-                    ends_soon = (expiring & ~e.vis & full) != 0u;
-                }
-                // ---- reward / goal / termination (Engine.step order)
-                double r = 0.0;
-                bool goal;
-                if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                    if (first >= 0) {
-                        const int nd = hamming_to_goal(e.colpack, Z);
-                        r = (double)(e.goal_dist - nd);
-                        e.goal_dist = nd;
-                    }
-                    goal = e.goal_dist == 0;
-                } else {
-                    r = first >= 0 ? 1.0 : 0.0;
-                    goal = (e.vis & full) == full;
-                }
-                bool done = false;
-                if (goal) {
-                    r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
-                    done = true;
-                    goal_out = 1;
-                }
-                e.steps = k;
-                if (k >= p.num_steps) done = true;
-                if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
-                ep_ret = ep_ret + r;
-                rew_out = (float)r;
-                done_out = done ? 1 : 0;
-                p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
-                mode = 0;
-                if (done) {
-                    p.last_return[env] = ep_ret;
-                    p.last_len[env] = k;
-                    p.episodes[env] += 1;
-                    if (auto_reset) {
-                        need_reset = true;
-                    } else {
-                        p.done_state[env] = 1;
-                        was_done = 1;
-                        mode = 3;     // observable, and the env is frozen from the next step on
-                    }
-                }
-                const int open_zones = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : Z - (int)__popc(e.vis);
-                ends_soon = !done && (ends_soon || k + 1 >= p.num_steps ||
-                                      open_zones <= (TASK == ZENV_TASK_COLOUR_MATCH ? 2 : 1));
-            }
-
-            // ---- reset prefetch, one step ahead (see k_step_lane)
-            int pf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-            if (ends_soon && auto_reset && p.sched_mode == SCHED_SEQUENTIAL) {
-                const long long sl = ((long long)slot_first + (long long)epi_idx * (long long)p.sched_stride) %
-                                     (long long)p.bank_size;
-                const int *bz = reinterpret_cast<const int *>(p.bank_zone + 2 * (size_t)sl * Z);
-                pf[0] = bz[0];
-                if (4 * Z > 32) pf[1] = bz[32];
-                if (4 * Z > 64) pf[2] = bz[64];
-                if (4 * Z > 96) pf[3] = bz[96];
-                pf[4] = bz[4 * Z - 1];
-                pf[5] = reinterpret_cast<const int *>(p.bank_robot + 4 * (size_t)sl)[0];
-                if (TASK != ZENV_TASK_TSP) {
-                    const int *ba = p.bank_aux + (size_t)sl * Z;
-                    pf[6] = ba[0];
-                    pf[7] = ba[Z - 1];
-                }
-                pf[8] = (int)p.bank_seed[sl];
-            }
-
-            // ---- auto-reset (penv.py:8-11), wave-cooperative (see k_step_lane); additionally the
-            // finished lane refreshes its register copy of the zone arrays from LDS
-            unsigned long long pending = __ballot(need_reset);
-            if (pending) {
-                int my_slot = 0;
-                if (need_reset) {
-                    my_slot = next_bank_slot(p, env, epi_idx, slot_first);
-                    epi_idx += 1;
-                }
-                while (pending) {
-                    const int j = __ffsll((long long)pending) - 1;   // wave-uniform
-                    pending &= pending - 1;
-                    const int slot = __shfl(my_slot, j);
-                    const int env_j = env0 + j;
-                    const double *br = p.bank_robot + 4 * (size_t)slot;
-                    const double b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];
-                    int code = 0, aux = 0;
-                    float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (lane < Z) {
-                        const size_t bi = (size_t)slot * Z + lane;
-                        const double2 zz = reinterpret_cast<const double2 *>(p.bank_zone)[bi];
-                        const size_t zi = (size_t)lane * N + env_j;
-                        p.zxy[zi] = zz;
-                        if (TASK == ZENV_TASK_TIMED_TSP) {
-                            aux = p.bank_aux[bi];
-                            p.tmax[zi] = aux;
-                        } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                            code = p.bank_aux[bi];
-                        }
-                        en = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
-                        ents[j * Z + lane] = en;
-                        xaux[lane] = aux;
-                    }
-                    {
-                        const float nx = __shfl_down(en.x, 1), ny = __shfl_down(en.y, 1);
-                        if (lane < Z && !(lane & 1))
-                            p.zpf[(size_t)(lane >> 1) * N + env_j] =
-                                make_float4(en.x, en.y, lane + 1 < Z ? nx : 0.f, lane + 1 < Z ? ny : 0.f);
-                    }
-                    uint64_t colpack = 0ull;
-                    if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                        const unsigned long long m0 = __ballot(lane < Z && (code & 1));
-                        const unsigned long long m1 = __ballot(lane < Z && (code & 2));
-                        colpack = spread_even_bits((uint32_t)m0) | (spread_even_bits((uint32_t)m1) << 1);
-                    }
-                    EnvRegs fresh;
-                    fresh.x0 = b0; fresh.y0 = b1; fresh.bq0 = b2; fresh.bq3 = b3;
-                    fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
-                    fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
-                    fresh.vis = 0u;
-                    fresh.colpack = colpack;
-                    fresh.goal_dist = (TASK == ZENV_TASK_COLOUR_MATCH) ? hamming_to_goal(colpack, Z) : 0;
-                    fresh.steps = 0;
-                    float of[8];
-                    emit_obs8(p, fresh, of);   // the first obs of the next episode
-                    float2 next_act = make_float2(0.f, 0.f);
-                    if (pol.policy == ZENV_POLICY_UNIFORM)
-                        next_act = uniform_action(polt.env_index0 + (uint64_t)env_j, polt.step_index, polt.seed);
-                    else if (pol.policy == ZENV_POLICY_GREEDY)
-                        next_act = greedy_action_coop<TASK>(lane, Z, en.x, en.y, code, en.w, of[1], of[2], of[3], of[4]);
-                    wave_lds_fence();   // lane j reads back what its neighbours wrote
-                    // lane j: registers of the new episode
-#pragma unroll
-                    for (int h = 0; h < ZH; ++h) {
-                        const float4 a = ents[j * Z + 2 * h];
-                        const float4 b = (2 * h + 1 < Z) ? ents[j * Z + 2 * h + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (lane == j) zp[h] = make_float4(a.x, a.y, b.x, b.y);
-                    }
-#pragma unroll
-                    for (int z = 0; z < ZT; ++z) {
-                        const int v = (TASK == ZENV_TASK_TIMED_TSP) ? xaux[z] : 0;
-                        if (lane == j) auxr[z] = v;
-                    }
-                    if (lane == j) {
-                        e.vis = 0u;
-                        e.colpack = colpack;
-                        e.goal_dist = fresh.goal_dist;
-                        e.steps = 0;
-                        ep_ret = 0.0;
-                        mode = 2;
-                        p.seed[env] = p.bank_seed[slot];
-                        store_frame(p, env, fresh);
-                        xframe[2 * lane] = make_double2(b0, b1);
-                        xframe[2 * lane + 1] = make_double2(b2, b3);
-                        xact[lane] = next_act;
-                        store_obs8(p, env, of);
-                    }
-                    wave_lds_fence();   // xaux is reused by the next finished env
-                }
-            }
-
-            if (valid) {
-                xmode[lane] = mode;
-                xstep[lane] = e.steps;
-            }
-            lds_ctr_set(ctr + 0, t + 1);                  // finalised(t)
-            if (valid) {
-                p.reward[env] = rew_out;
-                p.done_out[env] = done_out;
-                p.goal_met[env] = goal_out;
-            }
-            wave_lds_fence();
+            lds_ctr_wait(ctr + 0, t + 1);                 // published(t)
+            const int b = t & 1;
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 1)   // diagnostic builds only: ZENV_EXP bit 0 drops the flush
-            flush_entries<TASK>(ents, stage, tile_dst, n_rows, lane);
+            flush_static<TASK, ZT>(p, sent, dynw + b * kWave, reinterpret_cast<const uint8_t *>(cdw + b * kWave * (ZB / 4)),
+                                   stage, tile_dst, n_rows, lane);
 #endif
-            asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]),
-                         "v"(pf[7]), "v"(pf[8]));
+            lds_ctr_set(ctr + 1, t + 1);                  // flushed(t)
         }
-
-        // ---- epilogue: the registers go back to the state arrays
-        if (valid) {
-            p.ep_return[env] = ep_ret;
-            store_counters(p, env, TASK, e);
-            if (TASK == ZENV_TASK_COLOUR_MATCH) {
-#pragma unroll
-                for (int z = 0; z < ZT; ++z) p.cooldown[(size_t)z * N + env] = (uint8_t)auxr[z];
-            }
-        }
-        (void)n_chunks;
         return;
     }
 
-    // ======================================================================= physics wave
+    // ======================================================================= env wave
+    // The env wave is one long dependent instruction stream and the stream wave mostly waits on the
+    // store path: let the env wave win the SIMD's issue slot when both are ready (8.5 -> 7.7 us).
+    __builtin_amdgcn_s_setprio(ZENV_EPRIO);
     EnvRegs e;
-    e.steps = 0;
-    float2 act = make_float2(0.f, 0.f);
     bool frozen = false;
+    double ep_ret = 0.0;
+    int epi_idx = 0, slot_first = 0;
+    float2 act = make_float2(0.f, 0.f);
+    float4 zp[ZH];
+    int auxr[ZT];
+    e.steps = 0; e.vis = 0u; e.colpack = 0ull; e.goal_dist = 0;
+    e.q0 = e.q1 = e.q2 = e.v0 = e.v1 = e.v2 = 0.0;
+    e.x0 = e.y0 = e.bq0 = e.bq3 = 0.0;
+#pragma unroll
+    for (int h = 0; h < ZH; ++h) zp[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int z = 0; z < ZT; ++z) auxr[z] = 0;
     if (valid) {
         const double2 qa = p.qa[env], qb = p.qb[env], qc = p.qc[env];
         const double2 fa = p.fa[env], fb = p.fb[env];
@@ -1485,56 +1433,283 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
         e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
         act = reinterpret_cast<const float2 *>(p.actions)[env];
         frozen = p.done_state[env] != 0;
+        e.steps = p.steps[env];
+        if (kColour) {
+            e.colpack = p.colpack[env];
+            e.goal_dist = p.goal_dist[env];
+        } else {
+            e.vis = p.vis[env];
+        }
+        ep_ret = p.ep_return[env];
+        epi_idx = p.episode_idx[env];
+        slot_first = p.slot_first[env];
+#pragma unroll
+        for (int h = 0; h < ZH; ++h) zp[h] = p.zpf[(size_t)h * N + env];
+#pragma unroll
+        for (int z = 0; z < ZT; ++z) {
+            const size_t zi = (size_t)z * N + env;
+            if (TASK == ZENV_TASK_TIMED_TSP) auxr[z] = p.tmax[zi];
+            if (kColour) auxr[z] = p.cooldown[zi];
+        }
     }
-    __syncthreads();
-    {
-        double rx = 0.0, ry = 0.0;
-        if (valid) world_pos(e, rx, ry);
-        xpose[lane] = make_double2(rx, ry);
-        lds_ctr_set(ctr + 2, 1);                          // pose(0)
+#pragma unroll
+    for (int z = 0; z < ZT; ++z) {
+        const float4 pr = zp[z >> 1];
+        sent[lane * Z + z] = make_static<TASK>((z & 1) ? pr.z : pr.x, (z & 1) ? pr.w : pr.y, auxr[z]);
     }
+    if (lane < 4) ctr[lane] = 0;
+    __syncthreads();   // the only barrier of the launch
+
     for (int t = 0; t < n_steps; ++t) {
         StepPolicy polt = pol;
         polt.step_index = pol.step_index + (uint32_t)t;
+        float rew_out = 0.f;
+        uint8_t done_out = 1, goal_out = 0;
+        bool need_reset = false;
+        int first = -1;
+        uint64_t dword = kDynZero;
         float o[8];
-        if (valid && !frozen) {
-            // Engine.step: ctrl = clip(action, ctrlrange); frameskip x mj_step
-            const double c0 = det_clamp((double)act.x, -1.0, 1.0);
-            const double c1 = det_clamp((double)act.y, -1.0, 1.0);
-            EnvRegs w = e;
+        if (valid && frozen) {
+            // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
+            for (int i = 0; i < 8; ++i) o[i] = 0.f;
+            store_obs8(p, env, o);
+            if (pol.policy >= 0) act = make_float2(0.f, 0.f);   // what either policy kernel makes of a zero obs
+        } else if (valid) {
+            const int k = e.steps + 1;
+            double rx, ry;
+            world_pos(e, rx, ry);          // set_mocaps() sees the PRE-physics pose
+            // ---- zone pass (see k_step_lane), entirely on registers
+            const float rxf = (float)rx, ryf = (float)ry;
+            // d2f >= +0, so its bit pattern orders like its value: "d2f < d2_lo" is the borrow of an
+            // integer subtraction, shifted into the mask with one v_alignbit (zones visited from the
+            // top so that zone z ends up in bit z).  A NaN pose sorts above d2_hi: outside, as before.
+            uint32_t in_mask = 0u, out_mask = 0u, elig_mask = 0u, expired = 0u;
+            const uint32_t lo_bits = __float_as_uint(p.d2_lo), hi_bits = __float_as_uint(p.d2_hi);
+#pragma unroll
+            for (int z = ZT - 1; z >= 0; --z) {
+                const float4 pr = zp[z >> 1];
+                const float x3 = (z & 1) ? pr.z : pr.x, y3 = (z & 1) ? pr.w : pr.y;
+                const float dxf = __builtin_fmaf(3.f, x3, -rxf), dyf = __builtin_fmaf(3.f, y3, -ryf);
+                const uint32_t d2b = __float_as_uint(__builtin_fmaf(dxf, dxf, dyf * dyf));
+                in_mask = __builtin_amdgcn_alignbit(in_mask, d2b - lo_bits, 31);       // d2f <  d2_lo
+                out_mask = __builtin_amdgcn_alignbit(out_mask, hi_bits - d2b, 31);     // d2f >  d2_hi
+                if (kColour) {
+                    const int cd = max(auxr[z] - 1, 0);         // colour_match_env.py:98-100
+                    auxr[z] = cd;
+                    elig_mask = __builtin_amdgcn_alignbit(elig_mask, (uint32_t)(cd - 1), 31);          // cd == 0
+                } else if (TASK == ZENV_TASK_TIMED_TSP) {
+                    expired = __builtin_amdgcn_alignbit(expired, (uint32_t)(auxr[z] - (k + 1)), 31);   // tmax - k <= 0, TTSP_env.py:67
+                }
+            }
+            if (!(rxf == rxf && ryf == ryf)) {   // NaN pose (its sign bit is arbitrary): every zone is outside
+                in_mask = 0u;
+                out_mask = ~0u;
+            }
+            uint32_t amb_mask = ~(in_mask | out_mask);
+            while (amb_mask & full) {
+                // the rim: exact float64 test on the float64 zone centres (rare, divergent)
+                const int z = __ffs((int)(amb_mask & full)) - 1;
+                amb_mask &= ~(1u << z);
+                const double2 zz = p.zxy[(size_t)z * N + env];
+                const double dx = zz.x - rx, dy = zz.y - ry;
+                if (dx * dx + dy * dy <= p.hit_d2) in_mask |= 1u << z;
+            }
+            if (!kColour) elig_mask = ~e.vis;
+            const uint32_t hits = in_mask & elig_mask & full;
+            first = hits ? __ffs((int)hits) - 1 : -1;                // lowest index wins, one per step
+            if (first >= 0) {
+                if (kColour) {
+                    int col = (int)((e.colpack >> (2 * first)) & 3ull);
+                    col = (col == 2) ? 0 : col + 1;                  // Blue->Green->Red->Blue
+                    e.colpack = (e.colpack & ~(3ull << (2 * first))) | ((uint64_t)col << (2 * first));
+#pragma unroll
+                    for (int z = 0; z < ZT; ++z)
+                        if (z == first) auxr[z] = p.max_cd;
+                } else {
+                    e.vis |= 1u << first;
+                }
+            }
+            const bool timed_out = TASK == ZENV_TASK_TIMED_TSP && (expired & ~e.vis & full) != 0u;
+            // ---- reward / goal / termination (Engine.step order)
+            double r = 0.0;
+            bool goal;
+            if (kColour) {
+                if (first >= 0) {
+                    const int nd = hamming_to_goal(e.colpack, Z);
+                    r = (double)(e.goal_dist - nd);
+                    e.goal_dist = nd;
+                }
+                goal = e.goal_dist == 0;
+            } else {
+                r = first >= 0 ? 1.0 : 0.0;
+                goal = (e.vis & full) == full;
+            }
+            bool done = false;
+            if (goal) {
+                r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
+                done = true;
+                goal_out = 1;
+            }
+            e.steps = k;
+            if (k >= p.num_steps) done = true;
+            if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
+            ep_ret = ep_ret + r;
+            rew_out = (float)r;
+            done_out = done ? 1 : 0;
+            p.visit_count[env] = kColour ? e.goal_dist : __popc(e.vis);
+            if (done) {
+                p.last_return[env] = ep_ret;
+                p.last_len[env] = k;
+                p.episodes[env] += 1;
+            }
+            need_reset = done && auto_reset;
+            dword = kColour ? e.colpack
+                            : ((uint64_t)e.vis | (TASK == ZENV_TASK_TIMED_TSP ? (uint64_t)(uint32_t)k << 32 : 0ull));
+
+            if (!need_reset) {
+                // ---- Engine.step: ctrl = clip(action, ctrlrange); frameskip x mj_step; obs; next action
+                const double c0 = det_clamp((double)act.x, -1.0, 1.0);
+                const double c1 = det_clamp((double)act.y, -1.0, 1.0);
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 2)   // diagnostic: bit 1 drops the physics
-            for (int i = 0; i < p.frameskip; ++i) mj_substep(p, w, c0, c1);
+                for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
 #endif
-            lds_ctr_wait(ctr + 0, t + 1);                 // finalised(t)
-            const int mode = xmode[lane];
-            if (mode == 0 || mode == 3) {
-                e = w;
-                e.steps = xstep[lane];
                 emit_obs8(p, e, o);
                 store_obs8(p, env, o);
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 4)   // diagnostic: bit 2 drops the action source
-                if (pol.policy >= 0) act = scripted_action<TASK, ZT>(polt, env, my_ents, Z, o);
+                if (pol.policy == ZENV_POLICY_UNIFORM)
+                    act = uniform_action(polt.env_index0 + (uint64_t)env, polt.step_index, polt.seed);
+                else if (pol.policy == ZENV_POLICY_GREEDY)
+                    act = greedy_action_regs<TASK, ZT>(zp, auxr, e.vis, e.colpack, o[1], o[2], o[3], o[4]);
 #endif
-                if (mode == 3) frozen = true;
-            } else if (mode == 2) {
-                // reset: the zone wave published the new placement, first obs and next action
-                const double2 fa = xframe[2 * lane], fb = xframe[2 * lane + 1];
-                e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
-                e.q0 = e.q1 = e.q2 = 0.0;
-                e.v0 = e.v1 = e.v2 = 0.0;
-                act = xact[lane];
+                if (done) {          // finished, no auto-reset: frozen from the next step on
+                    p.done_state[env] = 1;
+                    frozen = true;
+                }
             }
-        } else {
-            lds_ctr_wait(ctr + 0, t + 1);
         }
-        lds_ctr_set(ctr + 1, t + 1);                      // consumed(t)
-        double rx = 0.0, ry = 0.0;
-        if (valid) world_pos(e, rx, ry);
-        xpose[lane] = make_double2(rx, ry);
-        lds_ctr_set(ctr + 2, t + 2);                      // pose(t+1)
+
+        // ---- auto-reset (penv.py:8-11), wave-cooperative: lane z <-> zone z of the finished env
+        unsigned long long pending = __ballot(need_reset);
+        if (pending) {
+            lds_ctr_wait(ctr + 1, t);     // flush(t-1) has read the static entries about to change
+            int my_slot = 0;
+            if (need_reset) {
+                my_slot = next_bank_slot(p, env, epi_idx, slot_first);
+                epi_idx += 1;
+            }
+            while (pending) {
+                const int j = __ffsll((long long)pending) - 1;   // wave-uniform
+                pending &= pending - 1;
+                const int slot = __shfl(my_slot, j);
+                const int env_j = env0 + j;
+                const double *br = p.bank_robot + 4 * (size_t)slot;
+                const double b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];
+                int code = 0, aux = 0;
+                float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lane < Z) {
+                    const size_t bi = (size_t)slot * Z + lane;
+                    const double2 zz = reinterpret_cast<const double2 *>(p.bank_zone)[bi];
+                    const size_t zi = (size_t)lane * N + env_j;
+                    p.zxy[zi] = zz;
+                    if (TASK == ZENV_TASK_TIMED_TSP) {
+                        aux = p.bank_aux[bi];
+                        p.tmax[zi] = aux;
+                    } else if (kColour) {
+                        code = p.bank_aux[bi];
+                    }
+                    en = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
+                    sent[j * Z + lane] = make_static<TASK>(en.x, en.y, aux);
+                }
+                {
+                    const float nx = __shfl_down(en.x, 1), ny = __shfl_down(en.y, 1);
+                    if (lane < Z && !(lane & 1))
+                        p.zpf[(size_t)(lane >> 1) * N + env_j] =
+                            make_float4(en.x, en.y, lane + 1 < Z ? nx : 0.f, lane + 1 < Z ? ny : 0.f);
+                }
+                uint64_t colpack = 0ull;
+                if (kColour) {
+                    const unsigned long long m0 = __ballot(lane < Z && (code & 1));
+                    const unsigned long long m1 = __ballot(lane < Z && (code & 2));
+                    colpack = spread_even_bits((uint32_t)m0) | (spread_even_bits((uint32_t)m1) << 1);
+                }
+                EnvRegs fresh;
+                fresh.x0 = b0; fresh.y0 = b1; fresh.bq0 = b2; fresh.bq3 = b3;
+                fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
+                fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
+                fresh.vis = 0u;
+                fresh.colpack = colpack;
+                fresh.goal_dist = kColour ? hamming_to_goal(colpack, Z) : 0;
+                fresh.steps = 0;
+                float of[8];
+                emit_obs8(p, fresh, of);   // the first obs of the next episode
+                float2 next_act = make_float2(0.f, 0.f);
+                if (pol.policy == ZENV_POLICY_UNIFORM)
+                    next_act = uniform_action(polt.env_index0 + (uint64_t)env_j, polt.step_index, polt.seed);
+                else if (pol.policy == ZENV_POLICY_GREEDY)
+                    next_act = greedy_action_coop<TASK>(lane, Z, en.x, en.y, code, en.w, of[1], of[2], of[3], of[4]);
+                wave_lds_fence();   // lane j reads back what its neighbours wrote
+#pragma unroll
+                for (int h = 0; h < ZH; ++h) {
+                    const SE a = sent[j * Z + 2 * h];
+                    const SE b = sent[j * Z + ((2 * h + 1 < Z) ? 2 * h + 1 : 2 * h)];
+                    if (lane == j) zp[h] = make_float4(a.x, a.y, (2 * h + 1 < Z) ? b.x : 0.f, (2 * h + 1 < Z) ? b.y : 0.f);
+                }
+                if constexpr (TASK == ZENV_TASK_TIMED_TSP) {
+#pragma unroll
+                    for (int z = 0; z < ZT; ++z) {
+                        const int v = __float_as_int(sent[j * Z + z].z);
+                        if (lane == j) auxr[z] = v;
+                    }
+                }
+                if (lane == j) {
+                    if (kColour) {
+#pragma unroll
+                        for (int z = 0; z < ZT; ++z) auxr[z] = 0;
+                    }
+                    e = fresh;
+                    ep_ret = 0.0;
+                    act = next_act;
+                    dword = kColour ? colpack : 0ull;          // nothing visited, step count 0
+                    p.seed[env] = p.bank_seed[slot];
+                    store_obs8(p, env, of);
+                }
+            }
+        }
+
+        // ---- publish the step word of this step (its slot was last read by flush(t-2))
+        if (t >= 2) lds_ctr_wait(ctr + 1, t - 1);
+        {
+            const int b = t & 1;
+            dynw[b * kWave + lane] = dword;
+            if (kColour) {
+#pragma unroll
+                for (int w = 0; w < ZB / 4; ++w) {
+                    uint32_t pk = 0u;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (4 * w + i < ZT) pk |= ((uint32_t)auxr[4 * w + i] & 0xFFu) << (8 * i);
+                    cdw[(b * kWave + lane) * (ZB / 4) + w] = pk;
+                }
+            }
+        }
+        lds_ctr_set(ctr + 0, t + 1);                      // published(t)
+        if (valid) {
+            p.reward[env] = rew_out;
+            p.done_out[env] = done_out;
+            p.goal_met[env] = goal_out;
+        }
     }
+
+    // ---- the registers go back to the state arrays
     if (valid) {
         store_dyn(p, env, e);
+        store_frame(p, env, e);
+        store_counters(p, env, TASK, e);
+        p.ep_return[env] = ep_ret;
+        if (kColour) {
+#pragma unroll
+            for (int z = 0; z < ZT; ++z) p.cooldown[(size_t)z * N + env] = (uint8_t)auxr[z];
+        }
         if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = act;
     }
 }
@@ -1609,9 +1784,12 @@ hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset,
 static inline size_t rollout_lds_bytes(const DevParams &p)
 {
     const int G = p.F == 6 ? 3 : 7;
-    return (size_t)kWave * p.Z * sizeof(float4) + (size_t)kWave * G * sizeof(float4)   // entries, flush slab
-           + kWave * sizeof(double2) + 2 * kWave * sizeof(double2) + kWave * sizeof(float2)   // pose, frame, action
-           + 3 * kWave * sizeof(int) + 4 * sizeof(int);                                  // mode, step, aux; counters
+    const int ZB = (p.Z + 3) & ~3;
+    const size_t ent = p.task == ZENV_TASK_TIMED_TSP ? sizeof(float4) : sizeof(float2);
+    return (size_t)kWave * p.Z * ent + (size_t)kWave * G * sizeof(float4)         // static entries, flush slab
+           + 2 * kWave * sizeof(uint64_t)                                          // per-step words
+           + (p.task == ZENV_TASK_COLOUR_MATCH ? 2 * (size_t)kWave * ZB : 0)       // cooldown bytes
+           + 4 * sizeof(int);                                                      // counters
 }
 
 bool rollout_kernel_available(const DevParams &p) { return p.Z == 5 || p.Z == 6 || p.Z == 15 || p.Z == 25; }

@@ -588,7 +588,7 @@ extern "C" int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t
     return ZENV_OK;
 }
 
-static constexpr int kRolloutChunk = 64;   // steps per launch of the persistent kernel
+static constexpr int kRolloutChunk = ZENV_ROLLOUT_CHUNK;   // steps per launch of the persistent kernel
 
 extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
                             int auto_reset, int flags, int event_stride, float *ms_total, float *ms_step_kernel_avg)

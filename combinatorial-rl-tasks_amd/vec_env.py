@@ -176,7 +176,7 @@ class ZoneVecEnv:
                 time_step_kernel=False, fused=True, event_stride=1, mode=None):
         """K closed-loop steps a_t = policy(obs_t, t); step(a_t) on the handle's stream.
 
-        mode "persistent" (default): one launch advances every env by up to 64 steps, state in
+        mode "persistent" (default): one launch advances every env by up to 256 steps, state in
         registers, all per-step outputs still written on every step; "per_step": one step-kernel
         launch per step which also emits the next action; "unfused" (or fused=False): per-step
         launches with a stand-alone policy kernel before each.  Same results in all three.

@@ -104,6 +104,11 @@ def lib():
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]
         L.orc_rollout.restype = C.c_int64
+        L.orc_rollout_wrapped.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_int64, C.c_int32, C.c_uint64, C.c_uint64, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+        L.orc_rollout_wrapped.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -203,8 +208,9 @@ class OracleEnv:
 
 
 def rollout(cfg, seeds0, n_steps, policy, seed_stride=0, policy_seed=0x5EED, env_index0=0,
-            n_threads=1):
-    """Batch driver.  Returns dict of per-env arrays + total env-steps."""
+            n_threads=1, seed_period=0):
+    """Batch driver.  Returns dict of per-env arrays + total env-steps.  seed_period > 0: episode k
+    of env i replays seed seeds0[i] + (k % seed_period) * seed_stride (a wrapping map bank)."""
     seeds0 = np.ascontiguousarray(seeds0, np.int64)
     n = len(seeds0)
     Z, F = cfg.num_zones, lib().orc_zone_feat(C.byref(cfg))
@@ -212,8 +218,8 @@ def rollout(cfg, seeds0, n_steps, policy, seed_stride=0, policy_seed=0x5EED, env
         reward_sum=np.zeros(n, np.float64), episodes=np.zeros(n, np.int32),
         last_return=np.zeros(n, np.float64), last_len=np.zeros(n, np.int32),
         obs=np.zeros((n, 8), np.float32), zone_obs=np.zeros((n, Z, F), np.float32))
-    total = lib().orc_rollout(
-        C.byref(cfg), n, int(n_steps), int(policy), seeds0.ctypes.data, int(seed_stride),
+    total = lib().orc_rollout_wrapped(
+        C.byref(cfg), n, int(n_steps), int(policy), seeds0.ctypes.data, int(seed_stride), int(seed_period),
         int(policy_seed), int(env_index0), int(n_threads),
         out["reward_sum"].ctypes.data, out["episodes"].ctypes.data,
         out["last_return"].ctypes.data, out["last_len"].ctypes.data,

@@ -579,8 +579,8 @@ void orc_policy(int policy, const orc_config *cfg, const float *o, const float *
 /* =====================================================================================
  * Batch driver: N independent envs, closed loop, auto-reset as penv.py:7-11.
  * ===================================================================================== */
-int64_t orc_rollout(const orc_config *cfg, int n_env, int n_steps, int policy,
-                    const int64_t *seeds0, int64_t seed_stride, uint64_t policy_seed,
+int64_t orc_rollout_wrapped(const orc_config *cfg, int n_env, int n_steps, int policy,
+                    const int64_t *seeds0, int64_t seed_stride, int32_t seed_period, uint64_t policy_seed,
                     uint64_t env_index0, int n_threads,
                     double *reward_sum, int32_t *episodes, double *last_return,
                     int32_t *last_len, float *final_obs8, float *final_zone_obs)
@@ -608,7 +608,8 @@ int64_t orc_rollout(const orc_config *cfg, int n_env, int n_steps, int policy,
             if (d) {
                 l_ret = ep_ret; l_len = ep_len; n_ep++;
                 ep_ret = 0.0; ep_len = 0;
-                seed += seed_stride;
+                /* bank of seed_period maps per env, replayed in order (the device bank wraps the same way) */
+                seed = seeds0[i] + (seed_period > 0 ? (int64_t)(n_ep % seed_period) : (int64_t)n_ep) * seed_stride;
                 if (orc_reset(&e, cfg, seed) != 0) break;
             }
             orc_obs(&e, o, zo);
@@ -621,4 +622,14 @@ int64_t orc_rollout(const orc_config *cfg, int n_env, int n_steps, int policy,
         if (final_zone_obs) memcpy(final_zone_obs + (size_t)i * Z * F, zo, sizeof(float) * Z * F);
     }
     return total;
+}
+
+int64_t orc_rollout(const orc_config *cfg, int n_env, int n_steps, int policy,
+                    const int64_t *seeds0, int64_t seed_stride, uint64_t policy_seed,
+                    uint64_t env_index0, int n_threads,
+                    double *reward_sum, int32_t *episodes, double *last_return,
+                    int32_t *last_len, float *final_obs8, float *final_zone_obs)
+{
+    return orc_rollout_wrapped(cfg, n_env, n_steps, policy, seeds0, seed_stride, 0, policy_seed, env_index0, n_threads,
+                               reward_sum, episodes, last_return, last_len, final_obs8, final_zone_obs);
 }

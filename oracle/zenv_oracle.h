@@ -120,6 +120,14 @@ int64_t orc_rollout(const orc_config *cfg, int n_env, int n_steps, int policy,
                     double *reward_sum, int32_t *episodes, double *last_return,
                     int32_t *last_len, float *final_obs8, float *final_zone_obs);
 
+/* Same, with a bank of seed_period maps per env replayed in order: episode k uses seed
+ * seeds0[i] + (k % seed_period)*seed_stride (seed_period = 0: no wrap). */
+int64_t orc_rollout_wrapped(const orc_config *cfg, int n_env, int n_steps, int policy,
+                            const int64_t *seeds0, int64_t seed_stride, int32_t seed_period,
+                            uint64_t policy_seed, uint64_t env_index0, int n_threads,
+                            double *reward_sum, int32_t *episodes, double *last_return,
+                            int32_t *last_len, float *final_obs8, float *final_zone_obs);
+
 #ifdef __cplusplus
 }
 #endif

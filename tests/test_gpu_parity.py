@@ -164,6 +164,27 @@ def test_persistent_rollout_interleaves_with_steps(zenv_mod, oracle_mod, task, z
     env.close()
 
 
+@pytest.mark.parametrize("mode", ["persistent", "per_step"])
+def test_rollout_wraps_around_the_map_bank(zenv_mod, oracle_mod, mode):
+    """More episodes than the bank holds per env: the schedule replays the env's maps in order."""
+    Z, O = zenv_mod, oracle_mod
+    n, depth, T = 150, 3, 700
+    cfg = Z.default_config(1, 15, zones_keepout=0.55, num_steps=60)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(1, depth * n)
+    env.schedule_sequential(stride=n)
+    env.reset()
+    env.rollout(T, Z.POLICY_GREEDY, mode=mode)
+    ref = O.rollout(oracle_config_from(O, cfg), 1 + np.arange(n), T, O.POLICY_GREEDY, seed_stride=n,
+                    seed_period=depth, n_threads=8)
+    assert ref["episodes"].min() > 2 * depth
+    assert np.array_equal(env.get(Z.F_EPISODES), ref["episodes"])
+    assert np.array_equal(env.get(Z.F_OBS), ref["obs"])
+    assert np.array_equal(env.get(Z.F_ZONE_OBS), ref["zone_obs"])
+    assert np.array_equal(env.get(Z.F_LAST_RETURN), ref["last_return"])
+    env.close()
+
+
 def test_persistent_rollout_without_auto_reset(zenv_mod):
     """auto_reset = 0 inside a persistent launch: a finished env freezes (WaitWrapper masking),
     its joint state stays where the episode ended -- same as per-step launches."""

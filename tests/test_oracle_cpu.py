@@ -358,3 +358,22 @@ def test_greedy_policy_solves_pointtsp(oracle_mod):
     out = O.rollout(cfg, np.arange(1000000, 1000016), 2000, O.POLICY_GREEDY, n_threads=4)
     assert (out["episodes"] >= 1).all()
     assert out["last_return"].mean() > 15.0        # all 15 zones + a time bonus on most maps
+
+
+def test_rollout_wrapping_map_bank(oracle_mod):
+    """orc_rollout_wrapped: a bank of `seed_period` maps per env replayed in order."""
+    O = oracle_mod
+    cfg = O.default_config(O.TASK_TIMED, 6, zones_keepout=0.55, num_steps=40)
+    seeds = np.arange(11, 19)
+    a = O.rollout(cfg, seeds, 300, O.POLICY_GREEDY, seed_stride=7, seed_period=1, n_threads=2)
+    b = O.rollout(cfg, seeds, 300, O.POLICY_GREEDY, seed_stride=0, n_threads=2)
+    assert a["episodes"].min() >= 7
+    for k in ("obs", "zone_obs", "episodes", "last_return", "reward_sum"):
+        assert np.array_equal(a[k], b[k])
+    c = O.rollout(cfg, seeds, 300, O.POLICY_GREEDY, seed_stride=7, seed_period=3, n_threads=2)
+    d = O.rollout(cfg, seeds, 300, O.POLICY_GREEDY, seed_stride=7, n_threads=2)       # no wrap
+    assert not np.array_equal(c["zone_obs"], d["zone_obs"])
+    # the first three episodes are the same maps in both
+    e = O.rollout(cfg, seeds, 10, O.POLICY_GREEDY, seed_stride=7, seed_period=3, n_threads=2)
+    f = O.rollout(cfg, seeds, 10, O.POLICY_GREEDY, seed_stride=7, n_threads=2)
+    assert e["episodes"].max() < 3 and np.array_equal(e["zone_obs"], f["zone_obs"])
