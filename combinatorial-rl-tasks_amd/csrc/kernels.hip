@@ -172,26 +172,26 @@ struct Pose {
 
 __device__ __forceinline__ void world_pos(const EnvRegs &e, double &px, double &py)
 {
-    const double cr = e.bq0 * e.bq0 - e.bq3 * e.bq3;
+    const double cr = __builtin_fma(e.bq0, e.bq0, -(e.bq3 * e.bq3));
     const double sr = 2.0 * (e.bq0 * e.bq3);
-    px = e.x0 + (cr * e.q0 - sr * e.q1);
-    py = e.y0 + (sr * e.q0 + cr * e.q1);
+    px = __builtin_fma(cr, e.q0, __builtin_fma(-sr, e.q1, e.x0));
+    py = __builtin_fma(sr, e.q0, __builtin_fma(cr, e.q1, e.y0));
 }
 
 __device__ __forceinline__ Pose forward_pose(const EnvRegs &e)
 {
     Pose o;
-    const double cr = e.bq0 * e.bq0 - e.bq3 * e.bq3;
+    const double cr = __builtin_fma(e.bq0, e.bq0, -(e.bq3 * e.bq3));
     const double sr = 2.0 * (e.bq0 * e.bq3);
-    o.px = e.x0 + (cr * e.q0 - sr * e.q1);
-    o.py = e.y0 + (sr * e.q0 + cr * e.q1);
-    o.vx = cr * e.v0 - sr * e.v1;
-    o.vy = sr * e.v0 + cr * e.v1;
+    o.px = __builtin_fma(cr, e.q0, __builtin_fma(-sr, e.q1, e.x0));
+    o.py = __builtin_fma(sr, e.q0, __builtin_fma(cr, e.q1, e.y0));
+    o.vx = __builtin_fma(cr, e.v0, -(sr * e.v1));
+    o.vy = __builtin_fma(sr, e.v0, cr * e.v1);
     o.w = e.v2;
     double hs, hc;
     det_sincos_inl(0.5 * e.q2, hs, hc);
-    o.xq0 = e.bq0 * hc - e.bq3 * hs;
-    o.xq3 = e.bq0 * hs + e.bq3 * hc;
+    o.xq0 = __builtin_fma(e.bq0, hc, -(e.bq3 * hs));
+    o.xq3 = __builtin_fma(e.bq0, hs, e.bq3 * hc);
     return o;
 }
 
@@ -351,23 +351,23 @@ __device__ __forceinline__ void mj_substep(const DevParams &p, EnvRegs &e, doubl
     const double mcs = p.mc * s, mck = p.mc * k;
     const double w2 = e.v2 * e.v2;
     const double f0 = det_clamp(c0, -p.fmax, p.fmax);
-    const double f1 = det_clamp(p.kv * c1 - p.kv * (p.gear * e.v2), -p.fmax, p.fmax);
+    const double f1 = det_clamp(__builtin_fma(-p.kv, p.gear * e.v2, p.kv * c1), -p.fmax, p.fmax);
     const double gf0 = p.gear * f0;
-    const double rhs0 = (gf0 * k + mck * w2) - p.b0 * e.v0;
-    const double rhs1 = (gf0 * s + mcs * w2) - p.b1 * e.v1;
-    const double rhs2 = p.gear * f1 - p.b2 * e.v2;
+    const double rhs0 = __builtin_fma(-p.b0, e.v0, __builtin_fma(mck, w2, gf0 * k));
+    const double rhs1 = __builtin_fma(-p.b1, e.v1, __builtin_fma(mcs, w2, gf0 * s));
+    const double rhs2 = __builtin_fma(-p.b2, e.v2, p.gear * f1);
     const double t0 = rhs0 * p.inv00, t1 = rhs1 * p.inv11;
-    const double den = (p.A22 - (mcs * mcs) * p.inv00) - (mck * mck) * p.inv11;
-    const double num = (rhs2 + mcs * t0) - mck * t1;
+    const double den = __builtin_fma(-(mck * mck), p.inv11, __builtin_fma(-(mcs * mcs), p.inv00, p.A22));
+    const double num = __builtin_fma(-mck, t1, __builtin_fma(mcs, t0, rhs2));
     const double a2 = num / den;
-    const double a0 = (rhs0 + mcs * a2) * p.inv00;
-    const double a1 = (rhs1 - mck * a2) * p.inv11;
-    e.v0 = e.v0 + p.h * a0;
-    e.v1 = e.v1 + p.h * a1;
-    e.v2 = e.v2 + p.h * a2;
-    e.q0 = e.q0 + p.h * e.v0;
-    e.q1 = e.q1 + p.h * e.v1;
-    e.q2 = e.q2 + p.h * e.v2;
+    const double a0 = __builtin_fma(mcs, a2, rhs0) * p.inv00;
+    const double a1 = __builtin_fma(-mck, a2, rhs1) * p.inv11;
+    e.v0 = __builtin_fma(p.h, a0, e.v0);
+    e.v1 = __builtin_fma(p.h, a1, e.v1);
+    e.v2 = __builtin_fma(p.h, a2, e.v2);
+    e.q0 = __builtin_fma(p.h, e.v0, e.q0);
+    e.q1 = __builtin_fma(p.h, e.v1, e.q1);
+    e.q2 = __builtin_fma(p.h, e.v2, e.q2);
 }
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -392,9 +392,6 @@ __device__ __forceinline__ void wave_lds_fence()
 // PointTSP-25: plain 14.0 us, sc1 12.8 us, nt 12.65 us per launch.
 #ifndef ZENV_STORE_AUX
 #define ZENV_STORE_AUX 2
-#endif
-#ifndef ZENV_EPRIO
-#define ZENV_EPRIO 3   // wave priority of the persistent kernel's env wave (diagnostic builds vary it)
 #endif
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
@@ -561,8 +558,8 @@ __device__ __forceinline__ float2 greedy_action(const Rows rows, int Zrt, float 
             const ZoneView v = rows.get(z);
             const bool eligible = (TASK == ZENV_TASK_COLOUR_MATCH) ? (v.aux == 0.f && v.code != target_colour)
                                                                     : (v.code == 0);
-            const double dx = 3.0 * (double)v.x - px, dy = 3.0 * (double)v.y - py;
-            const double d2 = dx * dx + dy * dy;
+            const double dx = __builtin_fma(3.0, (double)v.x, -px), dy = __builtin_fma(3.0, (double)v.y, -py);
+            const double d2 = __builtin_fma(dx, dx, dy * dy);
             d2s[z] = eligible ? d2 : __builtin_inf();
             idx[z] = z;
         }
@@ -579,25 +576,25 @@ __device__ __forceinline__ float2 greedy_action(const Rows rows, int Zrt, float 
         if (d2s[0] < __builtin_inf()) {
             best = idx[0];
             const ZoneView v = rows.get(best);
-            bdx = 3.0 * (double)v.x - px;
-            bdy = 3.0 * (double)v.y - py;
-            bd2 = bdx * bdx + bdy * bdy;
+            bdx = __builtin_fma(3.0, (double)v.x, -px);
+            bdy = __builtin_fma(3.0, (double)v.y, -py);
+            bd2 = __builtin_fma(bdx, bdx, bdy * bdy);
         }
     } else {
         for (int z = 0; z < Z; ++z) {
             const ZoneView v = rows.get(z);
             const bool eligible = (TASK == ZENV_TASK_COLOUR_MATCH) ? (v.aux == 0.f && v.code != target_colour)
                                                                     : (v.code == 0);
-            const double dx = 3.0 * (double)v.x - px, dy = 3.0 * (double)v.y - py;
-            const double d2 = dx * dx + dy * dy;
+            const double dx = __builtin_fma(3.0, (double)v.x, -px), dy = __builtin_fma(3.0, (double)v.y, -py);
+            const double d2 = __builtin_fma(dx, dx, dy * dy);
             if (eligible && (best < 0 || d2 < bd2)) { best = z; bd2 = d2; bdx = dx; bdy = dy; }
         }
     }
     float2 a = make_float2(0.f, 0.f);
     if (best >= 0 && bd2 > 1e-18) {
         const double n = sqrt(bd2);
-        const double cs = (hx * bdx + hy * bdy) / n;
-        const double sn = (hx * bdy - hy * bdx) / n;
+        const double cs = __builtin_fma(hx, bdx, hy * bdy) / n;
+        const double sn = __builtin_fma(hx, bdy, -(hy * bdx)) / n;
         if (cs < 0.0) a.y = sn >= 0.0 ? 1.f : -1.f;
         else a.y = (float)det_clamp(4.0 * sn, -1.0, 1.0);
         a.x = cs > 0.8 ? 1.f : 0.f;
@@ -626,8 +623,8 @@ __device__ __forceinline__ float2 greedy_action_coop(int lane, int Z, float zx3,
         if (cr > best_cnt) { target = 2; }
         eligible = live && aux == 0.f && code != target;
     }
-    const double dx = 3.0 * (double)zx3 - px, dy = 3.0 * (double)zy3 - py;
-    double d2 = eligible ? dx * dx + dy * dy : __builtin_inf();
+    const double dx = __builtin_fma(3.0, (double)zx3, -px), dy = __builtin_fma(3.0, (double)zy3, -py);
+    double d2 = eligible ? __builtin_fma(dx, dx, dy * dy) : __builtin_inf();
     int idx = lane;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -639,11 +636,11 @@ __device__ __forceinline__ float2 greedy_action_coop(int lane, int Z, float zx3,
     }
     float2 a = make_float2(0.f, 0.f);
     const double bdx = __shfl(dx, idx), bdy = __shfl(dy, idx);
-    const double bd2 = bdx * bdx + bdy * bdy;
+    const double bd2 = __builtin_fma(bdx, bdx, bdy * bdy);
     if (d2 < __builtin_inf() && bd2 > 1e-18) {
         const double n = sqrt(bd2);
-        const double cs = (hx * bdx + hy * bdy) / n;
-        const double sn = (hx * bdy - hy * bdx) / n;
+        const double cs = __builtin_fma(hx, bdx, hy * bdy) / n;
+        const double sn = __builtin_fma(hx, bdy, -(hy * bdx)) / n;
         if (cs < 0.0) a.y = sn >= 0.0 ? 1.f : -1.f;
         else a.y = (float)det_clamp(4.0 * sn, -1.0, 1.0);
         a.x = cs > 0.8 ? 1.f : 0.f;
@@ -1173,11 +1170,13 @@ template <int ZT> struct RowDiv {
 
 // One reference row (TSP_env.py:31-35, TTSP_env.py:86-92, colour_match_env.py:75-80) from
 // its static entry + the env's per-step word; same values as make_entry() + expand_entry().
-template <int TASK, int ZT>
+// MAY_ZERO = false: the env wave has told the stream wave that no env of the tile is frozen this
+// step (always the case with auto-reset on), so the all-zero-row selects drop out.
+template <int TASK, int ZT, bool MAY_ZERO>
 __device__ __forceinline__ void expand_row(const DevParams &p, const typename StaticEnt<TASK>::type s, uint64_t d,
                                            const uint8_t *cd_env, int z, float *row)
 {
-    const bool zero = (d & kDynZero) != 0ull;
+    const bool zero = MAY_ZERO && (d & kDynZero) != 0ull;
     row[0] = zero ? 0.f : s.x;
     row[1] = zero ? 0.f : s.y;
     row[5] = zero ? 0.f : 0.25f;
@@ -1203,7 +1202,7 @@ __device__ __forceinline__ void expand_row(const DevParams &p, const typename St
 }
 
 // flush_entries() for the persistent kernel: rows come from static entries + per-env words
-template <int TASK, int ZT>
+template <int TASK, int ZT, bool MAY_ZERO>
 __device__ __forceinline__ void flush_static(const DevParams &p, const typename StaticEnt<TASK>::type *sent,
                                              const uint64_t *dynw, const uint8_t *cdb, float4 *stage, float *dst,
                                              int n_rows, int lane)
@@ -1218,13 +1217,18 @@ __device__ __forceinline__ void flush_static(const DevParams &p, const typename 
         for (int j = 0; j < RPC; ++j) {
             const int r = c * RPC + j;
             const int el = RowDiv<ZT>::div(r);
-            expand_row<TASK, ZT>(p, sent[r], dynw[el], cdb + el * ZB, r - el * ZT, v + j * F);
+            expand_row<TASK, ZT, MAY_ZERO>(p, sent[r], dynw[el], cdb + el * ZB, r - el * ZT, v + j * F);
         }
     };
+    // Full iterations (64 chunks = 64*G float4 each), software-pipelined: while the staged rows of
+    // iteration i make their round trip through the slab, the static entries / step words of
+    // iteration i+1 are fetched and expanded.  The LDS executes one wave's accesses in order, so the
+    // slab write of i+1 cannot overtake the slab read of i; the fences only stop the compiler.
     int c0 = 0;
-    for (; c0 + kWave <= n_chunks; c0 += kWave) {
-        float v[RPC * F];
-        expand_chunk(c0 + lane, v);
+    const int n_full = n_chunks / kWave;
+    float v[RPC * F];
+    if (n_full > 0) expand_chunk(lane, v);
+    for (int it = 0; it < n_full; ++it, c0 += kWave) {
 #pragma unroll
         for (int g = 0; g < G; ++g)
             stage[lane * G + g] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
@@ -1232,12 +1236,13 @@ __device__ __forceinline__ void flush_static(const DevParams &p, const typename 
         float4 t[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) t[g] = stage[g * kWave + lane];
+        wave_lds_fence();
+        if (it + 1 < n_full) expand_chunk(c0 + kWave + lane, v);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const v4f_t val = { t[g].x, t[g].y, t[g].z, t[g].w };
             __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + g * kWave + lane) * 16, 0, ZENV_STORE_AUX);
         }
-        wave_lds_fence();
     }
     if (c0 < n_chunks) {
         const int c = c0 + lane;
@@ -1266,7 +1271,7 @@ __device__ __forceinline__ void flush_static(const DevParams &p, const typename 
     if (r < n_rows) {
         float v[F];
         const int el = RowDiv<ZT>::div(r);
-        expand_row<TASK, ZT>(p, sent[r], dynw[el], cdb + el * ZB, r - el * ZT, v);
+        expand_row<TASK, ZT, MAY_ZERO>(p, sent[r], dynw[el], cdb + el * ZB, r - el * ZT, v);
         for (int f = 0; f < F; ++f) dst[(size_t)r * F + f] = v[f];
     }
 }
@@ -1317,8 +1322,8 @@ __device__ __forceinline__ float2 greedy_action_regs(const float4 *zp, const int
             if (TASK == ZENV_TASK_COLOUR_MATCH)
                 eligible = auxr[z] == 0 && (int)((colpack >> (2 * z)) & 3ull) != target_colour;
             else eligible = ((vis >> z) & 1u) == 0u;
-            const double dx = 3.0 * (double)x3 - px, dy = 3.0 * (double)y3 - py;
-            const double d2 = dx * dx + dy * dy;
+            const double dx = __builtin_fma(3.0, (double)x3, -px), dy = __builtin_fma(3.0, (double)y3, -py);
+            const double d2 = __builtin_fma(dx, dx, dy * dy);
             d2s[i] = __hiloint2double(eligible ? __double2hiint(d2) : 0x7FE00000, __double2loint(d2));
         }
         constexpr int ZM = (ZA + 1) / 2;
@@ -1349,12 +1354,12 @@ __device__ __forceinline__ float2 greedy_action_regs(const float4 *zp, const int
     }
     float2 a = make_float2(0.f, 0.f);
     if (mbest < 1e300) {
-        const double bdx = 3.0 * (double)bx - px, bdy = 3.0 * (double)by - py;
-        const double bd2 = bdx * bdx + bdy * bdy;
+        const double bdx = __builtin_fma(3.0, (double)bx, -px), bdy = __builtin_fma(3.0, (double)by, -py);
+        const double bd2 = __builtin_fma(bdx, bdx, bdy * bdy);
         if (bd2 > 1e-18) {
             const double n = sqrt(bd2);
-            const double cs = (hx * bdx + hy * bdy) / n;
-            const double sn = (hx * bdy - hy * bdx) / n;
+            const double cs = __builtin_fma(hx, bdx, hy * bdy) / n;
+            const double sn = __builtin_fma(hx, bdy, -(hy * bdx)) / n;
             if (cs < 0.0) a.y = sn >= 0.0 ? 1.f : -1.f;
             else a.y = (float)det_clamp(4.0 * sn, -1.0, 1.0);
             a.x = cs > 0.8 ? 1.f : 0.f;
@@ -1376,6 +1381,12 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
     constexpr int ZH = (ZT + 1) / 2;
     constexpr int ZB = (ZT + 3) & ~3;                            // cooldown bytes per env, padded
     constexpr bool kColour = TASK == ZENV_TASK_COLOUR_MATCH;
+    // Which wave wins the SIMD's issue slot when both are ready.  Measured in steady state: when the
+    // tile's row block is big (Z = 25: 38-45 KB per step) the stream wave is the slower one and its few
+    // VALU instructions sit on the critical path of its store stream, so it goes first (PointTSP-25
+    // 6.50 -> 6.27 us, TimedTSP-25 8.14 -> 7.82); with small row blocks the env wave's dependent
+    // instruction stream is the bottleneck and it goes first (PointTSP-15 5.08 -> 4.89).
+    constexpr bool kStreamFirst = ZT * F >= 120;
     const int lane = threadIdx.x & (kWave - 1);
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
     const int env0 = blockIdx.x * kWave;
@@ -1386,7 +1397,8 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
     float4 *stage = reinterpret_cast<float4 *>(sent + kWave * Z);        // [64*G] flush staging slab
     uint64_t *dynw = reinterpret_cast<uint64_t *>(stage + kWave * G);    // [2][64] per-step words
     uint32_t *cdw = reinterpret_cast<uint32_t *>(dynw + 2 * kWave);      // [2][64][ZB/4] cooldown bytes
-    int *ctr = reinterpret_cast<int *>(cdw + (kColour ? 2 * kWave * (ZB / 4) : 0));   // [0] published, [1] flushed
+    // [0] published, [1] flushed, [2 + b] "step word buffer b holds an all-zero env"
+    int *ctr = reinterpret_cast<int *>(cdw + (kColour ? 2 * kWave * (ZB / 4) : 0));
     const uint32_t full = (1u << Z) - 1u;
     const int n_blk = min(kWave, N - env0);
     const int n_rows = n_blk * Z;
@@ -1394,23 +1406,29 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
 
     if (role == 1) {
         // =================================================================== stream wave
+        if (kStreamFirst) __builtin_amdgcn_s_setprio(3);
         __syncthreads();   // static entries of the first step + cleared counters
         for (int t = 0; t < n_steps; ++t) {
+            if (t == (n_steps >> 1)) ZSTAMP(8);
             lds_ctr_wait(ctr + 0, t + 1);                 // published(t)
+            if (t == (n_steps >> 1)) ZSTAMP(9);
             const int b = t & 1;
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 1)   // diagnostic builds only: ZENV_EXP bit 0 drops the flush
-            flush_static<TASK, ZT>(p, sent, dynw + b * kWave, reinterpret_cast<const uint8_t *>(cdw + b * kWave * (ZB / 4)),
-                                   stage, tile_dst, n_rows, lane);
+            const uint8_t *cdb = reinterpret_cast<const uint8_t *>(cdw + b * kWave * (ZB / 4));
+            if (__builtin_amdgcn_readfirstlane(*(lds_vint *)(ctr + 2 + b)))   // some env of the tile is frozen
+                flush_static<TASK, ZT, true>(p, sent, dynw + b * kWave, cdb, stage, tile_dst, n_rows, lane);
+            else
+                flush_static<TASK, ZT, false>(p, sent, dynw + b * kWave, cdb, stage, tile_dst, n_rows, lane);
 #endif
             lds_ctr_set(ctr + 1, t + 1);                  // flushed(t)
+            if (t == (n_steps >> 1) - 1) ZSTAMP(11);
+            if (t == (n_steps >> 1)) ZSTAMP(10);
         }
         return;
     }
 
     // ======================================================================= env wave
-    // The env wave is one long dependent instruction stream and the stream wave mostly waits on the
-    // store path: let the env wave win the SIMD's issue slot when both are ready (8.5 -> 7.7 us).
-    __builtin_amdgcn_s_setprio(ZENV_EPRIO);
+    if (!kStreamFirst) __builtin_amdgcn_s_setprio(3);
     EnvRegs e;
     bool frozen = false;
     double ep_ret = 0.0;
@@ -1469,6 +1487,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
         int first = -1;
         uint64_t dword = kDynZero;
         float o[8];
+        if (t == (n_steps >> 1)) ZSTAMP(0);
         if (valid && frozen) {
             // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
             for (int i = 0; i < 8; ++i) o[i] = 0.f;
@@ -1556,7 +1575,9 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
             ep_ret = ep_ret + r;
             rew_out = (float)r;
             done_out = done ? 1 : 0;
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 8)
             p.visit_count[env] = kColour ? e.goal_dist : __popc(e.vis);
+#endif
             if (done) {
                 p.last_return[env] = ep_ret;
                 p.last_len[env] = k;
@@ -1566,6 +1587,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
             dword = kColour ? e.colpack
                             : ((uint64_t)e.vis | (TASK == ZENV_TASK_TIMED_TSP ? (uint64_t)(uint32_t)k << 32 : 0ull));
 
+            if (t == (n_steps >> 1)) ZSTAMP(1);
             if (!need_reset) {
                 // ---- Engine.step: ctrl = clip(action, ctrlrange); frameskip x mj_step; obs; next action
                 const double c0 = det_clamp((double)act.x, -1.0, 1.0);
@@ -1573,8 +1595,11 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 2)   // diagnostic: bit 1 drops the physics
                 for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
 #endif
+                if (t == (n_steps >> 1)) ZSTAMP(2);
                 emit_obs8(p, e, o);
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 8)   // diagnostic: bit 3 drops the env wave's per-step global stores
                 store_obs8(p, env, o);
+#endif
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 4)   // diagnostic: bit 2 drops the action source
                 if (pol.policy == ZENV_POLICY_UNIFORM)
                     act = uniform_action(polt.env_index0 + (uint64_t)env, polt.step_index, polt.seed);
@@ -1677,7 +1702,9 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
         }
 
         // ---- publish the step word of this step (its slot was last read by flush(t-2))
+        if (t == (n_steps >> 1)) ZSTAMP(3);
         if (t >= 2) lds_ctr_wait(ctr + 1, t - 1);
+        if (t == (n_steps >> 1)) ZSTAMP(4);
         {
             const int b = t & 1;
             dynw[b * kWave + lane] = dword;
@@ -1692,12 +1719,19 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 }
             }
         }
+        {
+            const int any_zero = __ballot((dword & kDynZero) != 0ull && valid) != 0ull;
+            if (lane == 0) *(lds_vint *)(ctr + 2 + (t & 1)) = any_zero;
+        }
         lds_ctr_set(ctr + 0, t + 1);                      // published(t)
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 8)
         if (valid) {
             p.reward[env] = rew_out;
             p.done_out[env] = done_out;
             p.goal_met[env] = goal_out;
         }
+#endif
+        if (t == (n_steps >> 1)) ZSTAMP(5);
     }
 
     // ---- the registers go back to the state arrays

@@ -12,6 +12,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* One correctly rounded multiply-add, spelled out wherever the arithmetic uses one: the GPU kernels
+ * issue the same v_fma_f64 in the same places, and -ffp-contract=off keeps the compiler from adding
+ * or removing any. */
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+
 /* =====================================================================================
  * numpy legacy RandomState  (reference call sites: TTSP_env.py:20-21,
  * colour_match_env.py:60-62, [UPSTREAM] Engine.reset: RandomState(self._seed))
@@ -136,7 +141,8 @@ double orc_rs_beta(orc_rs *rs, double a, double b)
 
 /* =====================================================================================
  * Deterministic sin/cos: Cody-Waite 3-term reduction + minimax kernels, only IEEE
- * + - * (no libm, no fma) so CPU and GPU produce identical bits.  Valid |x| < ~1e6.
+ * + - * and fma (each correctly rounded, written out explicitly; the compiler contracts
+ * nothing) so CPU and GPU produce identical bits.  Valid |x| < ~1e6.
  * ===================================================================================== */
 void orc_sincos(double x, double *s_out, double *c_out)
 {
@@ -153,20 +159,28 @@ void orc_sincos(double x, double *s_out, double *c_out)
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
 
-    double fn = (x * TWO_OVER_PI + MAGIC) - MAGIC;
-    double r = x - fn * P1;
-    r = r - fn * P2;
-    r = r - fn * P3;
-    r = r - fn * P3T;
+    double fn = FMA(x, TWO_OVER_PI, MAGIC) - MAGIC;
+    double r = FMA(-fn, P1, x);
+    r = FMA(-fn, P2, r);
+    r = FMA(-fn, P3, r);
+    r = FMA(-fn, P3T, r);
     int64_t n = (int64_t)fn;
 
     double z = r * r;
-    double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
-    double sn = r + r * (z * ps);
-    double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
+    double ps = FMA(z, S6, S5);
+    ps = FMA(z, ps, S4);
+    ps = FMA(z, ps, S3);
+    ps = FMA(z, ps, S2);
+    ps = FMA(z, ps, S1);
+    double sn = FMA(r, z * ps, r);
+    double pc = FMA(z, C6, C5);
+    pc = FMA(z, pc, C4);
+    pc = FMA(z, pc, C3);
+    pc = FMA(z, pc, C2);
+    pc = FMA(z, pc, C1);
     double hz = 0.5 * z;
     double w = 1.0 - hz;
-    double cs = w + (((1.0 - w) - hz) + (z * z) * pc);
+    double cs = w + FMA(z * z, pc, (1.0 - w) - hz);
 
     switch (n & 3) {
     case 0: *s_out = sn;  *c_out = cs;  break;
@@ -243,17 +257,17 @@ static void forward(orc_env *e)
 {
     /* [UPSTREAM] mj_kinematics for body "robot": slides act in the body's initial frame
      * (rotated by rot), hinge adds qpos[2]; velocities are Jacobian * qvel. */
-    double cr = e->bq0 * e->bq0 - e->bq3 * e->bq3;   /* mju_quat2Mat entries */
+    double cr = FMA(e->bq0, e->bq0, -(e->bq3 * e->bq3));   /* mju_quat2Mat entries */
     double sr = 2.0 * (e->bq0 * e->bq3);
-    e->xpos[0] = e->x0 + (cr * e->qpos[0] - sr * e->qpos[1]);
-    e->xpos[1] = e->y0 + (sr * e->qpos[0] + cr * e->qpos[1]);
-    e->xvelp[0] = cr * e->qvel[0] - sr * e->qvel[1];
-    e->xvelp[1] = sr * e->qvel[0] + cr * e->qvel[1];
+    e->xpos[0] = FMA(cr, e->qpos[0], FMA(-sr, e->qpos[1], e->x0));
+    e->xpos[1] = FMA(sr, e->qpos[0], FMA(cr, e->qpos[1], e->y0));
+    e->xvelp[0] = FMA(cr, e->qvel[0], -(sr * e->qvel[1]));
+    e->xvelp[1] = FMA(sr, e->qvel[0], cr * e->qvel[1]);
     e->xvelr = e->qvel[2];
     double hs, hc;
     orc_sincos(0.5 * e->qpos[2], &hs, &hc);
-    e->xquat0 = e->bq0 * hc - e->bq3 * hs;
-    e->xquat3 = e->bq0 * hs + e->bq3 * hc;
+    e->xquat0 = FMA(e->bq0, hc, -(e->bq3 * hs));
+    e->xquat3 = FMA(e->bq0, hs, e->bq3 * hc);
 }
 
 static int sample_layout(orc_env *e, orc_rs *rs)
@@ -358,25 +372,25 @@ static void mj_substep(orc_env *e, const double ctrl[2])
     double w2 = v[2] * v[2];
     /* actuators: motor on site (gear .3 0 0 0 0 0); velocity servo on hinge (kv, gear .3) */
     double f0 = clampd(ctrl[0], -F, F);
-    double f1 = clampd(c->vel_kv * ctrl[1] - c->vel_kv * (g * v[2]), -F, F);
+    double f1 = clampd(FMA(-c->vel_kv, g * v[2], c->vel_kv * ctrl[1]), -F, F);
     double gf0 = g * f0;
     /* qfrc = passive(-b v) - bias(centrifugal of the offset COM) + actuator */
-    double rhs0 = (gf0 * k + mck * w2) - c->damping[0] * v[0];
-    double rhs1 = (gf0 * s + mcs * w2) - c->damping[1] * v[1];
-    double rhs2 = g * f1 - c->damping[2] * v[2];
+    double rhs0 = FMA(-c->damping[0], v[0], FMA(mck, w2, gf0 * k));
+    double rhs1 = FMA(-c->damping[1], v[1], FMA(mcs, w2, gf0 * s));
+    double rhs2 = FMA(-c->damping[2], v[2], g * f1);
     /* (M + h diag(b)) a = qfrc, M = [[m,0,-mcs],[0,m,mck],[-mcs,mck,I0]]  (implicit-damping Euler) */
     double t0 = rhs0 * inv00, t1 = rhs1 * inv11;
-    double den = (A22 - (mcs * mcs) * inv00) - (mck * mck) * inv11;
-    double num = (rhs2 + mcs * t0) - mck * t1;
+    double den = FMA(-(mck * mck), inv11, FMA(-(mcs * mcs), inv00, A22));
+    double num = FMA(-mck, t1, FMA(mcs, t0, rhs2));
     double a2 = num / den;
-    double a0 = (rhs0 + mcs * a2) * inv00;
-    double a1 = (rhs1 - mck * a2) * inv11;
-    v[0] = v[0] + h * a0;
-    v[1] = v[1] + h * a1;
-    v[2] = v[2] + h * a2;
-    q[0] = q[0] + h * v[0];
-    q[1] = q[1] + h * v[1];
-    q[2] = q[2] + h * v[2];
+    double a0 = FMA(mcs, a2, rhs0) * inv00;
+    double a1 = FMA(-mck, a2, rhs1) * inv11;
+    v[0] = FMA(h, a0, v[0]);
+    v[1] = FMA(h, a1, v[1]);
+    v[2] = FMA(h, a2, v[2]);
+    q[0] = FMA(h, v[0], q[0]);
+    q[1] = FMA(h, v[1], q[1]);
+    q[2] = FMA(h, v[2], q[2]);
 }
 
 int orc_step(orc_env *e, const float action[2], double *reward, int *done, int *goal_met)
@@ -533,7 +547,7 @@ void orc_policy(int policy, const orc_config *cfg, const float *o, const float *
         return;
     }
     /* greedy: steer to the nearest eligible zone */
-    double px = 3.0 * (double)o[1], py = 3.0 * (double)o[2];
+    double px = 3.0 * (double)o[1], py = 3.0 * (double)o[2];   /* exact: 3 * float has <= 26 bits */
     double hx = (double)o[3], hy = (double)o[4];
     int target_colour = -1;
     if (cfg->task == ORC_TASK_COLOUR) {
@@ -559,15 +573,15 @@ void orc_policy(int policy, const orc_config *cfg, const float *o, const float *
             eligible = row[2] == 0.f;
         }
         if (!eligible) continue;
-        double dx = 3.0 * (double)row[0] - px, dy = 3.0 * (double)row[1] - py;
-        double d2 = dx * dx + dy * dy;
+        double dx = FMA(3.0, (double)row[0], -px), dy = FMA(3.0, (double)row[1], -py);
+        double d2 = FMA(dx, dx, dy * dy);
         if (best < 0 || d2 < bd2) { best = z; bd2 = d2; bdx = dx; bdy = dy; }
     }
     float a0 = 0.f, a1 = 0.f;
     if (best >= 0 && bd2 > 1e-18) {
         double n = sqrt(bd2);
-        double cs = (hx * bdx + hy * bdy) / n;
-        double sn = (hx * bdy - hy * bdx) / n;
+        double cs = FMA(hx, bdx, hy * bdy) / n;
+        double sn = FMA(hx, bdy, -(hy * bdx)) / n;
         if (cs < 0.0) a1 = sn >= 0.0 ? 1.f : -1.f;
         else a1 = (float)clampd(4.0 * sn, -1.0, 1.0);
         a0 = cs > 0.8 ? 1.f : 0.f;

@@ -11,10 +11,17 @@ subprocess.run([B._hipcc()] + B.FLAGS + flags + ["-o", so] + [os.path.join(B.CSR
 import combinatorial_rl_tasks_amd._native as nat
 nat.LIB_PATH = so
 import combinatorial_rl_tasks_amd as Z
-task, zones, keep = {"tsp": (0, 25, .4), "timed": (1, 25, .4), "colour": (2, 6, .55), "tsp15": (0, 15, .55)}[wl[0] if wl else "tsp"]
+wl0 = [w for w in wl if w != "steady"]
+task, zones, keep = {"tsp": (0, 25, .4), "timed": (1, 25, .4), "colour": (2, 6, .55), "tsp15": (0, 15, .55)}[wl0[0] if wl0 else "tsp"]
 n = 65536
 cfg = Z.default_config(task, zones, zones_keepout=keep)
 env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n); env.reset()
-env.rollout(30, Z.POLICY_GREEDY)
-tot, k = env.rollout(300, Z.POLICY_GREEDY, time_step_kernel=True)
-print(flags, wl, "kernel avg us %.2f  loop us/step %.2f" % (k * 1e3, tot / 300 * 1e3))
+if "steady" in wl:      # past the power controller's transient, envs desynchronised
+    env.build_bank(1, 4 * n, n_threads=16); env.schedule_sequential(stride=n); env.reset()
+    env.rollout(6000, Z.POLICY_GREEDY)
+    T = 4096
+else:
+    env.rollout(30, Z.POLICY_GREEDY)
+    T = 300
+tot, k = env.rollout(T, Z.POLICY_GREEDY, time_step_kernel=True)
+print(flags, wl, "kernel avg us %.2f  loop us/step %.2f" % (k * 1e3, tot / T * 1e3))
