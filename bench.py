@@ -3,19 +3,22 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch: ONE step-kernel launch consumes the
-(N_env, 2) action buffer and advances all N_env = 65 536 envs (10 MuJoCo substeps, visit
-logic, reward/termination, fused auto-reset, obs emit); the scripted closed-loop policy
-pi_greedy(obs) that fills the action buffer for the next step runs inside the same launch
-(--unfused: as its own kernel before every step; identical results).  All inputs (env
-state, layout bank) are resident in HBM before the timed region.
+One "step" = one pass of the hot path over one batch: every one of the N_env = 65 536 envs
+takes one env.step() (10 MuJoCo substeps, visit logic, reward/termination, fused auto-reset,
+obs emit) and all of its outputs (obs, zone_obs, reward, done, goal_met) are written to HBM.
+The scripted closed-loop policy pi_greedy(obs) that produces the next action runs on the
+device.  --mode persistent (default): one launch of k_rollout_lane covers up to 256 steps with
+the env state in registers; --mode per_step: one k_step_lane launch per step (the kernel of
+step t also emits a_{t+1}); --mode unfused: a policy kernel + a step kernel per step.  The
+results are bit-identical in all modes.  All inputs (env state, layout bank) are resident in
+HBM before the timed region.
 
 N > 1: one process per GPU (torch.distributed, backend "nccl" == RCCL).  Envs shard
 trivially: rank r owns global envs [r*65536, (r+1)*65536); there is no collective on the
 step path; after the rollout the per-env episodic returns are all-gathered over xGMI.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
-dominant kernel (k_step_lane) and `cpu_baseline` (the float64 C oracle on the host cores).
+dominant kernel (k_rollout_lane, or k_step_lane with --mode per_step) and `cpu_baseline` (the float64 C oracle on the host cores).
 """
 import argparse
 import json
@@ -43,6 +46,7 @@ WORKLOADS = {
 }
 
 
+SETTLE_STEPS = 6000     # untimed steps (settle + warmup) before the timed region, ~40 ms of GPU time
 EPISODES_PER_ENV = 4   # depth of the map bank per env; the schedule wraps around it (the oracle too)
 
 
@@ -80,9 +84,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8000)
-    ap.add_argument("--warmup", type=int, default=6000,
-                    help="untimed steps first; the default is long enough (~40 ms of GPU time) for the power "
-                         "controller to settle -- it dips to ~1.5 GHz 4-15 ms after load arrives (profiles/r01)")
+    ap.add_argument("--warmup", type=int, default=1000, help="untimed steps right before the timed ones")
+    ap.add_argument("--no-settle", action="store_true",
+                    help="skip the untimed clock-settling steps that precede the warm-up (see SETTLE_STEPS)")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--workload", default="PointTSP-25", choices=sorted(WORKLOADS))
     ap.add_argument("--policy", default="greedy", choices=["greedy", "uniform"])
@@ -142,8 +146,13 @@ def main():
     shard.build_bank(env, episodes_per_env, n_threads=min(32, usable_cores()))
     t_bank = time.perf_counter() - t_bank
     env.reset()
-    env.rollout(args.warmup, policy, policy_seed=0x5EED, env_index0=shard.env_index0,
-                mode=args.mode)
+    # Untimed: first let the power controller settle (it dips to ~1.5 GHz 4-15 ms after load arrives and
+    # is steady after ~20 ms, profiles/r01/clock_per_launch.txt) -- enough steps that settle + warmup
+    # is at least SETTLE_STEPS -- then the W warm-up steps, then the K timed steps, back to back.
+    args.settle = 0 if args.no_settle else max(0, SETTLE_STEPS - args.warmup)
+    for k in (args.settle, args.warmup):
+        if k > 0:
+            env.rollout(k, policy, policy_seed=0x5EED, env_index0=shard.env_index0, mode=args.mode)
 
     def fence():
         env.sync()
@@ -217,7 +226,7 @@ def main():
                        "parallelism": f"env-shard x{world}, all-gather(ep_return) after rollout"},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "aux": {"hip_event_ms_total": round(ms_total, 3), "bank_build_s": round(t_bank, 2),
+            "aux": {"settle_steps_untimed": args.settle, "hip_event_ms_total": round(ms_total, 3), "bank_build_s": round(t_bank, 2),
                     "episodes_finished_rank0": int(ep.sum()),
                     "mean_last_return_all_ranks": float(np.mean(returns[returns != 0]))
                     if (returns != 0).any() else 0.0,
@@ -270,7 +279,7 @@ def parity_spot_check(env, cfg, shard, args, policy):
         from oracle import oracle as O
         from tests.helpers import oracle_config_from
         n = 16
-        T = args.warmup + args.steps
+        T = args.settle + args.warmup + args.steps
         ref = O.rollout(oracle_config_from(O, cfg), shard.first_seeds()[:n], T, policy,
                         seed_stride=shard.seed_stride, policy_seed=0x5EED,
                         env_index0=shard.env_index0, n_threads=4, seed_period=EPISODES_PER_ENV)
