@@ -54,7 +54,8 @@ struct zenv {
     zenv_config cfg{};
     int n_env = 0;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // the stream work is enqueued on
+    hipStream_t own_stream = nullptr;   // created with the handle; `stream` unless zenv_set_stream
     DevParams p{};
     std::vector<Alloc> allocs;
     void *bank_mem[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -320,7 +321,8 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
     want(h, p.done_out, N, true); want(h, p.goal_met, N, true);
     want(h, p.dbg, 16 * ((N + 63) / 64), false);
 
-    hipError_t err = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    hipError_t err = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    h->stream = h->own_stream;
     if (err != hipSuccess) {
         delete h;
         return fail(ZENV_E_HIP, "hipStreamCreate: %s", hipGetErrorString(err));
@@ -354,8 +356,18 @@ extern "C" int zenv_destroy(zenv_t *h)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_set_stream(zenv_t *h, void *hip_stream)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
     return ZENV_OK;
 }
 

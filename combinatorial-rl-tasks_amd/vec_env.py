@@ -197,6 +197,11 @@ class ZoneVecEnv:
     def sync(self):
         check(lib().zenv_sync(self._h))
 
+    def set_stream(self, hip_stream=None):
+        """Enqueue all further work on the caller's HIP stream (an integer hipStream_t, e.g.
+        ``torch.cuda.current_stream().cuda_stream``); None = the handle's own stream again."""
+        check(lib().zenv_set_stream(self._h, None if not hip_stream else C.c_void_p(int(hip_stream))))
+
     @property
     def step_count(self):
         return lib().zenv_step_count(self._h)

@@ -175,6 +175,11 @@ int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device);
 int zenv_device_ptr(zenv_t *h, int field, void **ptr);  /* zero-copy for GPU consumers */
 int64_t zenv_field_bytes(const zenv_t *h, int field);
 int zenv_sync(zenv_t *h);
+/* Enqueue everything from now on onto the caller's HIP stream (hipStream_t passed as void*; NULL =
+ * back to the handle's own stream).  The handle first drains the stream it was using.  This is how
+ * a device-resident policy (base.py:139-145 without the .cpu().numpy() round trip) shares one
+ * stream with the env: step, read the obs buffers of zenv_device_ptr(), compute actions, step. */
+int zenv_set_stream(zenv_t *h, void *hip_stream);
 int64_t zenv_step_count(const zenv_t *h);   /* batched steps executed so far */
 
 /* ---- state snapshot (tests / checkpointing; the reference never checkpoints env state) ---- */

@@ -21,6 +21,12 @@ def oracle_mod():
 
 @pytest.fixture(scope="session")
 def zenv_mod():
+    # torch (used by the interop / sharding tests) bundles its own libamdhip64: it must be the first
+    # HIP runtime loaded so that libzenv_hip.so binds to the same copy (streams and pointers are shared)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     import __graft_entry__ as g
     g.build()
     import combinatorial_rl_tasks_amd as Z

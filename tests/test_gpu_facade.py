@@ -155,3 +155,44 @@ def test_evaluate_protocol(zenv_mod, oracle_mod):
             t += 1
         assert got[m, 0] == total and out["length"][m][0] == t and out["goal_met"][m][0] == g
     assert ref["episodes"].min() >= 1
+
+
+def test_torch_policy_closed_loop_without_host_copies(zenv_mod, oracle_mod):
+    """SURVEY 8(f) row 1, the plumbing half: a device-resident torch policy consumes the env's obs
+    buffers as aliasing tensors and feeds its action tensor straight to zenv_step on torch's stream
+    (replaces base.py:139-145's .cpu().numpy() round trip).  The same actions replayed through the
+    host path and through the oracle give the same observations."""
+    torch = pytest.importorskip("torch")
+    from combinatorial_rl_tasks_amd.torch_interop import TorchZoneEnv
+    Z, O = zenv_mod, oracle_mod
+    n, T = 257, 60
+    cfg = Z.config_for_id("PointTTSP-v0", num_steps=40)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(7, n)
+    tenv = TorchZoneEnv(env)
+    obs = tenv.reset()
+    assert obs["obs"].data_ptr() == env.device_ptr(Z.F_OBS) and obs["zone_obs"].shape == (n, 15, 7)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w1 = torch.randn(8 + 7, 32, device="cuda", generator=g) * 0.5
+    w2 = torch.randn(8 + 32, 2, device="cuda", generator=g) * 0.5
+    ob = OracleBatch(O, _oracle_for(O, "PointTTSP-v0", Z, num_steps=40), range(7, 7 + n))
+    ob.reset()
+    actions_log = []
+    for t in range(T):
+        # a ZoneEnvModel-shaped policy (env_model.py:70-79): per-zone MLP on [obs, zone row], mean-pool, head
+        x = torch.cat([obs["obs"][:, None, :].expand(n, 15, 8), obs["zone_obs"]], dim=-1)
+        emb = torch.relu(x @ w1).mean(dim=1)
+        a = torch.tanh(torch.cat([obs["obs"], emb], dim=-1) @ w2).contiguous()
+        actions_log.append(a)                       # stays on the device; no sync in the loop
+        obs, reward, done, goal = tenv.step(a)
+    torch.cuda.synchronize()
+    o_dev, zo_dev = obs["obs"].cpu().numpy(), obs["zone_obs"].cpu().numpy()
+    for a in actions_log:
+        ob.step(a.cpu().numpy())
+    o_ref, zo_ref = ob.obs()
+    assert np.array_equal(o_dev, o_ref) and np.array_equal(zo_dev, zo_ref)
+    assert tenv.episodes.sum().item() > n          # TimedTSP with num_steps 40: everyone restarted
+    env.set_stream(None)
+    o_host, zo_host = env.observations()
+    assert np.array_equal(o_host, o_ref) and np.array_equal(zo_host, zo_ref)
+    env.close()
