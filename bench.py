@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="run the stand-alone policy kernel before every step instead of the fused action source")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mlp", action="store_true",
+                    help="skip the side measurement with the reference's actor network as the on-device policy")
     ap.add_argument("--event-stride", type=int, default=16,
                     help="time every k-th step-kernel dispatch with begin/end HIP events (each pair costs "
                          "~6 us of launch path, so timing all of them would distort `value`)")
@@ -230,7 +232,8 @@ def main():
                     "episodes_finished_rank0": int(ep.sum()),
                     "mean_last_return_all_ranks": float(np.mean(returns[returns != 0]))
                     if (returns != 0).any() else 0.0,
-                    "parity_spot_check": parity_spot_check(env, cfg, shard, args, policy)},
+                    "parity_spot_check": parity_spot_check(env, cfg, shard, args, policy),
+                    "mlp_policy": None if (args.no_mlp or distributed) else mlp_policy_rate(env, zones)},
         }
         print(json.dumps(out), flush=True)
     env.close()
@@ -270,6 +273,38 @@ def cpu_baseline(cfg, task, zones, keepout, policy):
             "kind": "port",
             "sample": f"first {n} envs x {T} steps of the same workload, OpenMP over envs, "
                       f"{dt:.2f}s wall"}
+
+
+def mlp_policy_rate(env, zones, steps=300):
+    """Side measurement (never `value`): the same envs stepped with the reference's actor network
+    (ZoneEnvModel + PolicyNetwork, h = 185, random weights) as the on-device policy -- two bf16 MFMA
+    kernels + the per-step env kernel per step."""
+    try:
+        import combinatorial_rl_tasks_amd as Z
+        F, h = env.zone_feat, 185
+        rs = np.random.RandomState(0)
+
+        def lin(n_out, n_in):
+            w = rs.standard_normal((n_out, n_in)).astype(np.float32)
+            return w / np.sqrt((w * w).sum(1, keepdims=True)), (0.1 * rs.standard_normal(n_out)).astype(np.float32)
+        t = {}
+        for name, shape in (("zone", (h, 8 + F)), ("zone2", (h, h)), ("zone3", (h, h)), ("comb", (h, 8 + h)),
+                            ("enc", (h, h)), ("mu", (2, h)), ("std", (2, h))):
+            w, b = lin(*shape)
+            key = {"zone": ("zone_w1", "zone_b1"), "zone2": ("zone_w2", "zone_b2"), "zone3": ("zone_w3", "zone_b3")}.get(
+                name, (name + "_w", name + "_b"))
+            t[key[0]], t[key[1]] = w, b
+        env.load_mlp(t)
+        env.rollout(steps, Z.POLICY_MLP_SAMPLE, policy_seed=1)
+        ms, _ = env.rollout(steps, Z.POLICY_MLP_SAMPLE, policy_seed=1)
+        n = env.num_envs
+        flop = n * (zones * 2 * ((8 + F) * h + h * h) + 2 * (h * h + (8 + h) * h + h * h + 4 * h))
+        us = ms / steps * 1e3
+        return {"us_per_step": round(us, 1), "env_steps_per_s": round(n * steps / (ms * 1e-3), 1),
+                "network_gflop_per_step": round(flop / 1e9, 1), "dtype": "bf16 MFMA, f32 accumulate",
+                "network_tflops_incl_env_step": round(flop / (us * 1e-6) / 1e12, 1), "mfma_peak_tflops": 2500.0}
+    except Exception as ex:  # the bench line must still print
+        return f"error: {ex}"
 
 
 def parity_spot_check(env, cfg, shard, args, policy):

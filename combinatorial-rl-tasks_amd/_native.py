@@ -15,7 +15,7 @@ MAX_ZONES = 32
 OBS_DIM = 8
 
 TASK_TSP, TASK_TIMED_TSP, TASK_COLOUR_MATCH = 0, 1, 2
-POLICY_UNIFORM, POLICY_GREEDY = 0, 1
+POLICY_UNIFORM, POLICY_GREEDY, POLICY_MLP_MEAN, POLICY_MLP_SAMPLE = 0, 1, 2, 3
 KERNEL_LANE_PER_ENV, KERNEL_WAVE_PER_ENV = 0, 1
 ROLLOUT_UNFUSED = 1
 ROLLOUT_PER_STEP = 2
@@ -24,7 +24,16 @@ ROLLOUT_CHUNK = 256
 E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE = -1, -2, -3, -4, -5
 
 (F_OBS, F_ZONE_OBS, F_REWARD, F_DONE, F_GOAL_MET, F_EP_RETURN, F_EP_LEN, F_LAST_RETURN,
- F_LAST_LEN, F_EPISODES, F_VISIT_COUNT, F_SEED, F_ACTIONS) = range(13)
+ F_LAST_LEN, F_EPISODES, F_VISIT_COUNT, F_SEED, F_ACTIONS, F_POLICY_MU, F_POLICY_STD) = range(15)
+
+
+MLP_TENSORS = ("zone_w1", "zone_b1", "zone_w2", "zone_b2", "zone_w3", "zone_b3", "comb_w", "comb_b",
+               "enc_w", "enc_b", "mu_w", "mu_b", "std_w", "std_b")
+
+
+class MlpWeights(C.Structure):
+    """struct zenv_mlp_weights (include/zenv.h): host float32 tensors in state_dict layout."""
+    _fields_ = [("h_dim", C.c_int32), ("reserved", C.c_int32)] + [(n, C.c_void_p) for n in MLP_TENSORS]
 
 
 class ZenvError(RuntimeError):
@@ -79,6 +88,8 @@ _PROTOTYPES = {
     "zenv_policy": (C.c_int, [_H, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "zenv_rollout": (C.c_int, [_H, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "zenv_mlp_load": (C.c_int, [_H, C.c_void_p]),
+    "zenv_mlp_forward": (C.c_int, [_H]),
     "zenv_get": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int]),
     "zenv_device_ptr": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),
     "zenv_field_bytes": (C.c_int64, [_H, C.c_int]),

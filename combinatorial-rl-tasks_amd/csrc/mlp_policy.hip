@@ -1,0 +1,497 @@
+// mlp_policy.hip -- ZoneEnvModel + actor forward on bf16 MFMA (gfx950), SURVEY.md 8(f) row 1.
+//
+// Reference (all float32 torch):  main/src/env_model.py:48-79
+//     zone_net_:  Linear(8+F, h) ReLU Linear(h, h) ReLU Linear(h, h)   on every [obs, zone row]
+//     zone_emb = zone_net_(...).sum(dim=1) / n_zones ;  combine_net_: Linear(8+h, h) on [obs, zone_emb]
+// main/src/flat_model.py:24-37 + policy_network.py:12-53 (Box action space):
+//     enc_: Linear(h, h) ReLU ;  mu = 2 (sigmoid(mu_(x)) - 0.5) ;  std = sigmoid(std_(x)) + 1e-3
+// h = 185 (utils/agent.py:17), padded here to 192 = 6 MFMA tiles.
+//
+// Formulation.  v_mfma_f32_32x32x16_bf16 leaves a 32x32 result with its COLUMN on the lane and its
+// ROWS in the 16 accumulator registers, and such a tile can feed the next MFMA directly -- as the B
+// operand of  Y = A X  or the A operand of  Z = X^T B  -- when the other operand's k order follows the
+// accumulator order (cdna_hip_programming.md section 3, "an accumulator tile as the next MFMA's
+// operand").  So activations never leave registers:
+//   kernel 1 (k_mlp_zone), one wave per 64 envs, batch = the envs' 64 Z zone rows, 32 per tile:
+//     X1   = relu(W1 X0)            features in registers, zone row on the lane     (6 MFMA / tile)
+//     H2^T = relu(X1^T W2^T)        zone row in registers, feature on the lane      (72 MFMA / tile)
+//     mean over the zone rows of an env = one more product P += S relu(H2^T) with a 0/1 selection
+//     matrix S[env slot][zone row] built in registers (12 MFMA / tile), accumulated per 32 envs.
+//     The third zone_net_ layer has no activation, so the mean commutes with it and moves into
+//     kernel 2 -- 25x fewer rows for that layer (float reassociation only).
+//   kernel 2 (k_mlp_head), one wave per 64 envs, batch = envs:  e3 = W3 mean(H2); c = Wc [e3; obs];
+//     a = relu(Wa c); [mu; std] = Wh a  -- a chain of Y = A X products, each taking the previous
+//     accumulator as its B operand.
+// Biases ride in a padded k slot: a constant-1 feature is carried through every layer (slot 15 of the
+// 16-wide input, feature h of every hidden layer), and the bias is that slot's weight column.
+// W2 / W1 fragments live in LDS (78 KB per workgroup); kernel 2 stages one layer's fragments at a time.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "mlp_policy.hpp"
+
+namespace zenvk {
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+constexpr int kWave = 64;
+constexpr int NT = kMlpNT, KS = kMlpKS, HP = kMlpHP;
+
+__device__ __forceinline__ bf16x8 as_frag(const uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f32x16 mfma(const bf16x8 a, const bf16x8 b, const f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16()
+{
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+// A 32x32 accumulator tile provides two k-steps of the next product: registers 8s..8s+7 -> step s.
+// ReLU is applied AFTER the conversion, on the packed bf16 pairs, as a signed 16-bit max with 0
+// (v_pk_max_i16): a bf16 is negative exactly when its bit pattern is a negative int16, and rounding
+// to bf16 never changes the sign -- one instruction per two elements instead of two per element.
+typedef __attribute__((__vector_size__(8 * sizeof(short)))) short s16x8;
+__device__ __forceinline__ bf16x8 relu_bf16(const bf16x8 f)
+{
+    const s16x8 v = __builtin_bit_cast(s16x8, f);
+    const s16x8 z = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(v, z));
+}
+__device__ __forceinline__ void acc_to_frags(const f32x16 &acc, bool relu, bf16x8 &f0, bf16x8 &f1)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f0[j] = (__bf16)acc[j];
+        f1[j] = (__bf16)acc[8 + j];
+    }
+    if (relu) {
+        f0 = relu_bf16(f0);
+        f1 = relu_bf16(f1);
+    }
+}
+__device__ __forceinline__ bf16x8 frag_from_floats(const float4 lo, const float4 hi)
+{
+    bf16x8 f;
+    f[0] = (__bf16)lo.x; f[1] = (__bf16)lo.y; f[2] = (__bf16)lo.z; f[3] = (__bf16)lo.w;
+    f[4] = (__bf16)hi.x; f[5] = (__bf16)hi.y; f[6] = (__bf16)hi.z; f[7] = (__bf16)hi.w;
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------ kernel 1
+// raw inputs of one 32-row tile as a lane holds them: lane half 0 the env's obs, half 1 the zone row
+template <int F>
+struct RawRow {
+    float v[8];
+    bool valid;
+};
+template <int ZT, int F>
+__device__ __forceinline__ RawRow<F> load_row(const float *__restrict__ obs, const float *__restrict__ zrows, int env0,
+                                               int Z, int row, int n_rows, int h)
+{
+    RawRow<F> x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x.v[j] = 0.f;
+    x.valid = row < n_rows;
+    if (x.valid) {
+        if (h == 0) {
+            const float4 *o = reinterpret_cast<const float4 *>(obs + (size_t)(env0 + row / Z) * 8);
+            const float4 a = o[0], b = o[1];
+            x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
+            x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+        } else {
+            const float *zr = zrows + (size_t)row * F;
+#pragma unroll
+            for (int f = 0; f < F; ++f) x.v[f] = zr[f];
+            x.v[7] = 1.0f;   // k = 15: the bias slot
+        }
+    }
+    return x;
+}
+
+template <int ZT, int F>
+__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, const float *__restrict__ zone_obs,
+                float *__restrict__ pooled)
+{
+    extern __shared__ uint4 lds[];
+    uint4 *w2s = lds;                       // [NT*KS][64]
+    uint4 *w1s = lds + NT * KS * kWave;     // [NT][64]
+    for (int i = threadIdx.x; i < NT * KS * kWave; i += 4 * kWave) w2s[i] = reinterpret_cast<const uint4 *>(img.w2)[i];
+    for (int i = threadIdx.x; i < NT * kWave; i += 4 * kWave) w1s[i] = reinterpret_cast<const uint4 *>(img.w1)[i];
+    __syncthreads();
+
+    const int Z = ZT > 0 ? ZT : Z_rt;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int env0 = (blockIdx.x * 4 + wave) * kWave;
+    if (env0 >= N) return;
+    const int n_env = min(kWave, N - env0), n_rows = n_env * Z;
+    const float inv_z = 1.0f / (float)Z;
+    const float *zrows = zone_obs + (size_t)env0 * Z * F;
+    const __bf16 one = (__bf16)1.0f, nil = (__bf16)0.0f;
+
+    // two groups of 32 envs: a group's zone rows all pool into ONE 32-env accumulator tile set
+    for (int e_base = 0; e_base < n_env; e_base += 32) {
+        const int g_lo = e_base * Z, g_hi = min(e_base + 32, n_env) * Z;     // the group's rows
+        f32x16 pool[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) pool[n] = zero16();
+        RawRow<F> nxt[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) nxt[t] = load_row<ZT, F>(obs, zrows, env0, Z, g_lo + 32 * t + r, n_rows, h);
+
+        for (int b0 = g_lo; b0 < g_hi; b0 += 2 * 32) {
+            bf16x8 xa[2][KS];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bf16x8 x0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x0[j] = (__bf16)nxt[t].v[j];
+                // the next pair's rows are fetched while this pair is in the matrix pipe
+                nxt[t] = load_row<ZT, F>(obs, zrows, env0, Z, b0 + 64 + 32 * t + r, min(n_rows, g_hi + 32), h);
+                // ---- layer 1: X1 = relu(W1 X0), features in registers
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    const f32x16 acc1 = mfma(as_frag(w1s[m * kWave + lane]), x0, zero16());
+                    acc_to_frags(acc1, true, xa[t][2 * m], xa[t][2 * m + 1]);
+                }
+            }
+            // ---- mean over an env's rows = one more product: P += S relu(H2^T), S[env slot][row] = 1 when
+            // the row belongs to env e_base + slot.  Lane (slot r, half h) element j of k-step s is tile row
+            // 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the accumulator order of H2^T.
+            bf16x8 ind[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int lo = (e_base + r) * Z - (b0 + 32 * t);   // first row of this lane's env, tile-relative
+#pragma unroll
+                for (int sgm = 0; sgm < 2; ++sgm)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int pos = 16 * sgm + 8 * (j >> 2) + 4 * h + (j & 3);
+                        ind[t][sgm][j] = ((unsigned)(pos - lo) < (unsigned)Z) ? one : nil;
+                    }
+            }
+            // ---- layer 2: H2^T = relu(X1^T W2^T), zone row in registers, feature on the lane; then the pooling.
+            // Software-pipelined over the output tiles: region n holds the 24 MFMAs of tile n, the ReLU / bf16
+            // conversion + pooling MFMAs of tile n-1 (independent of them: the scheduler interleaves the
+            // VALU work into the matrix pipe's shadow) and the LDS reads of tile n+1's fragments.
+            bf16x8 wf[NT][KS];              // statically indexed: only two tiles' worth is ever live
+            f32x16 acc2[NT][2];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) wf[0][kk] = as_frag(w2s[kk * kWave + lane]);
+#pragma unroll
+            for (int n = 0; n <= NT; ++n) {
+                if (n < NT) {
+                    if (n + 1 < NT) {
+#pragma unroll
+                        for (int kk = 0; kk < KS; ++kk) wf[n + 1][kk] = as_frag(w2s[((n + 1) * KS + kk) * kWave + lane]);
+                    }
+                    acc2[n][0] = zero16();
+                    acc2[n][1] = zero16();
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) {
+                        acc2[n][0] = mfma(xa[0][kk], wf[n][kk], acc2[n][0]);
+                        acc2[n][1] = mfma(xa[1][kk], wf[n][kk], acc2[n][1]);
+                    }
+                }
+                if (n > 0) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        bf16x8 f0, f1;
+                        acc_to_frags(acc2[n - 1][t], true, f0, f1);
+                        pool[n - 1] = mfma(ind[t][0], f0, pool[n - 1]);
+                        pool[n - 1] = mfma(ind[t][1], f1, pool[n - 1]);
+                    }
+                }
+                // region boundary: without it the scheduler hoists every later tile's fragment reads to the top
+                // (512 VGPRs + 128 spilled)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- the group's means: accumulator register i of lane half h is env slot (i&3) + 8 (i>>2) + 4 h
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = e_base + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (e < n_env) pooled[(size_t)(env0 + e) * HP + 32 * n + r] = pool[n][i] * inv_z;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ kernel 2
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// One layer's fragments, global -> LDS, by the whole workgroup
+__device__ __forceinline__ void stage_image(uint4 *dst, const void *src, int n_frags)
+{
+    __syncthreads();    // everyone is done with what the buffer held
+    for (int i = threadIdx.x; i < n_frags * kWave; i += 4 * kWave) dst[i] = reinterpret_cast<const uint4 *>(src)[i];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const float *__restrict__ pooled,
+                float *__restrict__ mu, float *__restrict__ stdv)
+{
+    extern __shared__ uint4 wl[];           // one layer's fragments at a time: up to NT*(KS+1) KiB
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // every wave of the workgroup takes part in the staging barriers, also one without envs
+    const int env0 = min((blockIdx.x * 4 + wave) * kWave, max(N - 1, 0));
+    const bool wave_has_envs = (int)(blockIdx.x * 4 + wave) * kWave < N;
+
+    bf16x8 x[2][KS], xo[2];
+    bool valid[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int env = env0 + 32 * t + r;
+        valid[t] = wave_has_envs && env < N;
+        const float4 *pr = reinterpret_cast<const float4 *>(pooled + (size_t)(valid[t] ? env : env0) * HP + 8 * h);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) x[t][kk] = frag_from_floats(pr[4 * kk], pr[4 * kk + 1]);
+        const float4 *o = reinterpret_cast<const float4 *>(obs + (size_t)(valid[t] ? env : env0) * 8);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        xo[t] = h == 0 ? frag_from_floats(o[0], o[1]) : frag_from_floats(z4, z4);
+    }
+    f32x16 acc[2][NT];
+    // ---- e3 = W3 mean(H2)   (zone_net_.4 after the mean; no activation)
+    stage_image(wl, img.w3, NT * KS);
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        acc[0][m] = zero16();
+        acc[1][m] = zero16();
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const bf16x8 a = as_frag(wl[(m * KS + kk) * kWave + lane]);
+            acc[0][m] = mfma(a, x[0][kk], acc[0][m]);
+            acc[1][m] = mfma(a, x[1][kk], acc[1][m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc_to_frags(acc[t][m], false, x[t][2 * m], x[t][2 * m + 1]);
+    // ---- c = Wc [e3; obs]   (combine_net_; no activation)
+    stage_image(wl, img.wc, NT * (KS + 1));
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        acc[0][m] = zero16();
+        acc[1][m] = zero16();
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const bf16x8 a = as_frag(wl[(m * (KS + 1) + kk) * kWave + lane]);
+            acc[0][m] = mfma(a, x[0][kk], acc[0][m]);
+            acc[1][m] = mfma(a, x[1][kk], acc[1][m]);
+        }
+        const bf16x8 a = as_frag(wl[(m * (KS + 1) + KS) * kWave + lane]);
+        acc[0][m] = mfma(a, xo[0], acc[0][m]);
+        acc[1][m] = mfma(a, xo[1], acc[1][m]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc_to_frags(acc[t][m], false, x[t][2 * m], x[t][2 * m + 1]);
+    // ---- a = relu(Wa c)   (actor.enc_)
+    stage_image(wl, img.wa, NT * KS);
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        acc[0][m] = zero16();
+        acc[1][m] = zero16();
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const bf16x8 a = as_frag(wl[(m * KS + kk) * kWave + lane]);
+            acc[0][m] = mfma(a, x[0][kk], acc[0][m]);
+            acc[1][m] = mfma(a, x[1][kk], acc[1][m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc_to_frags(acc[t][m], true, x[t][2 * m], x[t][2 * m + 1]);
+    // ---- heads: rows 0-1 = mu_, rows 2-3 = std_ (lane half 0, registers 0..3)
+    stage_image(wl, img.wh, KS);
+    f32x16 hd[2] = { zero16(), zero16() };
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const bf16x8 a = as_frag(wl[kk * kWave + lane]);
+        hd[0] = mfma(a, x[0][kk], hd[0]);
+        hd[1] = mfma(a, x[1][kk], hd[1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (h == 0 && valid[t]) {
+            const int env = env0 + 32 * t + r;
+            reinterpret_cast<float2 *>(mu)[env] =
+                make_float2(2.0f * (sigmoidf_(hd[t][0]) - 0.5f), 2.0f * (sigmoidf_(hd[t][1]) - 0.5f));
+            reinterpret_cast<float2 *>(stdv)[env] =
+                make_float2(sigmoidf_(hd[t][2]) + 1e-3f, sigmoidf_(hd[t][3]) + 1e-3f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ sampling
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mlp_action(int N, const float *__restrict__ mu, const float *__restrict__ stdv,
+                                                    int sample, uint64_t seed, uint64_t env_index0, uint32_t step_index,
+                                                    float *__restrict__ actions)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    float2 a = reinterpret_cast<const float2 *>(mu)[env];
+    if (sample) {
+        // Normal(mu, std).sample(): Box-Muller on two Philox uniforms keyed by (seed, global env, step)
+        const uint64_t g = env_index0 + (uint64_t)env;
+        uint32_t c[4] = { (uint32_t)g, (uint32_t)(g >> 32), step_index, 0x4D4C50u };
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const float u1 = ((float)(c[0] >> 8) + 0.5f) * 5.9604644775390625e-08f;     // (0, 1)
+        const float u2 = ((float)(c[1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+        const float rad = sqrtf(-2.0f * logf(u1));
+        const float2 s = reinterpret_cast<const float2 *>(stdv)[env];
+        a.x += s.x * rad * cosf(6.283185307179586f * u2);
+        a.y += s.y * rad * sinf(6.283185307179586f * u2);
+    }
+    reinterpret_cast<float2 *>(actions)[env] = a;
+}
+
+uint16_t to_bf16(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);      // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+
+// logical k of element j of lane half h in k-step kk
+int k_natural(int kk, int h, int j) { return 16 * kk + 8 * h + j; }
+int k_from_acc(int kk, int h, int j) { return 32 * (kk >> 1) + 16 * (kk & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+}  // namespace
+
+// One image = [n_tiles][n_ksteps] fragments of 64 lanes x 8 bf16.  Lane (r, h) of fragment (n, kk) holds
+// value(out = 32 n + r, k = order(kk, h, j)), j = 0..7.  `value` resolves a (row, logical k) pair.
+template <typename ValueFn, typename OrderFn>
+static void pack_image(std::vector<uint16_t> &out, int n_tiles, int n_ksteps, ValueFn value, OrderFn order)
+{
+    for (int n = 0; n < n_tiles; ++n)
+        for (int kk = 0; kk < n_ksteps; ++kk)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j)
+                    out.push_back(to_bf16(value(32 * n + (lane & 31), kk, order(kk, lane >> 5, j))));
+}
+
+int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, size_t offs[6])
+{
+    const int h = w.h_dim;
+    if (h < 1 || h + 1 > kMlpHP || 8 + F > 15) return -1;
+    out.clear();
+    // a hidden layer [h][h] whose input carries the constant 1 in feature h: bias in column h, row h keeps the 1
+    auto hidden = [h](const float *W, const float *b) {
+        return [=](int row, int, int k) -> float {
+            if (row == h) return k == h ? 1.f : 0.f;
+            if (row > h || k > h) return 0.f;
+            return k == h ? b[row] : W[(size_t)row * h + k];
+        };
+    };
+    // zone_net_.0: input k = [obs 0..7, zone row 0..F-1, 0.., bias slot 15]
+    offs[0] = out.size() * 2;
+    pack_image(out, kMlpNT, 1, [&](int row, int, int k) -> float {
+        if (row == h) return k == 15 ? 1.f : 0.f;
+        if (row > h) return 0.f;
+        if (k == 15) return w.zone_b1[row];
+        return k < 8 + F ? w.zone_w1[(size_t)row * (8 + F) + k] : 0.f;
+    }, k_natural);
+    offs[1] = out.size() * 2;
+    pack_image(out, kMlpNT, kMlpKS, hidden(w.zone_w2, w.zone_b2), k_from_acc);
+    offs[2] = out.size() * 2;
+    pack_image(out, kMlpNT, kMlpKS, hidden(w.zone_w3, w.zone_b3), k_natural);
+    // combine_net_: torch input order [obs (8), zone_emb (h)]; here k-steps 0..KS-1 = zone_emb in accumulator
+    // order (+ the constant), k-step KS = obs in natural order
+    offs[3] = out.size() * 2;
+    pack_image(out, kMlpNT, kMlpKS + 1, [&](int row, int kk, int k) -> float {
+        if (kk == kMlpKS) {
+            const int ko = k - 16 * kMlpKS;
+            return (row < h && ko < 8) ? w.comb_w[(size_t)row * (8 + h) + ko] : 0.f;
+        }
+        if (row == h) return k == h ? 1.f : 0.f;
+        if (row > h || k > h) return 0.f;
+        return k == h ? w.comb_b[row] : w.comb_w[(size_t)row * (8 + h) + 8 + k];
+    }, [](int kk, int hh, int j) { return kk == kMlpKS ? k_natural(kk, hh, j) : k_from_acc(kk, hh, j); });
+    offs[4] = out.size() * 2;
+    pack_image(out, kMlpNT, kMlpKS, hidden(w.enc_w, w.enc_b), k_from_acc);
+    offs[5] = out.size() * 2;
+    pack_image(out, 1, kMlpKS, [&](int row, int, int k) -> float {
+        if (row > 3 || k > h) return 0.f;
+        const float *W = row < 2 ? w.mu_w : w.std_w;
+        const float *b = row < 2 ? w.mu_b : w.std_b;
+        const int rr = row & 1;
+        return k == h ? b[rr] : W[(size_t)rr * h + k];
+    }, k_from_acc);
+    return 0;
+}
+
+hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
+                              float *pooled, float *mu, float *stdv, hipStream_t s)
+{
+    const dim3 grid((N + 4 * kWave - 1) / (4 * kWave)), block(4 * kWave);
+    const size_t lds = (size_t)(NT * KS + NT) * kWave * sizeof(uint4);
+#define ZENV_MLP(ZT, FF)                                                                                          \
+    do {                                                                                                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone<ZT, FF>),                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+        hipLaunchKernelGGL((k_mlp_zone<ZT, FF>), grid, block, lds, s, img, N, Z, obs, zone_obs, pooled);          \
+    } while (0)
+    if (F == 6) {
+        switch (Z) {
+        case 25: ZENV_MLP(25, 6); break;
+        case 15: ZENV_MLP(15, 6); break;
+        default: ZENV_MLP(0, 6); break;
+        }
+    } else {
+        switch (Z) {
+        case 25: ZENV_MLP(25, 7); break;
+        case 15: ZENV_MLP(15, 7); break;
+        case 6: ZENV_MLP(6, 7); break;
+        default: ZENV_MLP(0, 7); break;
+        }
+    }
+#undef ZENV_MLP
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t lds_head = (size_t)NT * (KS + 1) * kWave * sizeof(uint4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_head), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_head);
+    hipLaunchKernelGGL(k_mlp_head, grid, block, lds_head, s, img, N, obs, pooled, mu, stdv);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_action(int N, const float *mu, const float *stdv, int sample, uint64_t seed, uint64_t env_index0,
+                             uint32_t step_index, float *actions, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mlp_action, dim3((N + 255) / 256), dim3(256), 0, s, N, mu, stdv, sample, seed, env_index0,
+                       step_index, actions);
+    return hipGetLastError();
+}
+
+}  // namespace zenvk

@@ -1,0 +1,44 @@
+// mlp_policy.hpp -- the reference's actor network on the device.
+//
+// ZoneEnvModel (main/src/env_model.py:48-79) + the actor of ACModel (flat_model.py:24-37,
+// policy_network.py:12-53) as two bf16-MFMA kernels that read the env's own obs / zone_obs
+// buffers: no host round trip between env.step and the next action.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/zenv.h"
+
+namespace zenvk {
+
+constexpr int kMlpHP = 192;              // hidden width padded to whole 32-wide MFMA tiles
+constexpr int kMlpNT = kMlpHP / 32;      // output tiles per hidden layer
+constexpr int kMlpKS = kMlpHP / 16;      // k-steps (K = 16 each) per hidden layer
+
+// Device images of the weights, already in MFMA fragment order (one 16-byte piece per lane and
+// fragment; see pack_images()).  Counts are in fragments of 64 lanes x 8 bf16 = 1 KiB.
+struct MlpImages {
+    const void *w1;     // [NT][1]      zone_net_.0   A operand, natural k order (obs, zone row, bias slot)
+    const void *w2;     // [NT][KS]     zone_net_.2   B operand of H2^T = X1^T W2^T (k in accumulator order)
+    const void *w3;     // [NT][KS]     zone_net_.4   A operand, natural k order (input read from memory)
+    const void *wc;     // [NT][KS+1]   combine_net_  A operand: KS steps accumulator order + 1 step obs
+    const void *wa;     // [NT][KS]     actor.enc_.0.0  A operand, accumulator order
+    const void *wh;     // [1][KS]      actor.mu_ / actor.std_ (rows 0-1 / 2-3), accumulator order
+};
+
+// Packs the float32 state_dict tensors into one host buffer of fragments; offsets (in bytes) of the six
+// images are returned in `offs`.  h = hidden width (<= 191), F = zone features (6 or 7).
+int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, size_t offs[6]);
+
+// obs [N,8], zone_obs [N,Z,F] float32 (device) -> mu, std [N,2] float32 (device).
+// pooled: scratch [N][kMlpHP] float32 (device).
+hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
+                              float *pooled, float *mu, float *stdv, hipStream_t s);
+// actions[N,2] = mu (sample = 0) or mu + std * eps, eps ~ N(0,1) from Philox4x32-10 keyed by
+// (seed, global env, step) -- the reference's dist.sample() (utils/agent.py:41-44).
+hipError_t launch_mlp_action(int N, const float *mu, const float *stdv, int sample, uint64_t seed, uint64_t env_index0,
+                             uint32_t step_index, float *actions, hipStream_t s);
+
+}  // namespace zenvk

@@ -16,6 +16,7 @@
 #include "dev_params.hpp"
 #include "host_sampler.hpp"
 #include "kernels.hpp"
+#include "mlp_policy.hpp"
 
 using namespace zenvk;
 
@@ -65,6 +66,11 @@ struct zenv {
     bool was_reset = false;
     int64_t step_count = 0;
     std::vector<hipEvent_t> events;
+    // actor network (zenv_mlp_load)
+    void *mlp_mem = nullptr;
+    MlpImages mlp{};
+    float *mlp_pooled = nullptr, *mlp_mu = nullptr, *mlp_std = nullptr;
+    bool mlp_ready = false;
 };
 
 namespace {
@@ -155,6 +161,8 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_VISIT_COUNT: return { p.visit_count, N * 4 };
     case ZENV_F_SEED: return { p.seed, N * 8 };
     case ZENV_F_ACTIONS: return { p.actions, N * 2 * 4 };
+    case ZENV_F_POLICY_MU: return { h->mlp_mu, h->mlp_mu ? N * 2 * 4 : 0 };
+    case ZENV_F_POLICY_STD: return { h->mlp_std, h->mlp_std ? N * 2 * 4 : 0 };
     default: return { nullptr, 0 };
     }
 }
@@ -355,6 +363,8 @@ extern "C" int zenv_destroy(zenv_t *h)
     for (void *m : h->bank_mem)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
+    for (void *m : { h->mlp_mem, (void *)h->mlp_pooled, (void *)h->mlp_mu, (void *)h->mlp_std })
+        if (m) (void)hipFree(m);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -587,17 +597,72 @@ extern "C" int zenv_step(zenv_t *h, const float *actions, int actions_on_device,
     return ZENV_OK;
 }
 
+// ============================================================================ actor network
+extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
+{
+    if (!h || !w) return fail(ZENV_E_ARG, "null argument");
+    for (const float *t : { w->zone_w1, w->zone_b1, w->zone_w2, w->zone_b2, w->zone_w3, w->zone_b3, w->comb_w, w->comb_b,
+                            w->enc_w, w->enc_b, w->mu_w, w->mu_b, w->std_w, w->std_b })
+        if (!t) return fail(ZENV_E_ARG, "zenv_mlp_weights has a null tensor");
+    std::vector<uint16_t> img;
+    size_t offs[6];
+    if (pack_images(*w, h->p.F, img, offs) != 0)
+        return fail(ZENV_E_ARG, "h_dim %d outside [1, %d]", w->h_dim, kMlpHP - 1);
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t N = (size_t)h->n_env;
+    if (!h->mlp_mem) HIP_TRY(hipMalloc(&h->mlp_mem, img.size() * 2));
+    if (!h->mlp_pooled) HIP_TRY(hipMalloc((void **)&h->mlp_pooled, N * kMlpHP * sizeof(float)));
+    if (!h->mlp_mu) HIP_TRY(hipMalloc((void **)&h->mlp_mu, N * 2 * sizeof(float)));
+    if (!h->mlp_std) HIP_TRY(hipMalloc((void **)&h->mlp_std, N * 2 * sizeof(float)));
+    HIP_TRY(hipMemcpy(h->mlp_mem, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+    const char *base = static_cast<const char *>(h->mlp_mem);
+    h->mlp = MlpImages{ base + offs[0], base + offs[1], base + offs[2], base + offs[3], base + offs[4], base + offs[5] };
+    h->mlp_ready = true;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_mlp_forward(zenv_t *h)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (!h->mlp_ready) return fail(ZENV_E_STATE, "zenv_mlp_load first");
+    if (!h->was_reset) return fail(ZENV_E_STATE, "reset before asking for actions");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
+                               h->mlp_std, h->stream));
+    return ZENV_OK;
+}
+
+static bool policy_known(int policy) { return policy >= ZENV_POLICY_UNIFORM && policy <= ZENV_POLICY_MLP_SAMPLE; }
+static bool policy_is_mlp(int policy) { return policy == ZENV_POLICY_MLP_MEAN || policy == ZENV_POLICY_MLP_SAMPLE; }
+
+// a_t = pi(obs_t, t) into pol.out, for every kind of action source
+static int run_policy(zenv_t *h, const StepPolicy &pol)
+{
+    if (!policy_is_mlp(pol.policy)) {
+        HIP_TRY(launch_policy(h->p, pol, h->stream));
+        return ZENV_OK;
+    }
+    if (!h->mlp_ready) return fail(ZENV_E_STATE, "zenv_mlp_load first");
+    HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
+                               h->mlp_std, h->stream));
+    HIP_TRY(launch_mlp_action(h->n_env, h->mlp_mu, h->mlp_std, pol.policy == ZENV_POLICY_MLP_SAMPLE, pol.seed,
+                              pol.env_index0, pol.step_index, pol.out, h->stream));
+    return ZENV_OK;
+}
+
 extern "C" int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0, float *dst_device)
 {
     if (!h) return fail(ZENV_E_ARG, "null handle");
     if (!h->was_reset) return fail(ZENV_E_STATE, "reset before asking for actions");
-    if (policy != ZENV_POLICY_UNIFORM && policy != ZENV_POLICY_GREEDY) return fail(ZENV_E_ARG, "unknown policy %d", policy);
+    if (!policy_known(policy)) return fail(ZENV_E_ARG, "unknown policy %d", policy);
     int rc = use_device(h);
     if (rc) return rc;
     const StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0,
                           dst_device ? dst_device : h->p.actions };
-    HIP_TRY(launch_policy(h->p, pol, h->stream));
-    return ZENV_OK;
+    return run_policy(h, pol);
 }
 
 static constexpr int kRolloutChunk = ZENV_ROLLOUT_CHUNK;   // steps per launch of the persistent kernel
@@ -608,10 +673,12 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     if (!h) return fail(ZENV_E_ARG, "null handle");
     if (!h->was_reset) return fail(ZENV_E_STATE, "Environment must be reset before stepping");
     if (steps < 0) return fail(ZENV_E_ARG, "steps must be >= 0");
-    if (policy != ZENV_POLICY_UNIFORM && policy != ZENV_POLICY_GREEDY) return fail(ZENV_E_ARG, "unknown policy %d", policy);
+    if (!policy_known(policy)) return fail(ZENV_E_ARG, "unknown policy %d", policy);
+    if (policy_is_mlp(policy) && !h->mlp_ready) return fail(ZENV_E_STATE, "zenv_mlp_load first");
     int rc = use_device(h);
     if (rc) return rc;
-    const bool fused = (flags & ZENV_ROLLOUT_UNFUSED) == 0;
+    // the actor network is its own launch sequence: policy, then step, every step
+    const bool fused = (flags & ZENV_ROLLOUT_UNFUSED) == 0 && !policy_is_mlp(policy);
     const bool persistent = fused && (flags & ZENV_ROLLOUT_PER_STEP) == 0 && rollout_kernel_available(h->p);
     const bool per_kernel = ms_step_kernel_avg != nullptr && steps > 0;
     if (event_stride < 1) event_stride = 1;
@@ -642,7 +709,10 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
         StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };
         // a_t = pi(obs_t, t): one stand-alone policy launch per step (unfused) or only before
         // the first step (fused: every step kernel then leaves a_{t+1} in the action buffer)
-        if (!fused || t == 0) HIP_TRY(launch_policy(h->p, pol, h->stream));
+        if (!fused || t == 0) {
+            rc = run_policy(h, pol);
+            if (rc) return rc;
+        }
         StepPolicy next = no_policy();
         if (fused) {
             next = pol;

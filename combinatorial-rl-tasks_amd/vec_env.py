@@ -19,7 +19,7 @@ _FIELD_DTYPES = {
     nat.F_DONE: np.uint8, nat.F_GOAL_MET: np.uint8, nat.F_EP_RETURN: np.float64,
     nat.F_EP_LEN: np.int32, nat.F_LAST_RETURN: np.float64, nat.F_LAST_LEN: np.int32,
     nat.F_EPISODES: np.int32, nat.F_VISIT_COUNT: np.int32, nat.F_SEED: np.int64,
-    nat.F_ACTIONS: np.float32,
+    nat.F_ACTIONS: np.float32, nat.F_POLICY_MU: np.float32, nat.F_POLICY_STD: np.float32,
 }
 
 
@@ -48,6 +48,19 @@ def apply_overrides(cfg, overrides):
         else:
             setattr(cfg, k, v)
     return cfg
+
+
+def mlp_tensors_from_state_dict(sd):
+    """ACModel.state_dict() (flat_model.py:24-52) -> the tensors load_mlp wants (numpy float32)."""
+    names = {"zone_w1": "env_model.zone_net_.0.weight", "zone_b1": "env_model.zone_net_.0.bias",
+             "zone_w2": "env_model.zone_net_.2.weight", "zone_b2": "env_model.zone_net_.2.bias",
+             "zone_w3": "env_model.zone_net_.4.weight", "zone_b3": "env_model.zone_net_.4.bias",
+             "comb_w": "env_model.combine_net_.weight", "comb_b": "env_model.combine_net_.bias",
+             "enc_w": "actor.enc_.0.0.weight", "enc_b": "actor.enc_.0.0.bias",
+             "mu_w": "actor.mu_.weight", "mu_b": "actor.mu_.bias",
+             "std_w": "actor.std_.weight", "std_b": "actor.std_.bias"}
+    return {k: np.asarray(sd[v].detach().cpu().numpy() if hasattr(sd[v], "detach") else sd[v], np.float32)
+            for k, v in names.items()}
 
 
 def zone_feat(cfg):
@@ -194,6 +207,31 @@ class ZoneVecEnv:
                                  C.byref(kern) if time_step_kernel else None))
         return total.value, (kern.value if time_step_kernel else None)
 
+    # ------------------------------------------------------------------ actor network
+    def load_mlp(self, tensors):
+        """The reference's ZoneEnvModel + actor (env_model.py:48-79, policy_network.py:12-53) for the
+        device policies POLICY_MLP_MEAN / POLICY_MLP_SAMPLE.  tensors: dict of float32 arrays named as in
+        ``_native.MLP_TENSORS`` (see ``mlp_tensors_from_state_dict``), state_dict layout [out][in]."""
+        F = self.zone_feat
+        h = int(np.asarray(tensors["zone_b1"]).shape[0])
+        want = {"zone_w1": (h, 8 + F), "zone_b1": (h,), "zone_w2": (h, h), "zone_b2": (h,), "zone_w3": (h, h),
+                "zone_b3": (h,), "comb_w": (h, 8 + h), "comb_b": (h,), "enc_w": (h, h), "enc_b": (h,),
+                "mu_w": (2, h), "mu_b": (2,), "std_w": (2, h), "std_b": (2,)}
+        keep = {}
+        w = nat.MlpWeights(h_dim=h)
+        for name in nat.MLP_TENSORS:
+            a = np.ascontiguousarray(tensors[name], np.float32)
+            if a.shape != want[name]:
+                raise ValueError(f"{name}: shape {a.shape}, expected {want[name]}")
+            keep[name] = a
+            setattr(w, name, a.ctypes.data)
+        check(lib().zenv_mlp_load(self._h, C.byref(w)))
+
+    def mlp_forward(self):
+        """(mu, std) float32 [N,2] of the actor's Normal for the current observations."""
+        check(lib().zenv_mlp_forward(self._h))
+        return self.get(nat.F_POLICY_MU), self.get(nat.F_POLICY_STD)
+
     def sync(self):
         check(lib().zenv_sync(self._h))
 
@@ -213,7 +251,7 @@ class ZoneVecEnv:
             return (N, nat.OBS_DIM)
         if field == nat.F_ZONE_OBS:
             return (N, self.num_zones, self.zone_feat)
-        if field == nat.F_ACTIONS:
+        if field in (nat.F_ACTIONS, nat.F_POLICY_MU, nat.F_POLICY_STD):
             return (N, 2)
         return (N,)
 

@@ -58,11 +58,18 @@ enum {
     ZENV_F_VISIT_COUNT = 10,/* int32   [N]     visited zones (TSP/Timed) or goal_dist (ColourMatch) */
     ZENV_F_SEED = 11,       /* int64   [N]     env seed of the running episode */
     ZENV_F_ACTIONS = 12,    /* float32 [N,2]   internal action buffer (zenv_policy target) */
+    ZENV_F_POLICY_MU = 13,  /* float32 [N,2]   mean of the actor's Normal (after zenv_mlp_forward) */
+    ZENV_F_POLICY_STD = 14, /* float32 [N,2]   its standard deviation */
     ZENV_F_COUNT = 13
 };
 
 /* scripted on-device action sources (the build's own; used by bench/tests) */
-enum { ZENV_POLICY_UNIFORM = 0, ZENV_POLICY_GREEDY = 1 };
+enum {
+    ZENV_POLICY_UNIFORM = 0,
+    ZENV_POLICY_GREEDY = 1,
+    ZENV_POLICY_MLP_MEAN = 2,   /* a = mu of the loaded actor network (zenv_mlp_load) */
+    ZENV_POLICY_MLP_SAMPLE = 3  /* a ~ Normal(mu, std), the reference's dist.sample() (utils/agent.py:41-44) */
+};
 
 /* kernel layouts */
 enum {
@@ -169,6 +176,28 @@ int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0
 int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
                  int auto_reset, int flags, int event_stride, float *ms_total,
                  float *ms_step_kernel_avg);
+
+/* ---- the reference's actor network on the device ----
+ * ZoneEnvModel (main/src/env_model.py:48-79) + the actor of ACModel (flat_model.py:24-37,
+ * policy_network.py:12-53, Box action space), evaluated on bf16 MFMA with float32 accumulation from
+ * the handle's own obs / zone_obs buffers.  Pointers are host float32 tensors in the state_dict's
+ * layout (row-major [out][in]); F = zenv_zone_feat(cfg).  h_dim <= 191 (the reference uses 185). */
+typedef struct zenv_mlp_weights {
+    int32_t h_dim;
+    int32_t reserved;
+    const float *zone_w1, *zone_b1; /* env_model.zone_net_.0  [h, 8+F], [h]   input = [obs, zone row] */
+    const float *zone_w2, *zone_b2; /* env_model.zone_net_.2  [h, h],   [h] */
+    const float *zone_w3, *zone_b3; /* env_model.zone_net_.4  [h, h],   [h] */
+    const float *comb_w, *comb_b;   /* env_model.combine_net_ [h, 8+h], [h]   input = [obs, zone_emb] */
+    const float *enc_w, *enc_b;     /* actor.enc_.0.0         [h, h],   [h] */
+    const float *mu_w, *mu_b;       /* actor.mu_              [2, h],   [2] */
+    const float *std_w, *std_b;     /* actor.std_             [2, h],   [2] */
+} zenv_mlp_weights;
+int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w);
+/* mu = 2 (sigmoid(mu_(x)) - 0.5), std = sigmoid(std_(x)) + 1e-3 of the current observations into
+ * ZENV_F_POLICY_MU / ZENV_F_POLICY_STD.  zenv_policy() / zenv_rollout() with ZENV_POLICY_MLP_* call it
+ * and turn it into actions (rollouts then run one launch sequence per step). */
+int zenv_mlp_forward(zenv_t *h);
 
 /* ---- results ---- */
 int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device);

@@ -1,0 +1,95 @@
+"""the reference's actor network (ZoneEnvModel + PolicyNetwork) on bf16 MFMA.
+
+Checker = oracle/policy_ref.py (torch): (i) the same computation with the kernel's rounding points
+emulated -- tight tolerance, this is what pins the fragment layouts and the k permutations (random,
+asymmetric weights; every output depends on every weight); (ii) the reference's float32 computation --
+the tolerance that bf16 inputs buy.  Tolerances: |mu|,|std| <= 1; (i) 4e-3 absolute, (ii) 4e-2."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _env_with_obs(Z, env_id, n, steps, **over):
+    cfg = Z.config_for_id(env_id, **over)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(11, n)
+    env.reset()
+    if steps:
+        env.rollout(steps, Z.POLICY_GREEDY)
+    return env
+
+
+@pytest.mark.parametrize("env_id,n,steps", [("PointTSP-v0", 64, 0), ("PointTSP-v0", 203, 40), ("PointTTSP-v0", 130, 25),
+                                            ("ColourMatch-v0", 77, 60), ("PointTSP-v1", 65, 10)])
+def test_mlp_forward_matches_torch(zenv_mod, env_id, n, steps):
+    from oracle import policy_ref as P
+    Z = zenv_mod
+    env = _env_with_obs(Z, env_id, n, steps)
+    t = P.random_tensors(env.zone_feat, h=185, seed=5)
+    env.load_mlp(t)
+    mu, std = env.mlp_forward()
+    obs, zo = env.observations()
+    mu_e, std_e = P.forward_bf16_emulated(t, obs, zo)
+    mu_r, std_r = P.forward_fp32(t, obs, zo)
+    assert np.isfinite(mu).all() and np.isfinite(std).all()
+    assert np.abs(mu_r).max() > 0.05 and mu_r.std() > 0.01         # the network output is not degenerate
+    assert np.abs(mu - mu_e).max() < 4e-3 and np.abs(std - std_e).max() < 4e-3
+    assert np.abs(mu - mu_r).max() < 4e-2 and np.abs(std - std_r).max() < 4e-2
+    env.close()
+
+
+def test_mlp_other_widths_and_zone_counts(zenv_mod):
+    """h_dim below the padded width and zone counts without a compile-time instantiation."""
+    from oracle import policy_ref as P
+    Z = zenv_mod
+    for task, zones, h in ((0, 9, 64), (1, 32, 191), (2, 5, 33), (0, 1, 185)):
+        n = 97
+        cfg = Z.default_config(task, zones, zones_keepout=0.3 if zones > 20 else 0.55)
+        env = Z.ZoneVecEnv(cfg, n)
+        env.build_bank(3, n)
+        env.reset()
+        env.rollout(15, Z.POLICY_UNIFORM)
+        t = P.random_tensors(env.zone_feat, h=h, seed=zones)
+        env.load_mlp(t)
+        mu, std = env.mlp_forward()
+        obs, zo = env.observations()
+        mu_e, std_e = P.forward_bf16_emulated(t, obs, zo)
+        assert np.abs(mu - mu_e).max() < 4e-3 and np.abs(std - std_e).max() < 4e-3, (task, zones, h)
+        env.close()
+    with pytest.raises(Z.ZenvError):
+        env = Z.ZoneVecEnv(Z.default_config(0, 5), 4)
+        env.load_mlp(P.random_tensors(6, h=192))                   # no room for the bias slot
+
+
+def test_mlp_policy_actions_and_rollout(zenv_mod):
+    """POLICY_MLP_MEAN writes mu into the action buffer; POLICY_MLP_SAMPLE adds std * N(0,1) noise keyed by
+    (seed, env, step); a rollout is the same launch sequence as policy + step by hand."""
+    from oracle import policy_ref as P
+    Z = zenv_mod
+    n = 4096
+    env = _env_with_obs(Z, "PointTSP-v0", n, 5)
+    t = P.random_tensors(6, seed=1)
+    env.load_mlp(t)
+    mu, std = env.mlp_forward()
+    env.policy(Z.POLICY_MLP_MEAN)
+    assert np.array_equal(env.get(Z.F_ACTIONS), mu)
+    env.policy(Z.POLICY_MLP_SAMPLE, policy_seed=9)
+    a1 = env.get(Z.F_ACTIONS)
+    env.policy(Z.POLICY_MLP_SAMPLE, policy_seed=9)
+    assert np.array_equal(a1, env.get(Z.F_ACTIONS))                # deterministic in (seed, env, step)
+    eps = (a1 - mu) / std
+    assert abs(eps.mean()) < 0.05 and abs(eps.std() - 1.0) < 0.05 and abs(np.corrcoef(eps[:, 0], eps[:, 1])[0, 1]) < 0.05
+    env.policy(Z.POLICY_MLP_SAMPLE, policy_seed=10)
+    assert not np.array_equal(a1, env.get(Z.F_ACTIONS))
+    # rollout == policy; step, by hand
+    blob = env.get_state()
+    env.rollout(7, Z.POLICY_MLP_MEAN)
+    want = env.results()
+    env.set_state(blob)
+    for _ in range(7):
+        env.policy(Z.POLICY_MLP_MEAN)
+        env.step(None, auto_reset=True)
+    for x, y in zip(want, env.results()):
+        assert np.array_equal(x, y)
+    env.close()
