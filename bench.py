@@ -233,6 +233,8 @@ def main():
                     "mean_last_return_all_ranks": float(np.mean(returns[returns != 0]))
                     if (returns != 0).any() else 0.0,
                     "parity_spot_check": parity_spot_check(env, cfg, shard, args, policy),
+                    "per_step_launch_mode": per_step_rate(env, task, zones, policy, shard)
+                    if args.mode == "persistent" else None,
                     "mlp_policy": None if (args.no_mlp or distributed) else mlp_policy_rate(env, zones)},
         }
         print(json.dumps(out), flush=True)
@@ -273,6 +275,21 @@ def cpu_baseline(cfg, task, zones, keepout, policy):
             "kind": "port",
             "sample": f"first {n} envs x {T} steps of the same workload, OpenMP over envs, "
                       f"{dt:.2f}s wall"}
+
+
+def per_step_rate(env, task, zones, policy, shard, steps=2000):
+    """Side measurement (never `value`): the same envs with ONE kernel launch per step (k_step_lane, the
+    path an externally supplied action takes), right after the timed region, clocks still settled."""
+    try:
+        env.rollout(200, policy, policy_seed=0x5EED, env_index0=shard.env_index0, mode="per_step")
+        ms, _ = env.rollout(steps, policy, policy_seed=0x5EED, env_index0=shard.env_index0, mode="per_step")
+        us = ms / steps * 1e3
+        alg = algorithmic_bytes(task, zones, 1)
+        return {"us_per_step": round(us, 2), "env_steps_per_s": round(env.num_envs * steps / (ms * 1e-3), 1),
+                "kernel": "k_step_lane", "algorithmic_bytes_per_env_step": alg,
+                "frac_of_hbm_peak": round(alg * env.num_envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    except Exception as ex:  # the bench line must still print
+        return f"error: {ex}"
 
 
 def mlp_policy_rate(env, zones, steps=300):

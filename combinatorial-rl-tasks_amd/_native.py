@@ -9,7 +9,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libzenv_hip.so")
+LIB_PATH = os.environ.get("ZENV_LIB_PATH") or os.path.join(_HERE, "lib", "libzenv_hip.so")   # env: diagnostic builds
 
 MAX_ZONES = 32
 OBS_DIM = 8

@@ -12,7 +12,7 @@
 // operand of  Y = A X  or the A operand of  Z = X^T B  -- when the other operand's k order follows the
 // accumulator order (cdna_hip_programming.md section 3, "an accumulator tile as the next MFMA's
 // operand").  So activations never leave registers:
-//   kernel 1 (k_mlp_zone), one wave per 64 envs, batch = the envs' 64 Z zone rows, 32 per tile:
+//   kernel 1 (k_mlp_zone), a wave pair per 64 envs, batch = the envs' 64 Z zone rows, 32 per tile:
 //     X1   = relu(W1 X0)            features in registers, zone row on the lane     (6 MFMA / tile)
 //     H2^T = relu(X1^T W2^T)        zone row in registers, feature on the lane      (72 MFMA / tile)
 //     mean over the zone rows of an env = one more product P += S relu(H2^T) with a 0/1 selection
@@ -63,13 +63,29 @@ __device__ __forceinline__ bf16x8 relu_bf16(const bf16x8 f)
     const s16x8 z = { 0, 0, 0, 0, 0, 0, 0, 0 };
     return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(v, z));
 }
+// two floats -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32.  Converting element
+// by element makes the compiler emit a cvt per element plus a v_perm to pair them up.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b)
+{
+    const f32x2_t v = { a, b };
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ bf16x8 frag_from_8(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
+                                              float a7)
+{
+    uint4 u;
+    u.x = pk_bf16(a0, a1);
+    u.y = pk_bf16(a2, a3);
+    u.z = pk_bf16(a4, a5);
+    u.w = pk_bf16(a6, a7);
+    return as_frag(u);
+}
 __device__ __forceinline__ void acc_to_frags(const f32x16 &acc, bool relu, bf16x8 &f0, bf16x8 &f1)
 {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        f0[j] = (__bf16)acc[j];
-        f1[j] = (__bf16)acc[8 + j];
-    }
+    f0 = frag_from_8(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+    f1 = frag_from_8(acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
     if (relu) {
         f0 = relu_bf16(f0);
         f1 = relu_bf16(f1);
@@ -77,10 +93,7 @@ __device__ __forceinline__ void acc_to_frags(const f32x16 &acc, bool relu, bf16x
 }
 __device__ __forceinline__ bf16x8 frag_from_floats(const float4 lo, const float4 hi)
 {
-    bf16x8 f;
-    f[0] = (__bf16)lo.x; f[1] = (__bf16)lo.y; f[2] = (__bf16)lo.z; f[3] = (__bf16)lo.w;
-    f[4] = (__bf16)hi.x; f[5] = (__bf16)hi.y; f[6] = (__bf16)hi.z; f[7] = (__bf16)hi.w;
-    return f;
+    return frag_from_8(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
 }
 
 // ------------------------------------------------------------------------------------------ kernel 1
@@ -114,22 +127,33 @@ __device__ __forceinline__ RawRow<F> load_row(const float *__restrict__ obs, con
     return x;
 }
 
+// 8 waves per workgroup, two per SIMD: wave w works on the 64-env group (w & 3) of the workgroup and on
+// the output-feature half (w >> 2) -- tiles n = 3 half .. 3 half + 2 of layer 2 and of the pooled mean.  Both
+// waves of a pair compute X1 (6 MFMA per 32 rows, 7 % of the work) so that neither needs the other's
+// registers; in return a wave fits in 256 registers and the SIMD always has a second wave to issue from
+// while one waits for an MFMA result, an LDS fragment or the next rows (one wave per SIMD measured: matrix
+// pipe 49 % busy, 29 % of the cycles in s_waitcnt, 30 % in issue stalls).
+constexpr int kZoneWaves = 8;
+constexpr int NH = NT / 2;               // output tiles per wave
+
 template <int ZT, int F>
-__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ __launch_bounds__(kZoneWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, const float *__restrict__ zone_obs,
                 float *__restrict__ pooled)
 {
     extern __shared__ uint4 lds[];
     uint4 *w2s = lds;                       // [NT*KS][64]
     uint4 *w1s = lds + NT * KS * kWave;     // [NT][64]
-    for (int i = threadIdx.x; i < NT * KS * kWave; i += 4 * kWave) w2s[i] = reinterpret_cast<const uint4 *>(img.w2)[i];
-    for (int i = threadIdx.x; i < NT * kWave; i += 4 * kWave) w1s[i] = reinterpret_cast<const uint4 *>(img.w1)[i];
+    for (int i = threadIdx.x; i < NT * KS * kWave; i += kZoneWaves * kWave)
+        w2s[i] = reinterpret_cast<const uint4 *>(img.w2)[i];
+    for (int i = threadIdx.x; i < NT * kWave; i += kZoneWaves * kWave) w1s[i] = reinterpret_cast<const uint4 *>(img.w1)[i];
     __syncthreads();
 
     const int Z = ZT > 0 ? ZT : Z_rt;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int env0 = (blockIdx.x * 4 + wave) * kWave;
+    const int n0 = NH * (wave >> 2);        // this wave's first output tile
+    const int env0 = (blockIdx.x * 4 + (wave & 3)) * kWave;
     if (env0 >= N) return;
     const int n_env = min(kWave, N - env0), n_rows = n_env * Z;
     const float inv_z = 1.0f / (float)Z;
@@ -139,88 +163,72 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
     // two groups of 32 envs: a group's zone rows all pool into ONE 32-env accumulator tile set
     for (int e_base = 0; e_base < n_env; e_base += 32) {
         const int g_lo = e_base * Z, g_hi = min(e_base + 32, n_env) * Z;     // the group's rows
-        f32x16 pool[NT];
+        f32x16 pool[NH];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) pool[n] = zero16();
-        RawRow<F> nxt[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) nxt[t] = load_row<ZT, F>(obs, zrows, env0, Z, g_lo + 32 * t + r, n_rows, h);
+        for (int n = 0; n < NH; ++n) pool[n] = zero16();
+        RawRow<F> nxt = load_row<ZT, F>(obs, zrows, env0, Z, g_lo + r, n_rows, h);
 
-        for (int b0 = g_lo; b0 < g_hi; b0 += 2 * 32) {
-            bf16x8 xa[2][KS];
+        for (int b = g_lo; b < g_hi; b += 32) {
+            const bf16x8 x0 = frag_from_8(nxt.v[0], nxt.v[1], nxt.v[2], nxt.v[3], nxt.v[4], nxt.v[5], nxt.v[6], nxt.v[7]);
+            // the next tile's rows are fetched while this one is in the matrix pipe
+            nxt = load_row<ZT, F>(obs, zrows, env0, Z, b + 32 + r, min(n_rows, g_hi), h);
+            // ---- layer 1: X1 = relu(W1 X0), features in registers
+            bf16x8 xa[KS];
+#if defined(MLP_EXP) && (MLP_EXP & 2)      // diagnostic: no layer 1
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                bf16x8 x0;
+            for (int kk = 0; kk < KS; ++kk) xa[kk] = x0;
+#else
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x0[j] = (__bf16)nxt[t].v[j];
-                // the next pair's rows are fetched while this pair is in the matrix pipe
-                nxt[t] = load_row<ZT, F>(obs, zrows, env0, Z, b0 + 64 + 32 * t + r, min(n_rows, g_hi + 32), h);
-                // ---- layer 1: X1 = relu(W1 X0), features in registers
-#pragma unroll
-                for (int m = 0; m < NT; ++m) {
-                    const f32x16 acc1 = mfma(as_frag(w1s[m * kWave + lane]), x0, zero16());
-                    acc_to_frags(acc1, true, xa[t][2 * m], xa[t][2 * m + 1]);
-                }
+            for (int m = 0; m < NT; ++m) {
+                const f32x16 acc1 = mfma(as_frag(w1s[m * kWave + lane]), x0, zero16());
+                acc_to_frags(acc1, true, xa[2 * m], xa[2 * m + 1]);
             }
+#endif
             // ---- mean over an env's rows = one more product: P += S relu(H2^T), S[env slot][row] = 1 when
             // the row belongs to env e_base + slot.  Lane (slot r, half h) element j of k-step s is tile row
             // 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the accumulator order of H2^T.
-            bf16x8 ind[2][2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int lo = (e_base + r) * Z - (b0 + 32 * t);   // first row of this lane's env, tile-relative
+            bf16x8 ind[2];
+            {
+                const int lo = (e_base + r) * Z - b;   // first row of this lane's env, tile-relative
 #pragma unroll
                 for (int sgm = 0; sgm < 2; ++sgm)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int pos = 16 * sgm + 8 * (j >> 2) + 4 * h + (j & 3);
-                        ind[t][sgm][j] = ((unsigned)(pos - lo) < (unsigned)Z) ? one : nil;
+                        ind[sgm][j] = ((unsigned)(pos - lo) < (unsigned)Z) ? one : nil;
                     }
             }
-            // ---- layer 2: H2^T = relu(X1^T W2^T), zone row in registers, feature on the lane; then the pooling.
-            // Software-pipelined over the output tiles: region n holds the 24 MFMAs of tile n, the ReLU / bf16
-            // conversion + pooling MFMAs of tile n-1 (independent of them: the scheduler interleaves the
-            // VALU work into the matrix pipe's shadow) and the LDS reads of tile n+1's fragments.
-            bf16x8 wf[NT][KS];              // statically indexed: only two tiles' worth is ever live
-            f32x16 acc2[NT][2];
+            // ---- layer 2: H2^T = relu(X1^T W2^T), zone row in registers, feature on the lane; then the pooling
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) wf[0][kk] = as_frag(w2s[kk * kWave + lane]);
+            for (int n = 0; n < NH; ++n) {
+                f32x16 acc2 = zero16();
 #pragma unroll
-            for (int n = 0; n <= NT; ++n) {
-                if (n < NT) {
-                    if (n + 1 < NT) {
-#pragma unroll
-                        for (int kk = 0; kk < KS; ++kk) wf[n + 1][kk] = as_frag(w2s[((n + 1) * KS + kk) * kWave + lane]);
-                    }
-                    acc2[n][0] = zero16();
-                    acc2[n][1] = zero16();
-#pragma unroll
-                    for (int kk = 0; kk < KS; ++kk) {
-                        acc2[n][0] = mfma(xa[0][kk], wf[n][kk], acc2[n][0]);
-                        acc2[n][1] = mfma(xa[1][kk], wf[n][kk], acc2[n][1]);
-                    }
-                }
-                if (n > 0) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        bf16x8 f0, f1;
-                        acc_to_frags(acc2[n - 1][t], true, f0, f1);
-                        pool[n - 1] = mfma(ind[t][0], f0, pool[n - 1]);
-                        pool[n - 1] = mfma(ind[t][1], f1, pool[n - 1]);
-                    }
-                }
-                // region boundary: without it the scheduler hoists every later tile's fragment reads to the top
-                // (512 VGPRs + 128 spilled)
+                for (int kk = 0; kk < KS; ++kk)
+#if defined(MLP_EXP) && (MLP_EXP & 4)      // diagnostic: one fragment read per output tile instead of 12
+                    acc2 = mfma(xa[kk], as_frag(w2s[((n0 + n) * KS) * kWave + lane]), acc2);
+#else
+                    acc2 = mfma(xa[kk], as_frag(w2s[((n0 + n) * KS + kk) * kWave + lane]), acc2);
+#endif
+                bf16x8 f0, f1;
+#if defined(MLP_EXP) && (MLP_EXP & 1)      // diagnostic: no conversion / pooling product
+                pool[n] = acc2;
+                (void)f0; (void)f1;
+#else
+                acc_to_frags(acc2, true, f0, f1);
+                pool[n] = mfma(ind[0], f0, pool[n]);
+                pool[n] = mfma(ind[1], f1, pool[n]);
+#endif
+                // region boundary: keeps the scheduler from hoisting every later tile's fragment reads up here
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- the group's means: accumulator register i of lane half h is env slot (i&3) + 8 (i>>2) + 4 h
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NH; ++n)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int e = e_base + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (e < n_env) pooled[(size_t)(env0 + e) * HP + 32 * n + r] = pool[n][i] * inv_z;
+                if (e < n_env) pooled[(size_t)(env0 + e) * HP + 32 * (n0 + n) + r] = pool[n][i] * inv_z;
             }
     }
 }
@@ -228,15 +236,19 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
 // ------------------------------------------------------------------------------------------ kernel 2
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// One layer's fragments, global -> LDS, by the whole workgroup
-__device__ __forceinline__ void stage_image(uint4 *dst, const void *src, int n_frags)
+// (Fetching the next layer's fragments into registers during the current layer's products and committing them
+// to a second LDS buffer afterwards was slower than plain staging: 48 us against 34 us.)
+// 8 waves per workgroup (two per SIMD), 32 envs per wave: the second wave of a SIMD covers the first one's
+// waits for LDS fragments and MFMA results, and the staging copies go twice as wide.
+constexpr int kHeadWaves = 8;
+__device__ __forceinline__ void stage_image8(uint4 *dst, const void *src, int n_frags)
 {
     __syncthreads();    // everyone is done with what the buffer held
-    for (int i = threadIdx.x; i < n_frags * kWave; i += 4 * kWave) dst[i] = reinterpret_cast<const uint4 *>(src)[i];
+    for (int i = threadIdx.x; i < n_frags * kWave; i += kHeadWaves * kWave) dst[i] = reinterpret_cast<const uint4 *>(src)[i];
     __syncthreads();
 }
 
-__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ __launch_bounds__(kHeadWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const float *__restrict__ pooled,
                 float *__restrict__ mu, float *__restrict__ stdv)
 {
@@ -244,98 +256,63 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const float
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     // every wave of the workgroup takes part in the staging barriers, also one without envs
-    const int env0 = min((blockIdx.x * 4 + wave) * kWave, max(N - 1, 0));
-    const bool wave_has_envs = (int)(blockIdx.x * 4 + wave) * kWave < N;
+    const int first = (int)(blockIdx.x * kHeadWaves + wave) * 32;
+    const int env = min(first + r, max(N - 1, 0));
+    const bool valid = first + r < N;
 
-    bf16x8 x[2][KS], xo[2];
-    bool valid[2];
+    bf16x8 x[KS], xo;
+    {
+        const float4 *pr = reinterpret_cast<const float4 *>(pooled + (size_t)env * HP + 8 * h);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int env = env0 + 32 * t + r;
-        valid[t] = wave_has_envs && env < N;
-        const float4 *pr = reinterpret_cast<const float4 *>(pooled + (size_t)(valid[t] ? env : env0) * HP + 8 * h);
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) x[t][kk] = frag_from_floats(pr[4 * kk], pr[4 * kk + 1]);
-        const float4 *o = reinterpret_cast<const float4 *>(obs + (size_t)(valid[t] ? env : env0) * 8);
+        for (int kk = 0; kk < KS; ++kk) x[kk] = frag_from_floats(pr[4 * kk], pr[4 * kk + 1]);
+        const float4 *o = reinterpret_cast<const float4 *>(obs + (size_t)env * 8);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        xo[t] = h == 0 ? frag_from_floats(o[0], o[1]) : frag_from_floats(z4, z4);
+        xo = h == 0 ? frag_from_floats(o[0], o[1]) : frag_from_floats(z4, z4);
     }
-    f32x16 acc[2][NT];
+    f32x16 acc[NT];
     // ---- e3 = W3 mean(H2)   (zone_net_.4 after the mean; no activation)
-    stage_image(wl, img.w3, NT * KS);
+    stage_image8(wl, img.w3, NT * KS);
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
-        acc[0][m] = zero16();
-        acc[1][m] = zero16();
+        acc[m] = zero16();
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const bf16x8 a = as_frag(wl[(m * KS + kk) * kWave + lane]);
-            acc[0][m] = mfma(a, x[0][kk], acc[0][m]);
-            acc[1][m] = mfma(a, x[1][kk], acc[1][m]);
-        }
+        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(wl[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int m = 0; m < NT; ++m) acc_to_frags(acc[t][m], false, x[t][2 * m], x[t][2 * m + 1]);
+    for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], false, x[2 * m], x[2 * m + 1]);
     // ---- c = Wc [e3; obs]   (combine_net_; no activation)
-    stage_image(wl, img.wc, NT * (KS + 1));
+    stage_image8(wl, img.wc, NT * (KS + 1));
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
-        acc[0][m] = zero16();
-        acc[1][m] = zero16();
+        acc[m] = zero16();
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const bf16x8 a = as_frag(wl[(m * (KS + 1) + kk) * kWave + lane]);
-            acc[0][m] = mfma(a, x[0][kk], acc[0][m]);
-            acc[1][m] = mfma(a, x[1][kk], acc[1][m]);
-        }
-        const bf16x8 a = as_frag(wl[(m * (KS + 1) + KS) * kWave + lane]);
-        acc[0][m] = mfma(a, xo[0], acc[0][m]);
-        acc[1][m] = mfma(a, xo[1], acc[1][m]);
+        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(wl[(m * (KS + 1) + kk) * kWave + lane]), x[kk], acc[m]);
+        acc[m] = mfma(as_frag(wl[(m * (KS + 1) + KS) * kWave + lane]), xo, acc[m]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int m = 0; m < NT; ++m) acc_to_frags(acc[t][m], false, x[t][2 * m], x[t][2 * m + 1]);
+    for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], false, x[2 * m], x[2 * m + 1]);
     // ---- a = relu(Wa c)   (actor.enc_)
-    stage_image(wl, img.wa, NT * KS);
+    stage_image8(wl, img.wa, NT * KS);
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
-        acc[0][m] = zero16();
-        acc[1][m] = zero16();
+        acc[m] = zero16();
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const bf16x8 a = as_frag(wl[(m * KS + kk) * kWave + lane]);
-            acc[0][m] = mfma(a, x[0][kk], acc[0][m]);
-            acc[1][m] = mfma(a, x[1][kk], acc[1][m]);
-        }
+        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(wl[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int m = 0; m < NT; ++m) acc_to_frags(acc[t][m], true, x[t][2 * m], x[t][2 * m + 1]);
+    for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], true, x[2 * m], x[2 * m + 1]);
     // ---- heads: rows 0-1 = mu_, rows 2-3 = std_ (lane half 0, registers 0..3)
-    stage_image(wl, img.wh, KS);
-    f32x16 hd[2] = { zero16(), zero16() };
+    stage_image8(wl, img.wh, KS);
+    f32x16 hd = zero16();
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-        const bf16x8 a = as_frag(wl[kk * kWave + lane]);
-        hd[0] = mfma(a, x[0][kk], hd[0]);
-        hd[1] = mfma(a, x[1][kk], hd[1]);
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (h == 0 && valid[t]) {
-            const int env = env0 + 32 * t + r;
-            reinterpret_cast<float2 *>(mu)[env] =
-                make_float2(2.0f * (sigmoidf_(hd[t][0]) - 0.5f), 2.0f * (sigmoidf_(hd[t][1]) - 0.5f));
-            reinterpret_cast<float2 *>(stdv)[env] =
-                make_float2(sigmoidf_(hd[t][2]) + 1e-3f, sigmoidf_(hd[t][3]) + 1e-3f);
-        }
+    for (int kk = 0; kk < KS; ++kk) hd = mfma(as_frag(wl[kk * kWave + lane]), x[kk], hd);
+    if (h == 0 && valid) {
+        reinterpret_cast<float2 *>(mu)[env] =
+            make_float2(2.0f * (sigmoidf_(hd[0]) - 0.5f), 2.0f * (sigmoidf_(hd[1]) - 0.5f));
+        reinterpret_cast<float2 *>(stdv)[env] = make_float2(sigmoidf_(hd[2]) + 1e-3f, sigmoidf_(hd[3]) + 1e-3f);
     }
 }
 
@@ -454,13 +431,14 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
                               float *pooled, float *mu, float *stdv, hipStream_t s)
 {
-    const dim3 grid((N + 4 * kWave - 1) / (4 * kWave)), block(4 * kWave);
+    const dim3 grid((N + 4 * kWave - 1) / (4 * kWave));   // one workgroup per 4 groups of 64 envs
     const size_t lds = (size_t)(NT * KS + NT) * kWave * sizeof(uint4);
 #define ZENV_MLP(ZT, FF)                                                                                          \
     do {                                                                                                          \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone<ZT, FF>),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-        hipLaunchKernelGGL((k_mlp_zone<ZT, FF>), grid, block, lds, s, img, N, Z, obs, zone_obs, pooled);          \
+        hipLaunchKernelGGL((k_mlp_zone<ZT, FF>), grid, dim3(kZoneWaves * kWave), lds, s, img, N, Z, obs, zone_obs,  \
+                           pooled);                                                                               \
     } while (0)
     if (F == 6) {
         switch (Z) {
@@ -482,7 +460,8 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
     const size_t lds_head = (size_t)NT * (KS + 1) * kWave * sizeof(uint4);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_head), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_head);
-    hipLaunchKernelGGL(k_mlp_head, grid, block, lds_head, s, img, N, obs, pooled, mu, stdv);
+    hipLaunchKernelGGL(k_mlp_head, dim3((N + kHeadWaves * 32 - 1) / (kHeadWaves * 32)), dim3(kHeadWaves * kWave), lds_head, s,
+                       img, N, obs, pooled, mu, stdv);
     return hipGetLastError();
 }
 

@@ -1,0 +1,9 @@
+"""Diagnostic: build the library with extra -D flags into gpurun_out/<name>.so (use with ZENV_LIB_PATH)."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import combinatorial_rl_tasks_amd.build as B
+so = os.path.join(ROOT, "gpurun_out", sys.argv[1] + ".so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.run([B._hipcc()] + B.FLAGS + sys.argv[2:] + ["-o", so] + [os.path.join(B.CSRC, s) for s in B.SOURCES], check=True)
+print(so)
