@@ -24,16 +24,17 @@ ROLLOUT_CHUNK = 256
 E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE = -1, -2, -3, -4, -5
 
 (F_OBS, F_ZONE_OBS, F_REWARD, F_DONE, F_GOAL_MET, F_EP_RETURN, F_EP_LEN, F_LAST_RETURN,
- F_LAST_LEN, F_EPISODES, F_VISIT_COUNT, F_SEED, F_ACTIONS, F_POLICY_MU, F_POLICY_STD) = range(15)
+ F_LAST_LEN, F_EPISODES, F_VISIT_COUNT, F_SEED, F_ACTIONS, F_POLICY_MU, F_POLICY_STD, F_POLICY_VALUE) = range(16)
 
 
 MLP_TENSORS = ("zone_w1", "zone_b1", "zone_w2", "zone_b2", "zone_w3", "zone_b3", "comb_w", "comb_b",
                "enc_w", "enc_b", "mu_w", "mu_b", "std_w", "std_b")
+MLP_CRITIC_TENSORS = ("critic_w1", "critic_b1", "critic_w2", "critic_b2")   # optional, all or none
 
 
 class MlpWeights(C.Structure):
     """struct zenv_mlp_weights (include/zenv.h): host float32 tensors in state_dict layout."""
-    _fields_ = [("h_dim", C.c_int32), ("reserved", C.c_int32)] + [(n, C.c_void_p) for n in MLP_TENSORS]
+    _fields_ = [("h_dim", C.c_int32), ("reserved", C.c_int32)] + [(n, C.c_void_p) for n in MLP_TENSORS + MLP_CRITIC_TENSORS]
 
 
 class ZenvError(RuntimeError):

@@ -250,7 +250,7 @@ __device__ __forceinline__ void stage_image8(uint4 *dst, const void *src, int n_
 
 __global__ __launch_bounds__(kHeadWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const float *__restrict__ pooled,
-                float *__restrict__ mu, float *__restrict__ stdv)
+                float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value)
 {
     extern __shared__ uint4 wl[];           // one layer's fragments at a time: up to NT*(KS+1) KiB
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -293,6 +293,25 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const float
     }
 #pragma unroll
     for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], false, x[2 * m], x[2 * m + 1]);
+    // ---- value = Wv2 relu(Wv1 c)   (critic, flat_model.py:43-47), from the same embedding c
+    if (img.wv1) {
+        stage_image8(wl, img.wv1, NT * KS);
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            acc[m] = zero16();
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(wl[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bf16x8 xv[KS];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], true, xv[2 * m], xv[2 * m + 1]);
+        stage_image8(wl, img.wv2, KS);
+        f32x16 hv = zero16();
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) hv = mfma(as_frag(wl[kk * kWave + lane]), xv[kk], hv);
+        if (h == 0 && valid) value[env] = hv[0];
+    }
     // ---- a = relu(Wa c)   (actor.enc_)
     stage_image8(wl, img.wa, NT * KS);
 #pragma unroll
@@ -378,7 +397,7 @@ static void pack_image(std::vector<uint16_t> &out, int n_tiles, int n_ksteps, Va
                     out.push_back(to_bf16(value(32 * n + (lane & 31), kk, order(kk, lane >> 5, j))));
 }
 
-int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, size_t offs[6])
+int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, size_t offs[8])
 {
     const int h = w.h_dim;
     if (h < 1 || h + 1 > kMlpHP || 8 + F > 15) return -1;
@@ -425,11 +444,21 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
         const int rr = row & 1;
         return k == h ? b[rr] : W[(size_t)rr * h + k];
     }, k_from_acc);
+    offs[6] = offs[7] = 0;
+    if (w.critic_w1) {
+        offs[6] = out.size() * 2;
+        pack_image(out, kMlpNT, kMlpKS, hidden(w.critic_w1, w.critic_b1), k_from_acc);
+        offs[7] = out.size() * 2;
+        pack_image(out, 1, kMlpKS, [&](int row, int, int k) -> float {
+            if (row > 0 || k > h) return 0.f;
+            return k == h ? w.critic_b2[0] : w.critic_w2[k];
+        }, k_from_acc);
+    }
     return 0;
 }
 
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
-                              float *pooled, float *mu, float *stdv, hipStream_t s)
+                              float *pooled, float *mu, float *stdv, float *value, hipStream_t s)
 {
     const dim3 grid((N + 4 * kWave - 1) / (4 * kWave));   // one workgroup per 4 groups of 64 envs
     const size_t lds = (size_t)(NT * KS + NT) * kWave * sizeof(uint4);
@@ -461,7 +490,7 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_head), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_head);
     hipLaunchKernelGGL(k_mlp_head, dim3((N + kHeadWaves * 32 - 1) / (kHeadWaves * 32)), dim3(kHeadWaves * kWave), lds_head, s,
-                       img, N, obs, pooled, mu, stdv);
+                       img, N, obs, pooled, mu, stdv, value);
     return hipGetLastError();
 }
 

@@ -26,16 +26,18 @@ struct MlpImages {
     const void *wc;     // [NT][KS+1]   combine_net_  A operand: KS steps accumulator order + 1 step obs
     const void *wa;     // [NT][KS]     actor.enc_.0.0  A operand, accumulator order
     const void *wh;     // [1][KS]      actor.mu_ / actor.std_ (rows 0-1 / 2-3), accumulator order
+    const void *wv1;    // [NT][KS]     critic.0 (null: no value head), accumulator order
+    const void *wv2;    // [1][KS]      critic.2 (row 0), accumulator order
 };
 
-// Packs the float32 state_dict tensors into one host buffer of fragments; offsets (in bytes) of the six
-// images are returned in `offs`.  h = hidden width (<= 191), F = zone features (6 or 7).
-int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, size_t offs[6]);
+// Packs the float32 state_dict tensors into one host buffer of fragments; offsets (in bytes) of the
+// images are returned in `offs` (the last two only when the critic tensors are given).  h = hidden width (<= 191), F = zone features (6 or 7).
+int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, size_t offs[8]);
 
 // obs [N,8], zone_obs [N,Z,F] float32 (device) -> mu, std [N,2] float32 (device).
 // pooled: scratch [N][kMlpHP] float32 (device).
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
-                              float *pooled, float *mu, float *stdv, hipStream_t s);
+                              float *pooled, float *mu, float *stdv, float *value, hipStream_t s);
 // actions[N,2] = mu (sample = 0) or mu + std * eps, eps ~ N(0,1) from Philox4x32-10 keyed by
 // (seed, global env, step) -- the reference's dist.sample() (utils/agent.py:41-44).
 hipError_t launch_mlp_action(int N, const float *mu, const float *stdv, int sample, uint64_t seed, uint64_t env_index0,

@@ -69,7 +69,7 @@ struct zenv {
     // actor network (zenv_mlp_load)
     void *mlp_mem = nullptr;
     MlpImages mlp{};
-    float *mlp_pooled = nullptr, *mlp_mu = nullptr, *mlp_std = nullptr;
+    float *mlp_pooled = nullptr, *mlp_mu = nullptr, *mlp_std = nullptr, *mlp_value = nullptr;
     bool mlp_ready = false;
 };
 
@@ -163,6 +163,7 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_ACTIONS: return { p.actions, N * 2 * 4 };
     case ZENV_F_POLICY_MU: return { h->mlp_mu, h->mlp_mu ? N * 2 * 4 : 0 };
     case ZENV_F_POLICY_STD: return { h->mlp_std, h->mlp_std ? N * 2 * 4 : 0 };
+    case ZENV_F_POLICY_VALUE: return { h->mlp_value, h->mlp_value ? N * 4 : 0 };
     default: return { nullptr, 0 };
     }
 }
@@ -363,7 +364,7 @@ extern "C" int zenv_destroy(zenv_t *h)
     for (void *m : h->bank_mem)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
-    for (void *m : { h->mlp_mem, (void *)h->mlp_pooled, (void *)h->mlp_mu, (void *)h->mlp_std })
+    for (void *m : { h->mlp_mem, (void *)h->mlp_pooled, (void *)h->mlp_mu, (void *)h->mlp_std, (void *)h->mlp_value })
         if (m) (void)hipFree(m);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -604,21 +605,29 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     for (const float *t : { w->zone_w1, w->zone_b1, w->zone_w2, w->zone_b2, w->zone_w3, w->zone_b3, w->comb_w, w->comb_b,
                             w->enc_w, w->enc_b, w->mu_w, w->mu_b, w->std_w, w->std_b })
         if (!t) return fail(ZENV_E_ARG, "zenv_mlp_weights has a null tensor");
+    const int n_critic = (w->critic_w1 != nullptr) + (w->critic_b1 != nullptr) + (w->critic_w2 != nullptr) +
+                         (w->critic_b2 != nullptr);
+    if (n_critic != 0 && n_critic != 4) return fail(ZENV_E_ARG, "give all four critic tensors or none");
     std::vector<uint16_t> img;
-    size_t offs[6];
+    size_t offs[8];
     if (pack_images(*w, h->p.F, img, offs) != 0)
         return fail(ZENV_E_ARG, "h_dim %d outside [1, %d]", w->h_dim, kMlpHP - 1);
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t N = (size_t)h->n_env;
-    if (!h->mlp_mem) HIP_TRY(hipMalloc(&h->mlp_mem, img.size() * 2));
+    if (h->mlp_mem) HIP_TRY(hipFree(h->mlp_mem));   // its size depends on whether there is a critic
+    h->mlp_mem = nullptr;
+    HIP_TRY(hipMalloc(&h->mlp_mem, img.size() * 2));
+    if (!h->mlp_value) HIP_TRY(hipMalloc((void **)&h->mlp_value, N * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(h->mlp_value, 0, N * sizeof(float), h->stream));
     if (!h->mlp_pooled) HIP_TRY(hipMalloc((void **)&h->mlp_pooled, N * kMlpHP * sizeof(float)));
     if (!h->mlp_mu) HIP_TRY(hipMalloc((void **)&h->mlp_mu, N * 2 * sizeof(float)));
     if (!h->mlp_std) HIP_TRY(hipMalloc((void **)&h->mlp_std, N * 2 * sizeof(float)));
     HIP_TRY(hipMemcpy(h->mlp_mem, img.data(), img.size() * 2, hipMemcpyHostToDevice));
     const char *base = static_cast<const char *>(h->mlp_mem);
-    h->mlp = MlpImages{ base + offs[0], base + offs[1], base + offs[2], base + offs[3], base + offs[4], base + offs[5] };
+    h->mlp = MlpImages{ base + offs[0], base + offs[1], base + offs[2], base + offs[3], base + offs[4], base + offs[5],
+                        n_critic ? base + offs[6] : nullptr, n_critic ? base + offs[7] : nullptr };
     h->mlp_ready = true;
     return ZENV_OK;
 }
@@ -631,7 +640,7 @@ extern "C" int zenv_mlp_forward(zenv_t *h)
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
-                               h->mlp_std, h->stream));
+                               h->mlp_std, h->mlp_value, h->stream));
     return ZENV_OK;
 }
 
@@ -647,7 +656,7 @@ static int run_policy(zenv_t *h, const StepPolicy &pol)
     }
     if (!h->mlp_ready) return fail(ZENV_E_STATE, "zenv_mlp_load first");
     HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
-                               h->mlp_std, h->stream));
+                               h->mlp_std, h->mlp_value, h->stream));
     HIP_TRY(launch_mlp_action(h->n_env, h->mlp_mu, h->mlp_std, pol.policy == ZENV_POLICY_MLP_SAMPLE, pol.seed,
                               pol.env_index0, pol.step_index, pol.out, h->stream));
     return ZENV_OK;

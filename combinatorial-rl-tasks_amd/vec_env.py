@@ -20,6 +20,7 @@ _FIELD_DTYPES = {
     nat.F_EP_LEN: np.int32, nat.F_LAST_RETURN: np.float64, nat.F_LAST_LEN: np.int32,
     nat.F_EPISODES: np.int32, nat.F_VISIT_COUNT: np.int32, nat.F_SEED: np.int64,
     nat.F_ACTIONS: np.float32, nat.F_POLICY_MU: np.float32, nat.F_POLICY_STD: np.float32,
+    nat.F_POLICY_VALUE: np.float32,
 }
 
 
@@ -59,6 +60,9 @@ def mlp_tensors_from_state_dict(sd):
              "enc_w": "actor.enc_.0.0.weight", "enc_b": "actor.enc_.0.0.bias",
              "mu_w": "actor.mu_.weight", "mu_b": "actor.mu_.bias",
              "std_w": "actor.std_.weight", "std_b": "actor.std_.bias"}
+    if "critic.0.weight" in sd and "critic.2.weight" in sd:      # non-distributional critic, flat_model.py:43-47
+        names.update({"critic_w1": "critic.0.weight", "critic_b1": "critic.0.bias",
+                      "critic_w2": "critic.2.weight", "critic_b2": "critic.2.bias"})
     return {k: np.asarray(sd[v].detach().cpu().numpy() if hasattr(sd[v], "detach") else sd[v], np.float32)
             for k, v in names.items()}
 
@@ -216,10 +220,13 @@ class ZoneVecEnv:
         h = int(np.asarray(tensors["zone_b1"]).shape[0])
         want = {"zone_w1": (h, 8 + F), "zone_b1": (h,), "zone_w2": (h, h), "zone_b2": (h,), "zone_w3": (h, h),
                 "zone_b3": (h,), "comb_w": (h, 8 + h), "comb_b": (h,), "enc_w": (h, h), "enc_b": (h,),
-                "mu_w": (2, h), "mu_b": (2,), "std_w": (2, h), "std_b": (2,)}
+                "mu_w": (2, h), "mu_b": (2,), "std_w": (2, h), "std_b": (2,),
+                "critic_w1": (h, h), "critic_b1": (h,), "critic_w2": (1, h), "critic_b2": (1,)}
         keep = {}
         w = nat.MlpWeights(h_dim=h)
-        for name in nat.MLP_TENSORS:
+        names = nat.MLP_TENSORS + (nat.MLP_CRITIC_TENSORS if "critic_w1" in tensors else ())
+        self._mlp_has_critic = "critic_w1" in tensors
+        for name in names:
             a = np.ascontiguousarray(tensors[name], np.float32)
             if a.shape != want[name]:
                 raise ValueError(f"{name}: shape {a.shape}, expected {want[name]}")
@@ -227,10 +234,16 @@ class ZoneVecEnv:
             setattr(w, name, a.ctypes.data)
         check(lib().zenv_mlp_load(self._h, C.byref(w)))
 
-    def mlp_forward(self):
-        """(mu, std) float32 [N,2] of the actor's Normal for the current observations."""
+    def mlp_forward(self, with_value=False):
+        """(mu, std) float32 [N,2] of the actor's Normal for the current observations; with_value: also
+        the critic's value float32 [N] (needs the critic tensors in load_mlp)."""
         check(lib().zenv_mlp_forward(self._h))
-        return self.get(nat.F_POLICY_MU), self.get(nat.F_POLICY_STD)
+        out = (self.get(nat.F_POLICY_MU), self.get(nat.F_POLICY_STD))
+        if with_value:
+            if not getattr(self, "_mlp_has_critic", False):
+                raise ValueError("load_mlp was called without critic tensors")
+            out += (self.get(nat.F_POLICY_VALUE),)
+        return out
 
     def sync(self):
         check(lib().zenv_sync(self._h))

@@ -60,6 +60,7 @@ enum {
     ZENV_F_ACTIONS = 12,    /* float32 [N,2]   internal action buffer (zenv_policy target) */
     ZENV_F_POLICY_MU = 13,  /* float32 [N,2]   mean of the actor's Normal (after zenv_mlp_forward) */
     ZENV_F_POLICY_STD = 14, /* float32 [N,2]   its standard deviation */
+    ZENV_F_POLICY_VALUE = 15, /* float32 [N]   the critic's value (when critic weights were loaded) */
     ZENV_F_COUNT = 13
 };
 
@@ -192,10 +193,13 @@ typedef struct zenv_mlp_weights {
     const float *enc_w, *enc_b;     /* actor.enc_.0.0         [h, h],   [h] */
     const float *mu_w, *mu_b;       /* actor.mu_              [2, h],   [2] */
     const float *std_w, *std_b;     /* actor.std_             [2, h],   [2] */
+    /* critic of flat_model.ACModel (:43-47, non-distributional): all four NULL = no value head */
+    const float *critic_w1, *critic_b1; /* critic.0           [h, h],   [h] */
+    const float *critic_w2, *critic_b2; /* critic.2           [1, h],   [1] */
 } zenv_mlp_weights;
 int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w);
 /* mu = 2 (sigmoid(mu_(x)) - 0.5), std = sigmoid(std_(x)) + 1e-3 of the current observations into
- * ZENV_F_POLICY_MU / ZENV_F_POLICY_STD.  zenv_policy() / zenv_rollout() with ZENV_POLICY_MLP_* call it
+ * ZENV_F_POLICY_MU / ZENV_F_POLICY_STD (and value = critic(x) into ZENV_F_POLICY_VALUE).  zenv_policy() / zenv_rollout() with ZENV_POLICY_MLP_* call it
  * and turn it into actions (rollouts then run one launch sequence per step). */
 int zenv_mlp_forward(zenv_t *h);
 

@@ -17,7 +17,7 @@ TENSORS = ("zone_w1", "zone_b1", "zone_w2", "zone_b2", "zone_w3", "zone_b3", "co
            "enc_w", "enc_b", "mu_w", "mu_b", "std_w", "std_b")
 
 
-def random_tensors(F, h=185, seed=0, bias_scale=0.1):
+def random_tensors(F, h=185, seed=0, bias_scale=0.1, critic=False):
     """Weights drawn like flat_model.init_params (:13-19: rows of N(0,1) normalised to unit norm); the
     biases, zero there, get small random values so that the bias path is exercised."""
     g = torch.Generator().manual_seed(seed)
@@ -34,6 +34,9 @@ def random_tensors(F, h=185, seed=0, bias_scale=0.1):
     t["enc_w"], t["enc_b"] = lin(h, h)
     t["mu_w"], t["mu_b"] = lin(2, h)
     t["std_w"], t["std_b"] = lin(2, h)
+    if critic:
+        t["critic_w1"], t["critic_b1"] = lin(h, h)          # flat_model.py:43-47
+        t["critic_w2"], t["critic_b2"] = lin(1, h)
     return {k: v.numpy().astype(np.float32) for k, v in t.items()}
 
 
@@ -52,6 +55,9 @@ def forward_fp32(t, obs, zone_obs):
     a = torch.relu(emb @ t["enc_w"].T + t["enc_b"])                                  # policy_network.py:48
     mu = 2 * (torch.sigmoid(a @ t["mu_w"].T + t["mu_b"]) - 0.5)                      # :49
     std = torch.sigmoid(a @ t["std_w"].T + t["std_b"]) + 1e-3                        # :50
+    if "critic_w1" in t:                                                             # flat_model.py:62-64
+        v = (torch.relu(emb @ t["critic_w1"].T + t["critic_b1"]) @ t["critic_w2"].T + t["critic_b2"]).squeeze(1)
+        return mu.numpy(), std.numpy(), v.numpy()
     return mu.numpy(), std.numpy()
 
 
@@ -76,4 +82,8 @@ def forward_bf16_emulated(t, obs, zone_obs):
     a = _bf(torch.relu(c @ t["enc_w"].T + t["enc_b"]).float()).double()
     mu = 2 * (torch.sigmoid((a @ t["mu_w"].T + t["mu_b"]).float()) - 0.5)
     std = torch.sigmoid((a @ t["std_w"].T + t["std_b"]).float()) + 1e-3
+    if "critic_w1" in t:
+        v1 = _bf(torch.relu(c @ t["critic_w1"].T + t["critic_b1"]).float()).double()
+        v = (v1 @ t["critic_w2"].T + t["critic_b2"]).float().squeeze(1)
+        return mu.numpy(), std.numpy(), v.numpy()
     return mu.numpy(), std.numpy()

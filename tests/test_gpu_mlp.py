@@ -39,6 +39,29 @@ def test_mlp_forward_matches_torch(zenv_mod, env_id, n, steps):
     env.close()
 
 
+def test_mlp_value_head(zenv_mod):
+    """The critic of ACModel (flat_model.py:43-47,62-64) from the same embedding; mu / std unchanged by it."""
+    from oracle import policy_ref as P
+    Z = zenv_mod
+    env = _env_with_obs(Z, "PointTSP-v0", 300, 30)
+    t = P.random_tensors(6, seed=5, critic=True)
+    env.load_mlp(t)
+    mu, std, val = env.mlp_forward(with_value=True)
+    obs, zo = env.observations()
+    mu_e, std_e, val_e = P.forward_bf16_emulated(t, obs, zo)
+    mu_r, std_r, val_r = P.forward_fp32(t, obs, zo)
+    assert val.shape == (300,) and np.abs(val_r).max() > 0.05
+    assert np.abs(val - val_e).max() < 4e-3 and np.abs(val - val_r).max() < 4e-2
+    assert np.abs(mu - mu_e).max() < 4e-3 and np.abs(std - std_e).max() < 4e-3
+    t2 = {k: v for k, v in t.items() if not k.startswith("critic")}
+    env.load_mlp(t2)                                    # reload without a critic
+    mu2, std2 = env.mlp_forward()
+    assert np.array_equal(mu, mu2) and np.array_equal(std, std2)
+    with pytest.raises(ValueError):
+        env.mlp_forward(with_value=True)
+    env.close()
+
+
 def test_mlp_other_widths_and_zone_counts(zenv_mod):
     """h_dim below the padded width and zone counts without a compile-time instantiation."""
     from oracle import policy_ref as P
