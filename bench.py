@@ -271,10 +271,16 @@ def cpu_baseline(cfg, task, zones, keepout, policy):
     t0 = time.perf_counter()
     r = O.rollout(ocfg, seeds, T, policy, seed_stride=65536, policy_seed=0x5EED, n_threads=cores)
     dt = time.perf_counter() - t0
+    # one core (the single-env loop evaluate.py runs; the mujoco-py original is absent)
+    t1 = time.perf_counter()
+    r1 = O.rollout(ocfg, seeds[:1024], 1000, policy, seed_stride=65536, policy_seed=0x5EED, n_threads=1)
+    dt1 = time.perf_counter() - t1
     return {"value": round(r["total_steps"] / dt, 1), "unit": "env-steps/s", "cores": cores,
             "kind": "port",
             "sample": f"first {n} envs x {T} steps of the same workload, OpenMP over envs, "
-                      f"{dt:.2f}s wall"}
+                      f"{dt:.2f}s wall",
+            "one_core_value": round(r1["total_steps"] / dt1, 1),
+            "one_core_sample": f"1024 envs x 1000 steps on 1 thread, {dt1:.2f}s wall"}
 
 
 def per_step_rate(env, task, zones, policy, shard, steps=2000):
