@@ -164,7 +164,7 @@ void orc_sincos(double x, double *s_out, double *c_out)
     r = FMA(-fn, P2, r);
     r = FMA(-fn, P3, r);
     r = FMA(-fn, P3T, r);
-    int64_t n = (int64_t)fn;
+    int32_t n = (int32_t)fn;   /* |x| < 2^31 * pi/2; one v_cvt_i32_f64 on the GPU */
 
     double z = r * r;
     double ps = FMA(z, S6, S5);
