@@ -48,6 +48,16 @@ struct DevParams {
     uint8_t *done_state;
     double *ep_return, *last_return;
     int32_t *last_len, *episodes, *visit_count;
+    // goal-conditioned variant (TSP_next_city_env.py), null unless zenv_goal_enable(): the zone visited this
+    // step (-1: none) and the post-physics world position of an env whose episode ended in this step
+    int32_t *visit_zone;
+    double2 *term_xy;
+    int32_t *goal;          // goal zone, -1 = none (needs one)
+    double *goal_last;      // last_dist_to_goal
+    double2 *goal_xy;       // the goal zone's centre (survives the auto-reset of the zone arrays)
+    double *shaped;         // info['shaped_reward']
+    uint8_t *need_goal;     // info['need_next_goal']
+    uint32_t *available;    // get_available_goals() as a bit mask
     int64_t *seed;
     // schedule
     int32_t *slot_first, *episode_idx;

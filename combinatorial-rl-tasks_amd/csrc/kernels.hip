@@ -1029,7 +1029,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 if (lane == j) {
                     e = fresh;
                     ep_ret = 0.0;
-                    mode = 1;
+                    mode = 2;   // superseded by the reset (the physics wave keeps the terminal position)
                     p.seed[env] = p.bank_seed[slot];
                     store_frame(p, env, e);
                     store_dyn(p, env, e);
@@ -1047,6 +1047,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             }
             xmode[lane] = mode;
             xstep[lane] = e.steps;
+            if (p.visit_zone) p.visit_zone[env] = first;
             p.reward[env] = rew_out;
             p.done_out[env] = done_out;
             p.goal_met[env] = goal_out;
@@ -1097,6 +1098,10 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             // fused K3: the action of the NEXT step, from this step's obs and the entries in LDS
             if (pol.policy >= 0)
                 reinterpret_cast<float2 *>(pol.out)[env] = scripted_action<TASK, ZT>(pol, env, my_ents, Z, o);
+        } else if (xmode[lane] == 2 && p.term_xy) {
+            double tx, ty;
+            world_pos(e, tx, ty);           // where the finished episode ended (TSP_next_city_env.py:63-66)
+            p.term_xy[env] = make_double2(tx, ty);
         }
         ZSTAMP(13);
     }
@@ -1748,6 +1753,86 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
     }
 }
 
+// =========================================================================== K6: goal shaping
+// TSPNextCityEnv / TimedTSPNextCityEnv (main/envs/zone_envs/TSP_next_city_env.py:41-109,
+// zone-goals/envs/TTSP_next_city_env.py:40-51): a goal zone per env, a dense reward towards it and the
+// request for the next goal.  Runs right after the step kernel, which leaves the zone visited in this
+// step and -- for an env that was auto-reset -- the position where the episode ended.
+__global__ __launch_bounds__(256) void k_goal_set(DevParams p, const int32_t *__restrict__ new_goal, int32_t *bad)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.N) return;
+    const int g = new_goal[env];
+    if (g < 0) return;                                         // leave this env's goal alone
+    if (g >= p.Z || ((p.vis[env] >> g) & 1u)) {                // set_goal asserts the zone is unvisited (:86)
+        atomicAdd(bad, 1);
+        return;
+    }
+    EnvRegs e;
+    const double2 qa = p.qa[env], fa = p.fa[env], fb = p.fb[env];
+    e.q0 = qa.x; e.q1 = qa.y; e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
+    double rx, ry;
+    world_pos(e, rx, ry);
+    const double2 zz = p.zxy[(size_t)g * p.N + env];
+    const double dx = zz.x - rx, dy = zz.y - ry;
+    p.goal[env] = g;
+    p.goal_xy[env] = zz;
+    p.goal_last[env] = sqrt(dx * dx + dy * dy);                // dist_to_goal, :41-45
+    p.need_goal[env] = 0;
+}
+
+// reset(): the env has no goal yet (goal_zone = None), every zone is available
+__global__ __launch_bounds__(256) void k_goal_clear(DevParams p, const uint8_t *__restrict__ mask)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.N || (mask && !mask[env])) return;
+    p.goal[env] = -1;
+    p.need_goal[env] = 1;
+    p.shaped[env] = 0.0;
+    p.visit_zone[env] = -1;
+    p.available[env] = (p.Z >= 32) ? 0xFFFFFFFFu : ((1u << p.Z) - 1u);
+}
+
+__global__ __launch_bounds__(256) void k_goal_step(DevParams p)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.N) return;
+    const uint32_t full = (p.Z >= 32) ? 0xFFFFFFFFu : ((1u << p.Z) - 1u);
+    const int g = p.goal[env];
+    const bool done = p.done_out[env] != 0;
+    double sh = 0.0;
+    uint8_t need = g < 0;
+    if (g >= 0) {
+        const bool reached = p.visit_zone[env] == g;           // new_city_reached and zones[goal] == visited
+        if (!reached) {
+            double rx, ry;
+            if (done && !p.done_state[env]) {                  // auto-reset happened: the terminal position
+                const double2 t = p.term_xy[env];
+                rx = t.x; ry = t.y;
+            } else {
+                EnvRegs e;
+                const double2 qa = p.qa[env], fa = p.fa[env], fb = p.fb[env];
+                e.q0 = qa.x; e.q1 = qa.y; e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
+                world_pos(e, rx, ry);
+            }
+            // the goal zone's centre is kept beside the goal: after an auto-reset the zone arrays already
+            // hold the next map
+            const double2 zz = p.goal_xy[env];
+            const double dx = zz.x - rx, dy = zz.y - ry;
+            const double d = sqrt(dx * dx + dy * dy);
+            sh = p.goal_last[env] - d;                         // :63-66
+            p.goal_last[env] = d;
+        }
+        if (reached || done) {                                 // :69-72, TTSP_next_city_env.py:46-49
+            need = 1;
+            p.goal[env] = -1;
+        }
+    }
+    p.shaped[env] = sh;
+    p.need_goal[env] = need;
+    p.available[env] = ~p.vis[env] & full;                     // get_available_goals, :92-100
+}
+
 // =========================================================================== K2: reset
 template <int TASK>
 __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t *__restrict__ mask)
@@ -1855,6 +1940,24 @@ hipError_t launch_rollout(const DevParams &p, int n_steps, int auto_reset, const
     case ZENV_TASK_TIMED_TSP: launch_rollout_task<ZENV_TASK_TIMED_TSP>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop); break;
     default: launch_rollout_task<ZENV_TASK_COLOUR_MATCH>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_goal_set(const DevParams &p, const int32_t *new_goal, int32_t *bad, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_goal_set, dim3((p.N + 255) / 256), dim3(256), 0, s, p, new_goal, bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_goal_clear(const DevParams &p, const uint8_t *mask, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_goal_clear, dim3((p.N + 255) / 256), dim3(256), 0, s, p, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_goal_step(const DevParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_goal_step, dim3((p.N + 255) / 256), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -29,6 +29,10 @@ bool rollout_kernel_available(const DevParams &p);
 hipError_t launch_rollout(const DevParams &p, int n_steps, int auto_reset, const StepPolicy &pol, hipStream_t s,
                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t launch_reset(const DevParams &p, const uint8_t *mask, hipStream_t s);
+// goal-conditioned variant: set goals (new_goal[N], -1 = keep; *bad counts rejected ones) / per-step shaping
+hipError_t launch_goal_set(const DevParams &p, const int32_t *new_goal, int32_t *bad, hipStream_t s);
+hipError_t launch_goal_step(const DevParams &p, hipStream_t s);
+hipError_t launch_goal_clear(const DevParams &p, const uint8_t *mask, hipStream_t s);
 hipError_t launch_policy(const DevParams &p, const StepPolicy &pol, hipStream_t s);
 
 }  // namespace zenvk

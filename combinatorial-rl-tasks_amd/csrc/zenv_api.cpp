@@ -71,6 +71,9 @@ struct zenv {
     MlpImages mlp{};
     float *mlp_pooled = nullptr, *mlp_mu = nullptr, *mlp_std = nullptr, *mlp_value = nullptr;
     bool mlp_ready = false;
+    // goal-conditioned variant (zenv_goal_enable)
+    bool goal_enabled = false;
+    int32_t *goal_in = nullptr, *goal_bad = nullptr;
 };
 
 namespace {
@@ -164,6 +167,10 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_POLICY_MU: return { h->mlp_mu, h->mlp_mu ? N * 2 * 4 : 0 };
     case ZENV_F_POLICY_STD: return { h->mlp_std, h->mlp_std ? N * 2 * 4 : 0 };
     case ZENV_F_POLICY_VALUE: return { h->mlp_value, h->mlp_value ? N * 4 : 0 };
+    case ZENV_F_SHAPED_REWARD: return { p.shaped, p.shaped ? N * 8 : 0 };
+    case ZENV_F_NEED_GOAL: return { p.need_goal, p.need_goal ? N : 0 };
+    case ZENV_F_AVAILABLE_GOALS: return { p.available, p.available ? N * 4 : 0 };
+    case ZENV_F_GOAL: return { p.goal, p.goal ? N * 4 : 0 };
     default: return { nullptr, 0 };
     }
 }
@@ -364,7 +371,10 @@ extern "C" int zenv_destroy(zenv_t *h)
     for (void *m : h->bank_mem)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
-    for (void *m : { h->mlp_mem, (void *)h->mlp_pooled, (void *)h->mlp_mu, (void *)h->mlp_std, (void *)h->mlp_value })
+    for (void *m : { h->mlp_mem, (void *)h->mlp_pooled, (void *)h->mlp_mu, (void *)h->mlp_std, (void *)h->mlp_value,
+                     (void *)h->p.visit_zone, (void *)h->p.term_xy, (void *)h->p.goal, (void *)h->p.goal_last,
+                     (void *)h->p.goal_xy, (void *)h->p.shaped, (void *)h->p.need_goal, (void *)h->p.available,
+                     (void *)h->goal_in, (void *)h->goal_bad })
         if (m) (void)hipFree(m);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -574,6 +584,7 @@ extern "C" int zenv_reset(zenv_t *h, const uint8_t *mask)
         dmask = h->d_mask;
     }
     HIP_TRY(launch_reset(h->p, dmask, h->stream));
+    if (h->goal_enabled) HIP_TRY(launch_goal_clear(h->p, dmask, h->stream));
     h->was_reset = true;
     return ZENV_OK;
 }
@@ -594,7 +605,54 @@ extern "C" int zenv_step(zenv_t *h, const float *actions, int actions_on_device,
         }
     }
     HIP_TRY(launch_step(h->p, d_act, auto_reset, no_policy(), h->stream));
+    if (h->goal_enabled) HIP_TRY(launch_goal_step(h->p, h->stream));
     h->step_count += 1;
+    return ZENV_OK;
+}
+
+// ============================================================================ goal-conditioned variant
+extern "C" int zenv_goal_enable(zenv_t *h)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (h->cfg.task == ZENV_TASK_COLOUR_MATCH) return fail(ZENV_E_ARG, "goal-conditioned variant: TSP and TimedTSP only");
+    if (h->goal_enabled) return ZENV_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t N = (size_t)h->n_env;
+    DevParams &p = h->p;
+    HIP_TRY(hipMalloc((void **)&p.visit_zone, N * 4));
+    HIP_TRY(hipMalloc((void **)&p.term_xy, N * 16));
+    HIP_TRY(hipMalloc((void **)&p.goal, N * 4));
+    HIP_TRY(hipMalloc((void **)&p.goal_last, N * 8));
+    HIP_TRY(hipMalloc((void **)&p.goal_xy, N * 16));
+    HIP_TRY(hipMalloc((void **)&p.shaped, N * 8));
+    HIP_TRY(hipMalloc((void **)&p.need_goal, N));
+    HIP_TRY(hipMalloc((void **)&p.available, N * 4));
+    HIP_TRY(hipMalloc((void **)&h->goal_in, N * 4));
+    HIP_TRY(hipMalloc((void **)&h->goal_bad, 4));
+    HIP_TRY(hipMemsetAsync(p.term_xy, 0, N * 16, h->stream));
+    HIP_TRY(hipMemsetAsync(p.goal_last, 0, N * 8, h->stream));
+    HIP_TRY(hipMemsetAsync(p.goal_xy, 0, N * 16, h->stream));
+    HIP_TRY(launch_goal_clear(p, nullptr, h->stream));
+    h->goal_enabled = true;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_set_goals(zenv_t *h, const int32_t *goals)
+{
+    if (!h || !goals) return fail(ZENV_E_ARG, "null argument");
+    if (!h->goal_enabled) return fail(ZENV_E_STATE, "zenv_goal_enable first");
+    if (!h->was_reset) return fail(ZENV_E_STATE, "reset before setting goals");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->goal_in, goals, sizeof(int32_t) * (size_t)h->n_env, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->goal_bad, 0, 4, h->stream));
+    HIP_TRY(launch_goal_set(h->p, h->goal_in, h->goal_bad, h->stream));
+    int32_t bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, h->goal_bad, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (bad) return fail(ZENV_E_ARG, "%d goal zone(s) out of range or already visited", bad);
     return ZENV_OK;
 }
 
@@ -684,6 +742,7 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     if (steps < 0) return fail(ZENV_E_ARG, "steps must be >= 0");
     if (!policy_known(policy)) return fail(ZENV_E_ARG, "unknown policy %d", policy);
     if (policy_is_mlp(policy) && !h->mlp_ready) return fail(ZENV_E_STATE, "zenv_mlp_load first");
+    if (h->goal_enabled) return fail(ZENV_E_STATE, "goal-conditioned envs are stepped with zenv_step");
     int rc = use_device(h);
     if (rc) return rc;
     // the actor network is its own launch sequence: policy, then step, every step

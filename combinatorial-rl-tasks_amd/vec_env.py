@@ -20,7 +20,8 @@ _FIELD_DTYPES = {
     nat.F_EP_LEN: np.int32, nat.F_LAST_RETURN: np.float64, nat.F_LAST_LEN: np.int32,
     nat.F_EPISODES: np.int32, nat.F_VISIT_COUNT: np.int32, nat.F_SEED: np.int64,
     nat.F_ACTIONS: np.float32, nat.F_POLICY_MU: np.float32, nat.F_POLICY_STD: np.float32,
-    nat.F_POLICY_VALUE: np.float32,
+    nat.F_POLICY_VALUE: np.float32, nat.F_SHAPED_REWARD: np.float64, nat.F_NEED_GOAL: np.uint8,
+    nat.F_AVAILABLE_GOALS: np.uint32, nat.F_GOAL: np.int32,
 }
 
 
@@ -210,6 +211,24 @@ class ZoneVecEnv:
                                  flags, int(event_stride), C.byref(total),
                                  C.byref(kern) if time_step_kernel else None))
         return total.value, (kern.value if time_step_kernel else None)
+
+    # ------------------------------------------------------------------ goal-conditioned variant (8(f) row 3)
+    def enable_goals(self):
+        """TSPNextCityEnv / TimedTSPNextCityEnv semantics (TSP_next_city_env.py:41-109): after this every
+        ``step`` also yields shaped_reward / need_next_goal / available goals, see ``goal_info``."""
+        check(lib().zenv_goal_enable(self._h))
+
+    def set_goals(self, goals):
+        """goals: int32 [N], -1 = leave that env's goal alone (penv.py:76-80 set_goal, batched)."""
+        g = np.ascontiguousarray(goals, np.int32)
+        if g.shape != (self.num_envs,):
+            raise ValueError(f"goals must have shape ({self.num_envs},)")
+        check(lib().zenv_set_goals(self._h, g.ctypes.data))
+
+    def goal_info(self):
+        """(shaped_reward float64 [N], need_next_goal bool [N], available uint32 bit masks [N], goal int32 [N])."""
+        return (self.get(nat.F_SHAPED_REWARD), self.get(nat.F_NEED_GOAL).astype(bool), self.get(nat.F_AVAILABLE_GOALS),
+                self.get(nat.F_GOAL))
 
     # ------------------------------------------------------------------ actor network (SURVEY 8(f) row 1)
     def load_mlp(self, tensors):

@@ -61,6 +61,11 @@ enum {
     ZENV_F_POLICY_MU = 13,  /* float32 [N,2]   mean of the actor's Normal (after zenv_mlp_forward) */
     ZENV_F_POLICY_STD = 14, /* float32 [N,2]   its standard deviation */
     ZENV_F_POLICY_VALUE = 15, /* float32 [N]   the critic's value (when critic weights were loaded) */
+    /* goal-conditioned variant, after zenv_goal_enable(): */
+    ZENV_F_SHAPED_REWARD = 16,   /* float64 [N] info['shaped_reward'] (TSP_next_city_env.py:60-66) */
+    ZENV_F_NEED_GOAL = 17,       /* uint8   [N] info['need_next_goal'] / env.goal_zone is None (:69-75) */
+    ZENV_F_AVAILABLE_GOALS = 18, /* uint32  [N] get_available_goals() as a bit mask, bit z = zone z unvisited */
+    ZENV_F_GOAL = 19,            /* int32   [N] goal zone, -1 = none */
     ZENV_F_COUNT = 13
 };
 
@@ -177,6 +182,18 @@ int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0
 int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
                  int auto_reset, int flags, int event_stride, float *ms_total,
                  float *ms_step_kernel_avg);
+
+/* ---- goal-conditioned variant: TSPNextCityEnv, main/envs/zone_envs/
+ * TSP_next_city_env.py:41-109, and TimedTSPNextCityEnv, zone-goals/envs/TTSP_next_city_env.py:40-51, as the
+ * vector calls of zone-goals/src/torch_ac/torch_utils/penv.py:76-99 (set_goal / needs_goal / available_goals).
+ * TSP and TimedTSP handles only.  After zenv_goal_enable() every env needs a goal (ZENV_F_NEED_GOAL = 1);
+ * zenv_set_goals() takes int32 goals[N] from the host (-1 = leave that env alone) and fails with ZENV_E_ARG
+ * when a goal zone is already visited (set_goal's assert, :86); every zenv_step() then also produces
+ * shaped_reward = last_dist_to_goal - dist_to_goal (0 in the step that reaches the goal), need_next_goal
+ * (goal reached, or episode over) and the available-goals mask.  zenv_rollout() is refused on such a handle;
+ * the goal arrays are not part of zenv_get_state(). */
+int zenv_goal_enable(zenv_t *h);
+int zenv_set_goals(zenv_t *h, const int32_t *goals);
 
 /* ---- the reference's actor network on the device ----
  * ZoneEnvModel (main/src/env_model.py:48-79) + the actor of ACModel (flat_model.py:24-37,

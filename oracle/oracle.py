@@ -68,6 +68,7 @@ class Env(C.Structure):
         ("cooldown", C.c_int32 * MAX_Z),
         ("goal_dist", C.c_int32), ("steps", C.c_int32), ("done", C.c_int32),
         ("layout_restarts", C.c_int32),
+        ("goal_zone", C.c_int32), ("last_visit", C.c_int32), ("last_dist", C.c_double),
     ]
 
 
@@ -112,6 +113,9 @@ def lib():
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]
         L.orc_rollout.restype = C.c_int64
+        L.orc_set_goal.argtypes = [C.POINTER(Env), C.c_int]
+        L.orc_step_goal.argtypes = [C.POINTER(Env), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.orc_rollout_wrapped.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.c_int64, C.c_int32, C.c_uint64, C.c_uint64, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -184,6 +188,22 @@ class OracleEnv:
         if rc != 0:
             raise AssertionError("Environment must be reset before stepping")
         return r.value, bool(d.value), bool(g.value)
+
+    # goal-conditioned variant (TSP_next_city_env.py)
+    def set_goal(self, goal):
+        if lib().orc_set_goal(C.byref(self.e), int(goal)) != 0:
+            raise AssertionError("goal zone must be unvisited")
+
+    def step_goal(self, action):
+        a = (C.c_float * 2)(float(action[0]), float(action[1]))
+        r, d, g, sh, nd = C.c_double(), C.c_int(), C.c_int(), C.c_double(), C.c_int()
+        rc = lib().orc_step_goal(C.byref(self.e), a, C.byref(r), C.byref(d), C.byref(g), C.byref(sh), C.byref(nd))
+        if rc != 0:
+            raise AssertionError("no goal set" if rc == -2 else "Environment must be reset before stepping")
+        return r.value, bool(d.value), bool(g.value), sh.value, bool(nd.value)
+
+    def available_goals(self):
+        return np.array([not self.e.visited[z] for z in range(self.Z)], bool)
 
     def obs(self):
         o = np.empty(8, np.float32)

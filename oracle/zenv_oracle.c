@@ -307,6 +307,8 @@ int orc_reset(orc_env *e, const orc_config *cfg, int64_t seed)
     if (cfg->num_zones < 1 || cfg->num_zones > ORC_MAX_Z) return -2;
     memset(e, 0, sizeof(*e));
     e->cfg = *cfg;
+    e->goal_zone = -1;
+    e->last_visit = -1;
     e->seed = seed;
     int Z = cfg->num_zones;
     orc_rs rs;
@@ -399,6 +401,7 @@ int orc_step(orc_env *e, const float action[2], double *reward, int *done, int *
     const int Z = c->num_zones;
     if (e->done) return -1; /* 'Environment must be reset before stepping' */
     int event = 0;
+    e->last_visit = -1;
     *goal_met = 0;
 
     /* colour_match_env.py:98-100: cooldowns tick before anything else */
@@ -421,6 +424,7 @@ int orc_step(orc_env *e, const float action[2], double *reward, int *done, int *
                 e->visited[z] = 1;
             }
             event = 1;
+            e->last_visit = z;
             break;
         }
     }
@@ -467,6 +471,45 @@ int orc_step(orc_env *e, const float action[2], double *reward, int *done, int *
     }
     *reward = r;
     *done = e->done;
+    return 0;
+}
+
+/* ---- goal-conditioned variant ---- */
+static double dist_to_goal(const orc_env *e)
+{
+    /* TSP_next_city_env.py:41-45: sqrt(sum(square(goal_pos - robot_pos))) on the current world position */
+    double dx = e->zone_xy[e->goal_zone][0] - e->xpos[0], dy = e->zone_xy[e->goal_zone][1] - e->xpos[1];
+    return sqrt(dx * dx + dy * dy);
+}
+
+int orc_set_goal(orc_env *e, int goal)
+{
+    if (goal < 0 || goal >= e->cfg.num_zones || e->visited[goal]) return -1;   /* :86 */
+    e->goal_zone = goal;
+    e->last_dist = dist_to_goal(e);                                             /* :87-88 */
+    return 0;
+}
+
+int orc_step_goal(orc_env *e, const float action[2], double *reward, int *done, int *goal_met,
+                  double *shaped_reward, int *need_next_goal)
+{
+    if (e->goal_zone < 0) return -2;                                            /* :54 */
+    int rc = orc_step(e, action, reward, done, goal_met);
+    if (rc) return rc;
+    int reached = e->last_visit == e->goal_zone;    /* new_city_reached and zones[goal_zone] == visited */
+    if (reached) {
+        *shaped_reward = 0.0;                                                   /* :60-61 */
+    } else {
+        double d = dist_to_goal(e);
+        *shaped_reward = e->last_dist - d;                                      /* :63-66 */
+        e->last_dist = d;
+    }
+    if (reached || *done) {                                                     /* :69-72; TTSP_next_city_env.py:46-49 */
+        *need_next_goal = 1;
+        e->goal_zone = -1;
+    } else {
+        *need_next_goal = 0;
+    }
     return 0;
 }
 

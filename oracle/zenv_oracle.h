@@ -75,6 +75,10 @@ typedef struct orc_env {
     int32_t steps;
     int32_t done;
     int32_t layout_restarts;   /* diagnostics */
+    /* goal-conditioned variant (TSP_next_city_env.py) */
+    int32_t goal_zone;         /* -1 = None */
+    int32_t last_visit;        /* zone visited by the last step, -1 = none */
+    double last_dist;          /* last_dist_to_goal */
 } orc_env;
 
 /* ---- numpy-legacy RandomState restatement (exposed for pinning tests) ---- */
@@ -119,6 +123,14 @@ int64_t orc_rollout(const orc_config *cfg, int n_env, int n_steps, int policy,
                     uint64_t env_index0, int n_threads,
                     double *reward_sum, int32_t *episodes, double *last_return,
                     int32_t *last_len, float *final_obs8, float *final_zone_obs);
+
+/* ---- goal-conditioned variant: TSPNextCityEnv main/envs/zone_envs/TSP_next_city_env.py:41-109 and
+ * TimedTSPNextCityEnv zone-goals/envs/TTSP_next_city_env.py:40-51 (TSP / TimedTSP tasks) ----
+ * orc_set_goal: -1 when the zone is out of range or visited (set_goal's assert).  orc_step_goal: -2
+ * without a goal (step's assert); otherwise orc_step plus info['shaped_reward'] / info['need_next_goal']. */
+int orc_set_goal(orc_env *e, int goal);
+int orc_step_goal(orc_env *e, const float action[2], double *reward, int *done, int *goal_met,
+                  double *shaped_reward, int *need_next_goal);
 
 /* Same, with a bank of seed_period maps per env replayed in order: episode k uses seed
  * seeds0[i] + (k % seed_period)*seed_stride (seed_period = 0: no wrap). */

@@ -368,3 +368,63 @@ def test_rim_zones_take_the_exact_path(zenv_mod, oracle_mod, task):
                 assert np.array_equal(zo[i], zo_ref) and np.array_equal(o[i], o_ref)
     assert seen_inside > 4 * n        # about half of the rim zones are inside
     env.close()
+
+
+@pytest.mark.parametrize("env_id", ["PointTSP-v0", "PointTTSP-v0"])
+def test_goal_conditioned_variant_lockstep(zenv_mod, oracle_mod, env_id):
+    """TSPNextCityEnv / TimedTSPNextCityEnv (TSP_next_city_env.py:41-109): goal zone per
+    env, shaped_reward, need_next_goal, available goals -- in lock step with the oracle, with auto-reset and
+    a high-level 'policy' that picks a random available zone whenever one is needed."""
+    Z, O = zenv_mod, oracle_mod
+    n, T = 150, 260
+    cfg = Z.config_for_id(env_id, num_steps=120)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(21, n)
+    env.schedule_sequential()
+    env.enable_goals()
+    env.reset()
+    refs = [O.OracleEnv(oracle_config_from(O, cfg)) for _ in range(n)]
+    for i, e in enumerate(refs):
+        e.reset(21 + i)
+    rs = np.random.RandomState(8)
+    sh0, need, avail, goal = env.goal_info()
+    assert need.all() and (goal == -1).all() and (avail == (1 << 15) - 1).all()
+    n_reached = n_resets = 0
+    for t in range(T):
+        # high level: a goal for every env that needs one (penv.py:76-99)
+        goals = np.full(n, -1, np.int32)
+        for i in np.nonzero(need)[0]:
+            options = np.nonzero(refs[i].available_goals())[0]
+            assert np.array_equal(options, np.nonzero([(avail[i] >> z) & 1 for z in range(15)])[0])
+            goals[i] = rs.choice(options)
+            refs[i].set_goal(goals[i])
+        env.set_goals(goals)
+        # low level: steer towards the goal zone, with noise
+        o, zo = env.observations()
+        g_now = env.get(Z.F_GOAL)
+        assert (g_now >= 0).all()
+        tgt = zo[np.arange(n), g_now, :2] * 3.0
+        d = tgt - o[:, 1:3] * 3.0
+        ang = np.arctan2(d[:, 1], d[:, 0]) - np.arctan2(o[:, 4], o[:, 3])
+        ang = (ang + np.pi) % (2 * np.pi) - np.pi
+        a = np.stack([np.where(np.abs(ang) < 0.6, 1.0, 0.0), np.clip(2 * ang, -1, 1)], 1).astype(np.float32)
+        a += rs.normal(0, 0.05, a.shape).astype(np.float32)
+        env.step(a, auto_reset=True)
+        o, zo, r, dn, gm = env.results()
+        sh, need, avail, goal = env.goal_info()
+        for i, e in enumerate(refs):
+            r_ref, d_ref, g_ref, sh_ref, need_ref = e.step_goal(a[i])
+            assert (r[i], dn[i], gm[i]) == (np.float32(r_ref), d_ref, g_ref), (t, i)
+            assert sh[i] == sh_ref and need[i] == need_ref, (t, i, sh[i], sh_ref)
+            n_reached += need_ref and not d_ref
+            if d_ref:
+                e.reset(21 + i)
+                n_resets += 1
+        o_ref = np.stack([e.obs()[0] for e in refs])
+        assert np.array_equal(o, o_ref), t
+    assert n_resets > n and (n_reached > 50 or env_id == "PointTTSP-v0")   # TimedTSP mostly ends by timeout
+    with pytest.raises(Z.ZenvError):
+        env.set_goals(np.full(n, 99, np.int32))
+    with pytest.raises(Z.ZenvError):
+        env.rollout(3, Z.POLICY_GREEDY)
+    env.close()
