@@ -182,6 +182,58 @@ class TimedTSPEnv(TSPEnv):
         return self._vec.get(nat.F_ZONE_OBS)[0][:, 6].astype(np.float64)
 
 
+class TSPNextCityEnv(TSPEnv):
+    """PointTSP-v3 (main/envs/zone_envs/TSP_next_city_env.py:11-109): dense reward towards a goal city that the
+    caller chooses with set_goal() whenever info['need_next_goal'] is set."""
+    goal_dim = 2
+
+    def __init__(self, config, **kw):
+        super().__init__(config, **kw)
+        self._vec.enable_goals()
+        self.goal_zone = None
+
+    def reset(self):
+        obs = super().reset()
+        self.goal_zone = None
+        return obs
+
+    def step(self, action):
+        assert self.goal_zone is not None                                   # :54
+        obs, reward, done, info = super().step(action)
+        shaped, need, _, goal = self._vec.goal_info()
+        info["shaped_reward"] = float(shaped[0])                           # :60-66
+        info["need_next_goal"] = bool(need[0])                             # :69-75
+        self.goal_zone = None if need[0] else int(goal[0])
+        return obs, reward, done, info
+
+    def set_goal(self, next_goal):
+        assert self.zones[next_goal] == unvisited                           # :86
+        self._vec.set_goals(np.array([next_goal], np.int32))
+        self.goal_zone = int(next_goal)
+
+    def get_goal(self):
+        assert self.goal_zone is not None                                   # :90-91
+        return self._vec.get(nat.F_ZONE_OBS)[0][self.goal_zone, :2].astype(np.float64)
+
+    def get_available_goals(self):
+        assert self.goal_zone is None                                       # :93-100
+        mask = int(self._vec.get(nat.F_AVAILABLE_GOALS)[0])
+        return np.array([(mask >> i) & 1 for i in range(self.num_cities)], bool)
+
+
+class TimedTSPNextCityEnv(TSPNextCityEnv):
+    """zone-goals/envs/TTSP_next_city_env.py:14-51: TSPNextCityEnv with per-city deadlines."""
+    _TASK = nat.TASK_TIMED_TSP
+
+    def __init__(self, config, beta_a=3, beta_b=1.5, **kw):
+        self.beta_a, self.beta_b = beta_a, beta_b
+        super().__init__(config, **kw)
+        self.max_steps = self.num_steps
+
+    def _native_overrides(self):
+        return {"beta_a": float(self.beta_a), "beta_b": float(self.beta_b)}
+
+
 class ColourMatchEnv(ZoneEnvBase):
     """ColourMatch (main/envs/colour_match_env.py)."""
     _TASK = nat.TASK_COLOUR_MATCH

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _native as nat
 from .envs.wrappers import FixedSeedsWrapper, WaitWrapper, ZoneWrapper
-from .envs.zone_envs import ZoneEnvBase
+from .envs.zone_envs import TSPNextCityEnv, ZoneEnvBase
 from .vec_env import ZoneVecEnv
 
 _PLAIN_EPISODES = 256   # bank depth for envs that are not behind a FixedSeedsWrapper
@@ -66,6 +66,9 @@ class ParallelEnv:
                                           stride=1)
         else:
             raise ValueError("mixing seeded and FixedSeedsWrapper envs is not supported")
+        self._goals = all(isinstance(b, TSPNextCityEnv) for b in bases)
+        if self._goals:
+            self._vec.enable_goals()
 
     # ------------------------------------------------------------------ reference surface
     def reset(self):
@@ -81,6 +84,28 @@ class ParallelEnv:
 
     def render(self):
         raise NotImplementedError
+
+    # goal-conditioned envs: zone-goals/src/torch_ac/torch_utils/penv.py:76-99
+    def set_goal(self, env_idx, goal):
+        g = np.full(self.num_envs, -1, np.int32)
+        g[env_idx] = goal
+        self._vec.set_goals(g)
+
+    def set_goals(self, goals):
+        """Batched set_goal: int32 [P], -1 = leave that env alone (one call instead of P pipes)."""
+        self._vec.set_goals(goals)
+
+    def get_goal(self, env_idx):
+        g = int(self._vec.get(nat.F_GOAL)[env_idx])
+        assert g >= 0
+        return self._vec.get(nat.F_ZONE_OBS)[env_idx][g, :2].astype(np.float64)
+
+    def needs_goal(self):
+        return [bool(x) for x in self._vec.get(nat.F_NEED_GOAL)]
+
+    def available_goals(self, env_idx):
+        mask = int(self._vec.get(nat.F_AVAILABLE_GOALS)[env_idx])
+        return np.array([(mask >> i) & 1 for i in range(self._vec.num_zones)], bool)
 
     def close(self):
         self._vec.close()
@@ -108,11 +133,15 @@ class ParallelEnv:
         o = o.astype(np.float64)
         zo = zo.astype(np.float64)
         was_finished = getattr(self, "_finished", np.zeros(self.num_envs, bool))
+        goal_info = self._vec.goal_info() if getattr(self, "_goals", False) else None
         results = []
         for i in range(self.num_envs):
             info = {} if was_finished[i] else {"cost": 0}   # WaitWrapper no-op: info = {}
             if g[i]:
                 info["goal_met"] = True
+            if goal_info is not None:
+                info["shaped_reward"] = float(goal_info[0][i])
+                info["need_next_goal"] = bool(goal_info[1][i])
             results.append(({"zone_obs": zo[i], "obs": o[i]}, float(r[i]), bool(d[i]), info))
         self._finished = np.zeros(self.num_envs, bool) if auto_reset else (was_finished | d)
         return zip(*results)

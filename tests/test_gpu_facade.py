@@ -196,3 +196,41 @@ def test_torch_policy_closed_loop_without_host_copies(zenv_mod, oracle_mod):
     o_host, zo_host = env.observations()
     assert np.array_equal(o_host, o_ref) and np.array_equal(zo_host, zo_ref)
     env.close()
+
+
+def test_next_city_env_facade(zenv_mod, oracle_mod):
+    """PointTSP-v3 (TSPNextCityEnv): gym surface + set_goal / get_available_goals / info keys, single env and
+    folded into a ParallelEnv (zone-goals penv.py:76-99)."""
+    Zm, O = zenv_mod, oracle_mod
+    from combinatorial_rl_tasks_amd.envs import TSPNextCityEnv, make
+    from combinatorial_rl_tasks_amd.penv import ParallelEnv
+    env = make("PointTSP-v3")
+    assert isinstance(env, TSPNextCityEnv)
+    env.seed(77)
+    env.reset()
+    ref = O.OracleEnv(_oracle_for(O, "PointTSP-v0", Zm))
+    ref.reset(77)
+    with pytest.raises(AssertionError):
+        env.step(np.zeros(2, np.float32))                    # no goal yet
+    assert env.get_available_goals().all()
+    env.set_goal(4)
+    ref.set_goal(4)
+    assert np.allclose(env.get_goal() * 3.0, ref.layout[1][4], atol=1e-6)
+    for t in range(40):
+        a = np.array([1.0, 0.3 * np.sin(t / 3)], np.float32)
+        _, r, d, info = env.step(a)
+        r_ref, d_ref, _, sh_ref, need_ref = ref.step_goal(a)
+        assert (r, d, info["shaped_reward"], info["need_next_goal"]) == (r_ref, d_ref, sh_ref, need_ref)
+    env.close()
+    envs = [make("PointTSP-v3") for _ in range(3)]
+    for i, e in enumerate(envs):
+        e.seed(100 + i)
+    penv = ParallelEnv(envs)
+    penv.reset()
+    assert penv.needs_goal() == [True] * 3 and penv.available_goals(1).all()
+    penv.set_goal(0, 2); penv.set_goal(1, 0); penv.set_goal(2, 14)
+    assert penv.needs_goal() == [False] * 3
+    obs, rew, done, info = penv.step(np.zeros((3, 2), np.float32))
+    assert all("shaped_reward" in i and i["need_next_goal"] is False for i in info)
+    assert penv.get_goal(2).shape == (2,)
+    penv.close()
