@@ -3,11 +3,24 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import combinatorial_rl_tasks_amd as Z
-from oracle import policy_ref as P
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 cfg = Z.default_config(0, 25, zones_keepout=0.40)
 env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n, n_threads=16); env.reset()
-env.load_mlp(P.random_tensors(6, seed=0))
+rs = np.random.RandomState(0)
+h_, F_ = 185, 6
+
+
+def lin(n_out, n_in):   # rows of N(0,1) normalised to unit norm (flat_model.py:13-19), small biases
+    w = rs.standard_normal((n_out, n_in)).astype(np.float32)
+    return w / np.sqrt((w * w).sum(1, keepdims=True)), (0.1 * rs.standard_normal(n_out)).astype(np.float32)
+
+
+t = {}
+for (kw, kb), shape in ((("zone_w1", "zone_b1"), (h_, 8 + F_)), (("zone_w2", "zone_b2"), (h_, h_)),
+                        (("zone_w3", "zone_b3"), (h_, h_)), (("comb_w", "comb_b"), (h_, 8 + h_)),
+                        (("enc_w", "enc_b"), (h_, h_)), (("mu_w", "mu_b"), (2, h_)), (("std_w", "std_b"), (2, h_))):
+    t[kw], t[kb] = lin(*shape)
+env.load_mlp(t)
 env.rollout(300, Z.POLICY_MLP_MEAN)
 T = 300
 tot, _ = env.rollout(T, Z.POLICY_MLP_MEAN)
