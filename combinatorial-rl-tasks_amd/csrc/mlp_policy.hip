@@ -159,6 +159,11 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
     const float inv_z = 1.0f / (float)Z;
     const float *zrows = zone_obs + (size_t)env0 * Z * F;
     const __bf16 one = (__bf16)1.0f, nil = (__bf16)0.0f;
+    // layer 1's six fragments stay in registers for the whole kernel (read just in time from LDS they cost an
+    // exposed LDS round trip per MFMA)
+    bf16x8 w1f[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) w1f[m] = as_frag(w1s[m * kWave + lane]);
 
     // two groups of 32 envs: a group's zone rows all pool into ONE 32-env accumulator tile set
     for (int e_base = 0; e_base < n_env; e_base += 32) {
@@ -170,8 +175,13 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
 
         for (int b = g_lo; b < g_hi; b += 32) {
             const bf16x8 x0 = frag_from_8(nxt.v[0], nxt.v[1], nxt.v[2], nxt.v[3], nxt.v[4], nxt.v[5], nxt.v[6], nxt.v[7]);
-            // the next tile's rows are fetched while this one is in the matrix pipe
+            // the next tile's rows are fetched while this one is in the matrix pipe (fetching three tiles ahead
+            // was slower)
             nxt = load_row<ZT, F>(obs, zrows, env0, Z, b + 32 + r, min(n_rows, g_hi), h);
+            // layer 2's first fragments: issued here so that they land during layer 1
+            bf16x8 wf[NH + 1][KS];          // statically indexed: two tiles' worth live at a time
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) wf[0][kk] = as_frag(w2s[(n0 * KS + kk) * kWave + lane]);
             // ---- layer 1: X1 = relu(W1 X0), features in registers
             bf16x8 xa[KS];
 #if defined(MLP_EXP) && (MLP_EXP & 2)      // diagnostic: no layer 1
@@ -180,7 +190,7 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
 #else
 #pragma unroll
             for (int m = 0; m < NT; ++m) {
-                const f32x16 acc1 = mfma(as_frag(w1s[m * kWave + lane]), x0, zero16());
+                const f32x16 acc1 = mfma(w1f[m], x0, zero16());
                 acc_to_frags(acc1, true, xa[2 * m], xa[2 * m + 1]);
             }
 #endif
@@ -198,26 +208,37 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
                         ind[sgm][j] = ((unsigned)(pos - lo) < (unsigned)Z) ? one : nil;
                     }
             }
-            // ---- layer 2: H2^T = relu(X1^T W2^T), zone row in registers, feature on the lane; then the pooling
+            // ---- layer 2: H2^T = relu(X1^T W2^T), zone row in registers, feature on the lane; then the pooling.
+            // Software-pipelined over the wave's output tiles: region n issues the LDS reads of tile n+1's
+            // fragments, then tile n's 12 MFMAs, then tile n-1's conversion + pooling MFMAs.
+            f32x16 acc2[NH];
 #pragma unroll
-            for (int n = 0; n < NH; ++n) {
-                f32x16 acc2 = zero16();
+            for (int n = 0; n <= NH; ++n) {
+                if (n < NH) {
+                    if (n + 1 < NH) {
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk)
-#if defined(MLP_EXP) && (MLP_EXP & 4)      // diagnostic: one fragment read per output tile instead of 12
-                    acc2 = mfma(xa[kk], as_frag(w2s[((n0 + n) * KS) * kWave + lane]), acc2);
+                        for (int kk = 0; kk < KS; ++kk)
+                            wf[n + 1][kk] = as_frag(w2s[((n0 + n + 1) * KS + kk) * kWave + lane]);
+                    }
+                    acc2[n] = zero16();
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk)
+#if defined(MLP_EXP) && (MLP_EXP & 4)      // diagnostic: one fragment per output tile instead of 12
+                        acc2[n] = mfma(xa[kk], wf[n][0], acc2[n]);
 #else
-                    acc2 = mfma(xa[kk], as_frag(w2s[((n0 + n) * KS + kk) * kWave + lane]), acc2);
+                        acc2[n] = mfma(xa[kk], wf[n][kk], acc2[n]);   // (two independent chains per tile: slower)
 #endif
-                bf16x8 f0, f1;
+                }
+                if (n > 0) {
 #if defined(MLP_EXP) && (MLP_EXP & 1)      // diagnostic: no conversion / pooling product
-                pool[n] = acc2;
-                (void)f0; (void)f1;
+                    pool[n - 1] = acc2[n - 1];
 #else
-                acc_to_frags(acc2, true, f0, f1);
-                pool[n] = mfma(ind[0], f0, pool[n]);
-                pool[n] = mfma(ind[1], f1, pool[n]);
+                    bf16x8 f0, f1;
+                    acc_to_frags(acc2[n - 1], true, f0, f1);
+                    pool[n - 1] = mfma(ind[0], f0, pool[n - 1]);
+                    pool[n - 1] = mfma(ind[1], f1, pool[n - 1]);
 #endif
+                }
                 // region boundary: keeps the scheduler from hoisting every later tile's fragment reads up here
                 __builtin_amdgcn_sched_barrier(0);
             }
