@@ -1754,8 +1754,8 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
 }
 
 // =========================================================================== K6: goal shaping
-// TSPNextCityEnv / TimedTSPNextCityEnv (main/envs/zone_envs/TSP_next_city_env.py:41-109,
-// zone-goals/envs/TTSP_next_city_env.py:40-51): a goal zone per env, a dense reward towards it and the
+// TSPNextCityEnv / TimedTSPNextCityEnv / ColourMatchNextCityEnv (main/envs/zone_envs/TSP_next_city_env.py:41-109,
+// zone-goals/envs/TTSP_next_city_env.py:40-51, zone-goals/envs/colour_match_next_city_env.py): a goal zone per env, a dense reward towards it and the
 // request for the next goal.  Runs right after the step kernel, which leaves the zone visited in this
 // step and -- for an env that was auto-reset -- the position where the episode ended.
 __global__ __launch_bounds__(256) void k_goal_set(DevParams p, const int32_t *__restrict__ new_goal, int32_t *bad)
@@ -1764,7 +1764,9 @@ __global__ __launch_bounds__(256) void k_goal_set(DevParams p, const int32_t *__
     if (env >= p.N) return;
     const int g = new_goal[env];
     if (g < 0) return;                                         // leave this env's goal alone
-    if (g >= p.Z || ((p.vis[env] >> g) & 1u)) {                // set_goal asserts the zone is unvisited (:86)
+    // set_goal asserts the zone is unvisited (:86); ColourMatchNextCityEnv only checks the range
+    // (zone-goals/envs/colour_match_next_city_env.py set_goal)
+    if (g >= p.Z || (p.task != ZENV_TASK_COLOUR_MATCH && ((p.vis[env] >> g) & 1u))) {
         atomicAdd(bad, 1);
         return;
     }
@@ -1822,6 +1824,8 @@ __global__ __launch_bounds__(256) void k_goal_step(DevParams p)
             const double d = sqrt(dx * dx + dy * dy);
             sh = p.goal_last[env] - d;                         // :63-66
             p.goal_last[env] = d;
+            // ColourMatchNextCityEnv.step: cycling a zone other than the goal costs 1
+            if (p.task == ZENV_TASK_COLOUR_MATCH && p.visit_zone[env] >= 0) sh -= 1.0;
         }
         if (reached || done) {                                 // :69-72, TTSP_next_city_env.py:46-49
             need = 1;
@@ -1830,7 +1834,8 @@ __global__ __launch_bounds__(256) void k_goal_step(DevParams p)
     }
     p.shaped[env] = sh;
     p.need_goal[env] = need;
-    p.available[env] = ~p.vis[env] & full;                     // get_available_goals, :92-100
+    // get_available_goals, :92-100; every zone for ColourMatch
+    p.available[env] = p.task == ZENV_TASK_COLOUR_MATCH ? full : (~p.vis[env] & full);
 }
 
 // =========================================================================== K2: reset

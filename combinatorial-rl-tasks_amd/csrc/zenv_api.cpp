@@ -614,7 +614,6 @@ extern "C" int zenv_step(zenv_t *h, const float *actions, int actions_on_device,
 extern "C" int zenv_goal_enable(zenv_t *h)
 {
     if (!h) return fail(ZENV_E_ARG, "null handle");
-    if (h->cfg.task == ZENV_TASK_COLOUR_MATCH) return fail(ZENV_E_ARG, "goal-conditioned variant: TSP and TimedTSP only");
     if (h->goal_enabled) return ZENV_OK;
     int rc = use_device(h);
     if (rc) return rc;

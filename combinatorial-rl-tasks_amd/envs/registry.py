@@ -1,5 +1,6 @@
 """The gym registry of main/envs/__init__.py:7-141 for the ids on the MI355X hot path."""
-from .zone_envs import ColourMatchEnv, TimedTSPEnv, TimedTSPNextCityEnv, TSPEnv, TSPNextCityEnv
+from .zone_envs import (ColourMatchEnv, ColourMatchNextCityEnv, TimedTSPEnv, TimedTSPNextCityEnv, TSPEnv,
+                        TSPNextCityEnv)
 
 config_point = {                      # __init__.py:7-14
     "robot_base": "xmls/point.xml", "num_cities": 15, "walled": False,
@@ -22,6 +23,7 @@ REGISTRY = {
     "ColourMatch-v0": (ColourMatchEnv, config_point_colour),   # :136-138
     "PointTSP-v3": (TSPNextCityEnv, config_point),         # :104-106 goal-conditioned
     "PointTTSP-v3": (TimedTSPNextCityEnv, config_point),   # zone-goals/envs/__init__.py:140-142
+    "ColourMatch-v3": (ColourMatchNextCityEnv, config_point_colour),   # zone-goals/envs/__init__.py:151-153
 }
 
 # registered by the reference but outside this build (other robots, solver/goal variants)

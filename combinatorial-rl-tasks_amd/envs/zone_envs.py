@@ -251,3 +251,41 @@ class ColourMatchEnv(ZoneEnvBase):
     @property
     def goal_dist(self):
         return int(self._vec.get(nat.F_VISIT_COUNT)[0])
+
+
+class ColourMatchNextCityEnv(ColourMatchEnv):
+    """zone-goals/envs/colour_match_next_city_env.py: ColourMatch with a goal zone chosen by the caller; any zone
+    may be a goal, and cycling a zone other than the goal costs 1 of shaped reward."""
+    goal_dim = 2
+
+    def __init__(self, config, **kw):
+        super().__init__(config, **kw)
+        self._vec.enable_goals()
+        self.goal_zone = None
+
+    def reset(self):
+        obs = super().reset()
+        self.goal_zone = None
+        return obs
+
+    def step(self, action):
+        assert self.goal_zone is not None
+        obs, reward, done, info = super().step(action)
+        shaped, need, _, goal = self._vec.goal_info()
+        info["shaped_reward"] = float(shaped[0])
+        info["need_next_goal"] = bool(need[0])
+        self.goal_zone = None if need[0] else int(goal[0])
+        return obs, reward, done, info
+
+    def set_goal(self, next_goal):
+        assert 0 <= next_goal < self.num_cities
+        self._vec.set_goals(np.array([next_goal], np.int32))
+        self.goal_zone = int(next_goal)
+
+    def get_goal(self):
+        assert self.goal_zone is not None
+        return self._vec.get(nat.F_ZONE_OBS)[0][self.goal_zone, :2].astype(np.float64)
+
+    def get_available_goals(self):
+        assert self.goal_zone is None
+        return np.ones(self.num_cities, dtype=bool)

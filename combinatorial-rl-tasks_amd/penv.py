@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _native as nat
 from .envs.wrappers import FixedSeedsWrapper, WaitWrapper, ZoneWrapper
-from .envs.zone_envs import TSPNextCityEnv, ZoneEnvBase
+from .envs.zone_envs import ColourMatchNextCityEnv, TSPNextCityEnv, ZoneEnvBase
 from .vec_env import ZoneVecEnv
 
 _PLAIN_EPISODES = 256   # bank depth for envs that are not behind a FixedSeedsWrapper
@@ -66,7 +66,7 @@ class ParallelEnv:
                                           stride=1)
         else:
             raise ValueError("mixing seeded and FixedSeedsWrapper envs is not supported")
-        self._goals = all(isinstance(b, TSPNextCityEnv) for b in bases)
+        self._goals = all(isinstance(b, (TSPNextCityEnv, ColourMatchNextCityEnv)) for b in bases)
         if self._goals:
             self._vec.enable_goals()
 

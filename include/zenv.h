@@ -186,9 +186,10 @@ int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_
 /* ---- goal-conditioned variant: TSPNextCityEnv, main/envs/zone_envs/
  * TSP_next_city_env.py:41-109, and TimedTSPNextCityEnv, zone-goals/envs/TTSP_next_city_env.py:40-51, as the
  * vector calls of zone-goals/src/torch_ac/torch_utils/penv.py:76-99 (set_goal / needs_goal / available_goals).
- * TSP and TimedTSP handles only.  After zenv_goal_enable() every env needs a goal (ZENV_F_NEED_GOAL = 1);
+ * ColourMatchNextCityEnv (zone-goals/envs/colour_match_next_city_env.py) likewise: any zone may be a goal, and
+ * cycling a zone other than the goal costs 1.  After zenv_goal_enable() every env needs a goal (ZENV_F_NEED_GOAL = 1);
  * zenv_set_goals() takes int32 goals[N] from the host (-1 = leave that env alone) and fails with ZENV_E_ARG
- * when a goal zone is already visited (set_goal's assert, :86); every zenv_step() then also produces
+ * when a goal zone is out of range or (TSP / TimedTSP) already visited (set_goal's assert, :86); every zenv_step() then also produces
  * shaped_reward = last_dist_to_goal - dist_to_goal (0 in the step that reaches the goal), need_next_goal
  * (goal reached, or episode over) and the available-goals mask.  zenv_rollout() is refused on such a handle;
  * the goal arrays are not part of zenv_get_state(). */

@@ -203,6 +203,8 @@ class OracleEnv:
         return r.value, bool(d.value), bool(g.value), sh.value, bool(nd.value)
 
     def available_goals(self):
+        if self.cfg.task == TASK_COLOUR:
+            return np.ones(self.Z, bool)
         return np.array([not self.e.visited[z] for z in range(self.Z)], bool)
 
     def obs(self):

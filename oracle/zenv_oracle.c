@@ -484,7 +484,8 @@ static double dist_to_goal(const orc_env *e)
 
 int orc_set_goal(orc_env *e, int goal)
 {
-    if (goal < 0 || goal >= e->cfg.num_zones || e->visited[goal]) return -1;   /* :86 */
+    /* :86; ColourMatchNextCityEnv.set_goal only asserts the range */
+    if (goal < 0 || goal >= e->cfg.num_zones || (e->cfg.task != ORC_TASK_COLOUR && e->visited[goal])) return -1;
     e->goal_zone = goal;
     e->last_dist = dist_to_goal(e);                                             /* :87-88 */
     return 0;
@@ -503,6 +504,8 @@ int orc_step_goal(orc_env *e, const float action[2], double *reward, int *done, 
         double d = dist_to_goal(e);
         *shaped_reward = e->last_dist - d;                                      /* :63-66 */
         e->last_dist = d;
+        /* colour_match_next_city_env.py step: a zone other than the goal changed colour */
+        if (e->cfg.task == ORC_TASK_COLOUR && e->last_visit >= 0) *shaped_reward -= 1.0;
     }
     if (reached || *done) {                                                     /* :69-72; TTSP_next_city_env.py:46-49 */
         *need_next_goal = 1;

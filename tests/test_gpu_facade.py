@@ -234,3 +234,11 @@ def test_next_city_env_facade(zenv_mod, oracle_mod):
     assert all("shaped_reward" in i and i["need_next_goal"] is False for i in info)
     assert penv.get_goal(2).shape == (2,)
     penv.close()
+    cm = make("ColourMatch-v3")
+    cm.seed(5)
+    cm.reset()
+    assert cm.get_available_goals().all()
+    cm.set_goal(3)
+    _, _, _, info = cm.step(np.array([1.0, 0.0], np.float32))
+    assert set(info) >= {"shaped_reward", "need_next_goal"} and info["need_next_goal"] is False
+    cm.close()
