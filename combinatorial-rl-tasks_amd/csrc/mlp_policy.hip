@@ -391,6 +391,66 @@ __global__ __launch_bounds__(256) void k_mlp_action(int N, const float *__restri
     reinterpret_cast<float2 *>(actions)[env] = a;
 }
 
+// ------------------------------------------------------------------------------------------ experiences
+// collect_experiences (main/src/torch_ac/algos/base.py:131-216) on the device.  Buffers are env-major
+// [N][T][...], the layout of exps.* there ("k-th block of T consecutive frames = k-th env", :125-128).
+__global__ __launch_bounds__(256) void k_exp_record(ExpBuffers x, int N, int ZF, int t, const float *__restrict__ obs,
+                                                    const float *__restrict__ zone_obs,
+                                                    const float *__restrict__ actions, const float *__restrict__ mu,
+                                                    const float *__restrict__ stdv, const float *__restrict__ value)
+{
+    // one wave per env: the zone rows are the bulk (Z*F floats)
+    const int lane = threadIdx.x & 63;
+    const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (env >= N) return;
+    const size_t slot = (size_t)env * x.T + t;
+    const float *zsrc = zone_obs + (size_t)env * ZF;
+    float *zdst = x.zone_obs + slot * ZF;
+    for (int i = lane; i < ZF; i += 64) zdst[i] = zsrc[i];
+    if (lane < 8) x.obs[slot * 8 + lane] = obs[(size_t)env * 8 + lane];
+    if (lane < 2) {
+        const float a = actions[(size_t)env * 2 + lane], m = mu[(size_t)env * 2 + lane], sd = stdv[(size_t)env * 2 + lane];
+        x.action[slot * 2 + lane] = a;
+        // Normal(mu, std).log_prob(a), per action dimension (base.py:160)
+        const float zz = (a - m) / sd;
+        x.log_prob[slot * 2 + lane] = -0.5f * zz * zz - logf(sd) - 0.91893853320467274178f;
+    }
+    if (lane == 0) {
+        x.value[slot] = value[env];
+        x.mask[slot] = x.cur_mask[env];                 // self.masks[i] = self.mask (:149), BEFORE this step
+    }
+}
+
+// after the env step: rewards[i] (shaped_reward when the env provides it, :153-159) and the new self.mask
+__global__ __launch_bounds__(256) void k_exp_reward(ExpBuffers x, int N, int t, const float *__restrict__ reward,
+                                                    const double *__restrict__ shaped, const uint8_t *__restrict__ done)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    x.reward[(size_t)env * x.T + t] = shaped ? (float)shaped[env] : reward[env];
+    x.cur_mask[env] = done[env] ? 0.f : 1.f;            // self.mask = 1 - done (:150)
+}
+
+// advantages[i] = delta + discount * gae_lambda * advantages[i+1] * masks[i+1] (:190-196); returnn = value + advantage
+__global__ __launch_bounds__(256) void k_exp_gae(ExpBuffers x, int N, const float *__restrict__ next_value, float discount,
+                                                 float gae_lambda)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    const size_t base = (size_t)env * x.T;
+    float nv = next_value[env], nm = x.cur_mask[env], na = 0.f;
+    for (int i = x.T - 1; i >= 0; --i) {
+        const float v = x.value[base + i];
+        const float delta = x.reward[base + i] + discount * nv * nm - v;
+        const float adv = delta + discount * gae_lambda * na * nm;
+        x.advantage[base + i] = adv;
+        x.returnn[base + i] = v + adv;
+        nv = v;
+        nm = x.mask[base + i];
+        na = adv;
+    }
+}
+
 uint16_t to_bf16(float f)
 {
     uint32_t u;
@@ -512,6 +572,27 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
                               (int)lds_head);
     hipLaunchKernelGGL(k_mlp_head, dim3((N + kHeadWaves * 32 - 1) / (kHeadWaves * 32)), dim3(kHeadWaves * kWave), lds_head, s,
                        img, N, obs, pooled, mu, stdv, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_exp_record(const ExpBuffers &x, int N, int ZF, int t, const float *obs, const float *zone_obs,
+                             const float *actions, const float *mu, const float *stdv, const float *value, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_exp_record, dim3((N + 3) / 4), dim3(256), 0, s, x, N, ZF, t, obs, zone_obs, actions, mu, stdv, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_exp_reward(const ExpBuffers &x, int N, int t, const float *reward, const double *shaped,
+                             const uint8_t *done, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_exp_reward, dim3((N + 255) / 256), dim3(256), 0, s, x, N, t, reward, shaped, done);
+    return hipGetLastError();
+}
+
+hipError_t launch_exp_gae(const ExpBuffers &x, int N, const float *next_value, float discount, float gae_lambda,
+                          hipStream_t s)
+{
+    hipLaunchKernelGGL(k_exp_gae, dim3((N + 255) / 256), dim3(256), 0, s, x, N, next_value, discount, gae_lambda);
     return hipGetLastError();
 }
 

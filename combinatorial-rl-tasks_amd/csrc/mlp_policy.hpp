@@ -43,4 +43,21 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
 hipError_t launch_mlp_action(int N, const float *mu, const float *stdv, int sample, uint64_t seed, uint64_t env_index0,
                              uint32_t step_index, float *actions, hipStream_t s);
 
+// Experience buffers of one collect_experiences() call (base.py:131-216), env-major [N][T][...]
+struct ExpBuffers {
+    int T;
+    float *obs;        // [N][T][8]
+    float *zone_obs;   // [N][T][Z*F]
+    float *action;     // [N][T][2]
+    float *log_prob;   // [N][T][2]
+    float *value, *reward, *mask, *advantage, *returnn;   // [N][T]
+    float *cur_mask;   // [N]  self.mask, carried from one call to the next
+};
+hipError_t launch_exp_record(const ExpBuffers &x, int N, int ZF, int t, const float *obs, const float *zone_obs,
+                             const float *actions, const float *mu, const float *stdv, const float *value, hipStream_t s);
+hipError_t launch_exp_reward(const ExpBuffers &x, int N, int t, const float *reward, const double *shaped,
+                             const uint8_t *done, hipStream_t s);
+hipError_t launch_exp_gae(const ExpBuffers &x, int N, const float *next_value, float discount, float gae_lambda,
+                          hipStream_t s);
+
 }  // namespace zenvk

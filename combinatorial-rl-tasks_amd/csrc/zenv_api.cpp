@@ -74,6 +74,9 @@ struct zenv {
     // goal-conditioned variant (zenv_goal_enable)
     bool goal_enabled = false;
     int32_t *goal_in = nullptr, *goal_bad = nullptr;
+    // experience buffers (zenv_collect)
+    ExpBuffers exp{};
+    void *exp_mem = nullptr;
 };
 
 namespace {
@@ -171,6 +174,15 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_NEED_GOAL: return { p.need_goal, p.need_goal ? N : 0 };
     case ZENV_F_AVAILABLE_GOALS: return { p.available, p.available ? N * 4 : 0 };
     case ZENV_F_GOAL: return { p.goal, p.goal ? N * 4 : 0 };
+    case ZENV_F_EXP_OBS: return { h->exp.obs, h->exp.obs ? N * h->exp.T * 8 * 4 : 0 };
+    case ZENV_F_EXP_ZONE_OBS: return { h->exp.zone_obs, h->exp.obs ? N * h->exp.T * p.Z * p.F * 4 : 0 };
+    case ZENV_F_EXP_ACTION: return { h->exp.action, h->exp.obs ? N * h->exp.T * 2 * 4 : 0 };
+    case ZENV_F_EXP_LOG_PROB: return { h->exp.log_prob, h->exp.obs ? N * h->exp.T * 2 * 4 : 0 };
+    case ZENV_F_EXP_VALUE: return { h->exp.value, h->exp.obs ? N * h->exp.T * 4 : 0 };
+    case ZENV_F_EXP_REWARD: return { h->exp.reward, h->exp.obs ? N * h->exp.T * 4 : 0 };
+    case ZENV_F_EXP_MASK: return { h->exp.mask, h->exp.obs ? N * h->exp.T * 4 : 0 };
+    case ZENV_F_EXP_ADVANTAGE: return { h->exp.advantage, h->exp.obs ? N * h->exp.T * 4 : 0 };
+    case ZENV_F_EXP_RETURN: return { h->exp.returnn, h->exp.obs ? N * h->exp.T * 4 : 0 };
     default: return { nullptr, 0 };
     }
 }
@@ -374,7 +386,7 @@ extern "C" int zenv_destroy(zenv_t *h)
     for (void *m : { h->mlp_mem, (void *)h->mlp_pooled, (void *)h->mlp_mu, (void *)h->mlp_std, (void *)h->mlp_value,
                      (void *)h->p.visit_zone, (void *)h->p.term_xy, (void *)h->p.goal, (void *)h->p.goal_last,
                      (void *)h->p.goal_xy, (void *)h->p.shaped, (void *)h->p.need_goal, (void *)h->p.available,
-                     (void *)h->goal_in, (void *)h->goal_bad })
+                     (void *)h->goal_in, (void *)h->goal_bad, h->exp_mem })
         if (m) (void)hipFree(m);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -718,6 +730,64 @@ static int run_policy(zenv_t *h, const StepPolicy &pol)
                               pol.env_index0, pol.step_index, pol.out, h->stream));
     return ZENV_OK;
 }
+
+// ============================================================================ experience collection
+extern "C" int zenv_collect(zenv_t *h, int T, uint64_t policy_seed, uint64_t env_index0, float discount, float gae_lambda)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (T < 1) return fail(ZENV_E_ARG, "frames_per_proc must be positive");
+    if (!h->was_reset) return fail(ZENV_E_STATE, "Environment must be reset before stepping");
+    if (!h->mlp_ready || !h->mlp.wv1) return fail(ZENV_E_STATE, "zenv_mlp_load with actor and critic weights first");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const size_t N = (size_t)h->n_env, ZF = (size_t)h->p.Z * h->p.F;
+    if (!h->exp_mem || h->exp.T != T) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        std::vector<float> keep_mask;
+        if (h->exp_mem) {       // self.mask survives a change of T
+            keep_mask.resize(N);
+            HIP_TRY(hipMemcpy(keep_mask.data(), h->exp.cur_mask, N * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipFree(h->exp_mem));
+            h->exp_mem = nullptr;
+        }
+        const size_t per_slot = 8 + ZF + 2 + 2 + 5;            // floats per (env, t)
+        const size_t total = N * (size_t)T * per_slot + N;
+        HIP_TRY(hipMalloc(&h->exp_mem, total * sizeof(float)));
+        float *f = static_cast<float *>(h->exp_mem);
+        ExpBuffers &x = h->exp;
+        x.T = T;
+        x.obs = f;            f += N * T * 8;
+        x.zone_obs = f;       f += N * T * ZF;
+        x.action = f;         f += N * T * 2;
+        x.log_prob = f;       f += N * T * 2;
+        x.value = f;          f += N * T;
+        x.reward = f;         f += N * T;
+        x.mask = f;           f += N * T;
+        x.advantage = f;      f += N * T;
+        x.returnn = f;        f += N * T;
+        x.cur_mask = f;
+        if (keep_mask.empty()) keep_mask.assign(N, 1.0f);      // base.py:96 self.mask = ones
+        HIP_TRY(hipMemcpy(x.cur_mask, keep_mask.data(), N * 4, hipMemcpyHostToDevice));
+    }
+    for (int t = 0; t < T; ++t) {
+        StepPolicy pol{ ZENV_POLICY_MLP_SAMPLE, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };
+        rc = run_policy(h, pol);                               // dist, value = acmodel(obs); action = dist.sample()
+        if (rc) return rc;
+        HIP_TRY(launch_exp_record(h->exp, h->n_env, (int)ZF, t, h->p.obs, h->p.zone_obs, h->p.actions, h->mlp_mu,
+                                  h->mlp_std, h->mlp_value, h->stream));
+        HIP_TRY(launch_step(h->p, h->p.actions, 1, no_policy(), h->stream));     // ParallelEnv.step: auto-reset
+        if (h->goal_enabled) HIP_TRY(launch_goal_step(h->p, h->stream));
+        HIP_TRY(launch_exp_reward(h->exp, h->n_env, t, h->p.reward, h->goal_enabled ? h->p.shaped : nullptr,
+                                  h->p.done_out, h->stream));
+        h->step_count += 1;
+    }
+    // next_value = value(obs_T) (:177-187), then the GAE recursion
+    HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
+                               h->mlp_std, h->mlp_value, h->stream));
+    HIP_TRY(launch_exp_gae(h->exp, h->n_env, h->mlp_value, discount, gae_lambda, h->stream));
+    return ZENV_OK;
+}
+
 
 extern "C" int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0, float *dst_device)
 {

@@ -264,6 +264,27 @@ class ZoneVecEnv:
             out += (self.get(nat.F_POLICY_VALUE),)
         return out
 
+    # ------------------------------------------------------------------ one PPO rollout
+    def collect(self, frames_per_proc, policy_seed=1, env_index0=0, discount=0.99, gae_lambda=0.95):
+        """BaseAlgo.collect_experiences (main/src/torch_ac/algos/base.py:131-227) on the device with the loaded
+        actor-critic.  Returns a dict of env-major arrays [N, T, ...] -- reshape(N*T, ...) gives exps.* of the
+        reference (:211-227): obs, zone_obs, action, log_prob, value, reward, mask, advantage, returnn."""
+        T = int(frames_per_proc)
+        check(lib().zenv_collect(self._h, T, int(policy_seed), int(env_index0), float(discount), float(gae_lambda)))
+        N, Z, F = self.num_envs, self.num_zones, self.zone_feat
+        shapes = {"obs": (nat.F_EXP_OBS, (N, T, 8)), "zone_obs": (nat.F_EXP_ZONE_OBS, (N, T, Z, F)),
+                  "action": (nat.F_EXP_ACTION, (N, T, 2)), "log_prob": (nat.F_EXP_LOG_PROB, (N, T, 2)),
+                  "value": (nat.F_EXP_VALUE, (N, T)), "reward": (nat.F_EXP_REWARD, (N, T)),
+                  "mask": (nat.F_EXP_MASK, (N, T)), "advantage": (nat.F_EXP_ADVANTAGE, (N, T)),
+                  "returnn": (nat.F_EXP_RETURN, (N, T))}
+        out = {}
+        for name, (field, shape) in shapes.items():
+            a = np.empty(shape, np.float32)
+            assert a.nbytes == lib().zenv_field_bytes(self._h, field)
+            check(lib().zenv_get(self._h, field, a.ctypes.data, 0))
+            out[name] = a
+        return out
+
     def sync(self):
         check(lib().zenv_sync(self._h))
 

@@ -66,6 +66,16 @@ enum {
     ZENV_F_NEED_GOAL = 17,       /* uint8   [N] info['need_next_goal'] / env.goal_zone is None (:69-75) */
     ZENV_F_AVAILABLE_GOALS = 18, /* uint32  [N] get_available_goals() as a bit mask, bit z = zone z unvisited */
     ZENV_F_GOAL = 19,            /* int32   [N] goal zone, -1 = none */
+    /* experience buffers of the last zenv_collect(), env-major: [N][T][...] (base.py:125-128, :211-227) */
+    ZENV_F_EXP_OBS = 20,         /* float32 [N,T,8] */
+    ZENV_F_EXP_ZONE_OBS = 21,    /* float32 [N,T,Z,F] */
+    ZENV_F_EXP_ACTION = 22,      /* float32 [N,T,2] */
+    ZENV_F_EXP_LOG_PROB = 23,    /* float32 [N,T,2]  Normal(mu, std).log_prob(action) */
+    ZENV_F_EXP_VALUE = 24,       /* float32 [N,T] */
+    ZENV_F_EXP_REWARD = 25,      /* float32 [N,T]    shaped_reward when the handle is goal-conditioned (:153-159) */
+    ZENV_F_EXP_MASK = 26,        /* float32 [N,T]    1 - done of the previous step (:149-150) */
+    ZENV_F_EXP_ADVANTAGE = 27,   /* float32 [N,T]    GAE (:190-196) */
+    ZENV_F_EXP_RETURN = 28,      /* float32 [N,T]    value + advantage (:226) */
     ZENV_F_COUNT = 13
 };
 
@@ -220,6 +230,14 @@ int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w);
  * ZENV_F_POLICY_MU / ZENV_F_POLICY_STD (and value = critic(x) into ZENV_F_POLICY_VALUE).  zenv_policy() / zenv_rollout() with ZENV_POLICY_MLP_* call it
  * and turn it into actions (rollouts then run one launch sequence per step). */
 int zenv_mlp_forward(zenv_t *h);
+
+/* ---- one PPO rollout on the device: BaseAlgo.collect_experiences, main/src/torch_ac/algos/base.py:131-227 ----
+ * T times: (dist, value) = acmodel(obs) [zenv_mlp_forward]; action = dist.sample(); record obs, action, value,
+ * log_prob, mask; step the envs (auto-reset); record the reward.  Then next_value = value(obs_T) and the GAE
+ * recursion.  Needs actor AND critic weights (zenv_mlp_load).  The buffers (ZENV_F_EXP_*) stay valid until the
+ * next call with a different T or zenv_destroy; self.mask is carried from call to call like the reference's. */
+int zenv_collect(zenv_t *h, int frames_per_proc, uint64_t policy_seed, uint64_t env_index0, float discount,
+                 float gae_lambda);
 
 /* ---- results ---- */
 int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device);

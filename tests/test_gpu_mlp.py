@@ -116,3 +116,75 @@ def test_mlp_policy_actions_and_rollout(zenv_mod):
     for x, y in zip(want, env.results()):
         assert np.array_equal(x, y)
     env.close()
+
+
+@pytest.mark.parametrize("env_id,goals", [("PointTSP-v1", False), ("PointTTSP-v1", False), ("PointTSP-v0", True)])
+def test_collect_experiences(zenv_mod, oracle_mod, env_id, goals):
+    """BaseAlgo.collect_experiences (base.py:131-227) on the device.  The recorded actions
+    replayed through the oracle reproduce the recorded observations and rewards bit for bit (the env half);
+    log_prob, masks and the GAE recursion are recomputed in numpy from the recorded values (the bookkeeping
+    half); a second call continues where the first stopped (self.mask carried over)."""
+    from oracle import policy_ref as P
+    from tests.helpers import oracle_config_from
+    Z, O = zenv_mod, oracle_mod
+    n, T = 70, 48
+    cfg = Z.config_for_id(env_id, num_steps=30)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(5, n)
+    if goals:
+        env.enable_goals()
+    env.reset()
+    t = P.random_tensors(env.zone_feat, seed=2, critic=True)
+    env.load_mlp(t)
+    refs = [O.OracleEnv(oracle_config_from(O, cfg)) for _ in range(n)]
+    for i, e in enumerate(refs):
+        e.reset(5 + i)
+    if goals:
+        g0 = np.arange(n, dtype=np.int32) % cfg.num_zones
+        env.set_goals(g0)
+        for i, e in enumerate(refs):
+            e.set_goal(int(g0[i]))
+        T = 12                                        # shaped rewards of the first steps; nobody is re-goaled inside a rollout
+    prev_mask = np.ones(n, np.float32)
+    for call in range(2):
+        x = env.collect(T, policy_seed=3, discount=0.99, gae_lambda=0.95)
+        assert x["obs"].shape == (n, T, 8) and x["zone_obs"].shape == (n, T, cfg.num_zones, env.zone_feat)
+        # ---- env half: replay
+        need = np.zeros(n, bool)
+        for k in range(T):
+            for i, e in enumerate(refs):
+                o_ref, zo_ref = e.obs()
+                assert np.array_equal(x["obs"][i, k], o_ref) and np.array_equal(x["zone_obs"][i, k], zo_ref), (call, k, i)
+                assert x["mask"][i, k] == prev_mask[i]
+                if goals:
+                    if need[i]:
+                        continue                       # the reference would assert: this env waits for a goal
+                    r, d, _, sh, nd = e.step_goal(x["action"][i, k])
+                    assert x["reward"][i, k] == np.float32(sh)
+                    need[i] = nd
+                else:
+                    r, d, _ = e.step(x["action"][i, k])
+                    assert x["reward"][i, k] == np.float32(r)
+                prev_mask[i] = 0.0 if d else 1.0
+                if d:
+                    e.reset(5 + i)
+            if goals and need.any():
+                break
+        if goals:
+            break                                      # the rewards recorded above were the shaped ones
+        # ---- bookkeeping half
+        mu, std, val = P.forward_bf16_emulated(t, x["obs"].reshape(-1, 8), x["zone_obs"].reshape(n * T, cfg.num_zones, -1))
+        assert np.abs(val.reshape(n, T) - x["value"]).max() < 4e-3
+        mu, std = mu.reshape(n, T, 2), std.reshape(n, T, 2)
+        lp = -0.5 * ((x["action"] - mu) / std) ** 2 - np.log(std) - 0.5 * np.log(2 * np.pi)
+        assert np.abs(lp - x["log_prob"]).max() < 0.15      # mu / std carry the 4e-3 bf16 tolerance, divided by std
+        _, _, next_value = env.mlp_forward(with_value=True)
+        nv, nm, na = next_value.astype(np.float32), prev_mask.copy(), np.zeros(n, np.float32)
+        adv = np.zeros((n, T), np.float32)
+        for k in reversed(range(T)):
+            delta = x["reward"][:, k] + np.float32(0.99) * nv * nm - x["value"][:, k]
+            adv[:, k] = delta + np.float32(0.99) * np.float32(0.95) * na * nm
+            nv, nm, na = x["value"][:, k], x["mask"][:, k], adv[:, k]
+        assert np.abs(adv - x["advantage"]).max() < 1e-5 and np.abs(x["value"] + adv - x["returnn"]).max() < 1e-5
+        assert (x["mask"] == 0).any() and (x["mask"] == 1).any()
+    env.close()
