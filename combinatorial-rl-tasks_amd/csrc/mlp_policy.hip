@@ -170,7 +170,8 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
     for (int m = 0; m < NT; ++m) w1f[m] = as_frag(w1s[m * kWave + lane]);
 
     // (Starting the second wave of each SIMD half a tile late, so that the pair is not in its VALU phases at
-    // the same moments, changed nothing: 165.6 us per step at any offset.)
+    // the same moments, changed nothing: 165.6 us per step at any offset; neither did a static priority for the
+    // younger half of the workgroup.)
 
     // two groups of 32 envs: a group's zone rows all pool into ONE 32-env accumulator tile set
     for (int e_base = 0; e_base < n_env; e_base += 32) {
