@@ -404,13 +404,18 @@ __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage,
     // dst is wave-uniform: one buffer descriptor for the tile's [n_rows][F] block
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(dst, 0, n_rows * F * (int)sizeof(float), 0x00020000);
+    // full iterations (64 chunks = 64*G float4, no guards), software-pipelined: while the staged rows of
+    // iteration i make their round trip through the slab, the entries of iteration i+1 are read and expanded
+    // (the LDS executes one wave's accesses in order, so the slab write of i+1 cannot overtake the slab read
+    // of i; the fences only stop the compiler)
     int c0 = 0;
-    // full iterations: 64 chunks = 64*G float4, no guards
-    for (; c0 + kWave <= n_chunks; c0 += kWave) {
-        const int c = c0 + lane;
-        float v[RPC * F];
+    const int n_full = n_chunks / kWave;
+    float v[RPC * F];
+    if (n_full > 0) {
 #pragma unroll
-        for (int j = 0; j < RPC; ++j) expand_entry<TASK>(ents[c * RPC + j], v + j * F);
+        for (int j = 0; j < RPC; ++j) expand_entry<TASK>(ents[lane * RPC + j], v + j * F);
+    }
+    for (int it = 0; it < n_full; ++it, c0 += kWave) {
 #pragma unroll
         for (int g = 0; g < G; ++g)
             stage[lane * G + g] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
@@ -418,12 +423,17 @@ __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage,
         float4 t[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) t[g] = stage[g * kWave + lane];
+        wave_lds_fence();
+        if (it + 1 < n_full) {
+            const int c = c0 + kWave + lane;
+#pragma unroll
+            for (int j = 0; j < RPC; ++j) expand_entry<TASK>(ents[c * RPC + j], v + j * F);
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const v4f_t val = { t[g].x, t[g].y, t[g].z, t[g].w };
             __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + g * kWave + lane) * 16, 0, ZENV_STORE_AUX);
         }
-        wave_lds_fence();
     }
     // last, partial iteration
     if (c0 < n_chunks) {
