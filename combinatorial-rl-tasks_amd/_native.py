@@ -101,6 +101,9 @@ _PROTOTYPES = {
     "zenv_device_ptr": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),
     "zenv_field_bytes": (C.c_int64, [_H, C.c_int]),
     "zenv_sync": (C.c_int, [_H]),
+    "zenv_host_alloc": (C.c_void_p, [C.c_int64]),
+    "zenv_host_free": (C.c_int, [C.c_void_p]),
+    "zenv_get_many": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
     "zenv_set_stream": (C.c_int, [_H, C.c_void_p]),
     "zenv_step_count": (C.c_int64, [_H]),
     "zenv_state_bytes": (C.c_int64, [_H]),

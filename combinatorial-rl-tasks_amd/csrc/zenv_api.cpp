@@ -895,6 +895,36 @@ extern "C" int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device)
     return ZENV_OK;
 }
 
+extern "C" void *zenv_host_alloc(int64_t bytes)
+{
+    void *p = nullptr;
+    if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+        fail(ZENV_E_HIP, "hipHostMalloc(%lld) failed", (long long)bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" int zenv_host_free(void *ptr)
+{
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return ZENV_OK;
+}
+
+extern "C" int zenv_get_many(zenv_t *h, int n_fields, const int *fields, void *const *dst)
+{
+    if (!h || !fields || !dst || n_fields < 0) return fail(ZENV_E_ARG, "bad argument");
+    int rc = use_device(h);
+    if (rc) return rc;
+    for (int i = 0; i < n_fields; ++i) {
+        const FieldInfo f = field_info(h, fields[i]);
+        if (!f.ptr || !dst[i]) return fail(ZENV_E_ARG, "unknown field %d or null destination", fields[i]);
+        HIP_TRY(hipMemcpyAsync(dst[i], f.ptr, f.bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ZENV_OK;
+}
+
 extern "C" int zenv_device_ptr(zenv_t *h, int field, void **ptr)
 {
     if (!h || !ptr) return fail(ZENV_E_ARG, "null argument");

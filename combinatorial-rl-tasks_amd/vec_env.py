@@ -329,6 +329,24 @@ class ZoneVecEnv:
     def observations(self):
         return self.get(nat.F_OBS), self.get(nat.F_ZONE_OBS)
 
+    # ------------------------------------------------------------------ host-policy surface at PCIe rate
+    def pinned_array(self, shape, dtype):
+        """A numpy array in page-locked host memory (zenv_host_alloc): uploads from it / downloads into it are
+        plain DMA.  The memory stays allocated until the process ends (arrays may outlive the env)."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        ptr = lib().zenv_host_alloc(max(nbytes, 1))
+        if not ptr:
+            raise nat.ZenvError(nat.E_HIP, "zenv_host_alloc failed")
+        buf = (C.c_char * max(nbytes, 1)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def results_into(self, fields, arrays):
+        """Downloads of several fields, one synchronisation (zenv_get_many); arrays should be pinned_array()s."""
+        f = (C.c_int * len(fields))(*[int(x) for x in fields])
+        d = (C.c_void_p * len(fields))(*[a.ctypes.data for a in arrays])
+        check(lib().zenv_get_many(self._h, len(fields), f, d))
+
     def results(self):
         """(obs, zone_obs, reward, done, goal_met) of the last step, as host arrays."""
         return (self.get(nat.F_OBS), self.get(nat.F_ZONE_OBS), self.get(nat.F_REWARD),

@@ -244,6 +244,13 @@ int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device);
 int zenv_device_ptr(zenv_t *h, int field, void **ptr);  /* zero-copy for GPU consumers */
 int64_t zenv_field_bytes(const zenv_t *h, int field);
 int zenv_sync(zenv_t *h);
+/* Host-policy surface (a CPU-resident policy: actions up, observations down, every step): page-locked host
+ * memory for the caller's buffers, so that zenv_step()'s action upload and zenv_get()'s downloads run as DMA
+ * at PCIe rate instead of through a pageable bounce buffer.  zenv_get_many() enqueues several downloads and
+ * synchronises once.  Free with zenv_host_free (any time before process exit). */
+void *zenv_host_alloc(int64_t bytes);
+int zenv_host_free(void *ptr);
+int zenv_get_many(zenv_t *h, int n_fields, const int *fields, void *const *dst);
 /* Enqueue everything from now on onto the caller's HIP stream (hipStream_t passed as void*; NULL =
  * back to the handle's own stream).  The handle first drains the stream it was using.  This is how
  * a device-resident policy (base.py:139-145 without the .cpu().numpy() round trip) shares one

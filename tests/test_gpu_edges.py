@@ -129,3 +129,26 @@ def test_large_batch_runs(zenv_mod, oracle_mod):
     assert np.array_equal(env.get(Z.F_OBS)[4096 * 3:4096 * 3 + 64], ref["obs"])
     assert np.array_equal(env.get(Z.F_ZONE_OBS)[-64:], env.get(Z.F_ZONE_OBS)[4096 - 64:4096])   # same maps
     env.close()
+
+
+def test_pinned_host_buffers_and_batched_download(zenv_mod):
+    """zenv_host_alloc / zenv_get_many: the host-policy surface through page-locked buffers gives the same
+    arrays as zenv_get into pageable ones."""
+    Z = zenv_mod
+    n = 300
+    env = Z.ZoneVecEnv(Z.config_for_id("PointTTSP-v0"), n)
+    env.build_bank(2, n)
+    env.reset()
+    a = env.pinned_array((n, 2), np.float32)
+    a[:] = np.random.RandomState(0).uniform(-1, 1, (n, 2))
+    fields = (Z.F_OBS, Z.F_ZONE_OBS, Z.F_REWARD, Z.F_DONE)
+    bufs = [env.pinned_array(env._shape(f), t) for f, t in zip(fields, (np.float32, np.float32, np.float32, np.uint8))]
+    for _ in range(3):
+        env.step(a, auto_reset=True)
+        env.results_into(fields, bufs)
+        for f, b in zip(fields, bufs):
+            assert np.array_equal(b, env.get(f))
+    with pytest.raises(Z.ZenvError):
+        env.results_into((99,), [bufs[0]])
+    env.close()
+    assert np.isfinite(bufs[0]).all()          # pinned arrays outlive the env
