@@ -377,3 +377,78 @@ def test_rollout_wrapping_map_bank(oracle_mod):
     e = O.rollout(cfg, seeds, 10, O.POLICY_GREEDY, seed_stride=7, seed_period=3, n_threads=2)
     f = O.rollout(cfg, seeds, 10, O.POLICY_GREEDY, seed_stride=7, n_threads=2)
     assert e["episodes"].max() < 3 and np.array_equal(e["zone_obs"], f["zone_obs"])
+
+
+def test_goal_conditioned_semantics(oracle_mod):
+    """TSPNextCityEnv truth table (TSP_next_city_env.py:53-100), written from the reference source:
+    step asserts a goal; set_goal asserts unvisited; shaped_reward = last_dist - dist, 0 in the step that reaches
+    the goal; need_next_goal when the goal is reached or the episode ends; the goal is cleared then."""
+    O = oracle_mod
+    cfg = O.default_config(O.TASK_TSP, 5, num_steps=1000)
+    e = O.OracleEnv(cfg)
+    e.reset(1000000)
+    with pytest.raises(AssertionError):
+        e.step_goal([0.0, 0.0])                               # :54 assert goal_zone is not None
+    with pytest.raises(AssertionError):
+        e.set_goal(5)
+    robot, zones = e.layout
+    e.set_goal(2)
+    d0 = math.hypot(zones[2][0] - robot[0], zones[2][1] - robot[1])
+    assert e.e.goal_zone == 2 and e.e.last_dist == d0          # :87-88
+    total, reached_at = 0.0, None
+    for t in range(1000):
+        o, zo = e.obs()
+        g = zo[2, :2] * 3.0 - o[1:3] * 3.0
+        ang = (math.atan2(g[1], g[0]) - math.atan2(o[4], o[3]) + math.pi) % (2 * math.pi) - math.pi
+        r, d, gm, sh, need = e.step_goal([1.0 if abs(ang) < 0.6 else 0.0, max(-1.0, min(1.0, 2 * ang))])
+        if need:
+            reached_at = t
+            assert r == 1.0 and sh == 0.0 and e.e.goal_zone == -1 and e.e.visited[2]     # :60-61, :69-72
+            break
+        total += sh
+    assert reached_at is not None and reached_at > 10
+    # the shaped rewards telescope to (initial distance - distance one step before arrival), i.e. ~ d0 - 0.2
+    assert abs(total - (d0 - 0.2)) < 0.05
+    with pytest.raises(AssertionError):
+        e.set_goal(2)                                         # :86 visited zones are not valid goals
+    assert list(e.available_goals()) == [not e.e.visited[z] for z in range(5)]
+    # a timeout also asks for the next goal (TTSP_next_city_env.py:46-49)
+    cfg = O.default_config(O.TASK_TIMED, 5, num_steps=50)
+    e = O.OracleEnv(cfg)
+    e.reset(7)
+    e.set_goal(0)
+    need = False
+    for t in range(50):
+        r, d, gm, sh, need = e.step_goal([0.0, 0.0])
+        if d:
+            break
+    assert d and need and e.e.goal_zone == -1
+    # ColourMatchNextCityEnv: any zone may be the goal; cycling another zone costs 1
+    cfg = O.default_config(O.TASK_COLOUR, 6)
+    e = O.OracleEnv(cfg)
+    e.reset(3)
+    assert e.available_goals().all()
+    e.set_goal(5)
+    assert e.e.goal_zone == 5
+
+
+def test_actor_network_restatement_is_self_consistent():
+    """oracle/policy_ref.py: the bf16-emulated forward stays within bf16 tolerance of the float32 one, and
+    moving the mean in front of the (linear) third zone layer -- what the kernels do -- is exact algebra."""
+    torch = pytest.importorskip("torch")
+    from oracle import policy_ref as P
+    t = P.random_tensors(7, h=185, seed=4, critic=True)
+    rs = np.random.RandomState(1)
+    obs = rs.uniform(-1, 1, (40, 8)).astype(np.float32)
+    zo = rs.uniform(-1, 1, (40, 15, 7)).astype(np.float32)
+    mu, std, val = P.forward_fp32(t, obs, zo)
+    mu_e, std_e, val_e = P.forward_bf16_emulated(t, obs, zo)
+    assert mu.shape == (40, 2) and val.shape == (40,) and (std > 1e-3).all() and (np.abs(mu) < 1).all()
+    assert np.abs(mu - mu_e).max() < 2e-2 and np.abs(std - std_e).max() < 2e-2 and np.abs(val - val_e).max() < 3e-2
+    td = {k: torch.as_tensor(v, dtype=torch.float64) for k, v in t.items()}
+    x = torch.cat([torch.as_tensor(obs, dtype=torch.float64)[:, None, :].expand(40, 15, 8),
+                   torch.as_tensor(zo, dtype=torch.float64)], -1)
+    h2 = torch.relu(torch.relu(x @ td["zone_w1"].T + td["zone_b1"]) @ td["zone_w2"].T + td["zone_b2"])
+    after = (h2 @ td["zone_w3"].T + td["zone_b3"]).sum(1) / 15            # env_model.py:78
+    before = (h2.sum(1) / 15) @ td["zone_w3"].T + td["zone_b3"]            # mlp_policy.hip
+    assert (after - before).abs().max() < 1e-12
