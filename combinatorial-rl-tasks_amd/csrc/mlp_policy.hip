@@ -262,6 +262,32 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
     }
 }
 
+// ------------------------------------------------------------------------------------------ sampling
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// a = mu, or Normal(mu, std).sample(): Box-Muller on two Philox uniforms keyed by (seed, global env, step)
+__device__ __forceinline__ float2 mlp_action(const MlpAction &act, int env, float2 m, float2 sd)
+{
+    if (act.mode != 1) return m;
+    const uint64_t g = act.env_index0 + (uint64_t)env;
+    uint32_t c[4] = { (uint32_t)g, (uint32_t)(g >> 32), act.step_index, 0x4D4C50u };
+    philox4x32_10(c, (uint32_t)act.seed, (uint32_t)(act.seed >> 32));
+    const float u1 = ((float)(c[0] >> 8) + 0.5f) * 5.9604644775390625e-08f;     // (0, 1)
+    const float u2 = ((float)(c[1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+    const float rad = sqrtf(-2.0f * logf(u1));
+    return make_float2(m.x + sd.x * rad * cosf(6.283185307179586f * u2), m.y + sd.y * rad * sinf(6.283185307179586f * u2));
+}
+
 // ------------------------------------------------------------------------------------------ kernel 2
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -279,7 +305,7 @@ __device__ __forceinline__ void stage_image8(uint4 *dst, const void *src, int n_
 
 __global__ __launch_bounds__(kHeadWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const float *__restrict__ pooled,
-                float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value)
+                float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value, MlpAction act)
 {
     extern __shared__ uint4 wl[];           // one layer's fragments at a time: up to NT*(KS+1) KiB
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -358,45 +384,12 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const float
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) hd = mfma(as_frag(wl[kk * kWave + lane]), x[kk], hd);
     if (h == 0 && valid) {
-        reinterpret_cast<float2 *>(mu)[env] =
-            make_float2(2.0f * (sigmoidf_(hd[0]) - 0.5f), 2.0f * (sigmoidf_(hd[1]) - 0.5f));
-        reinterpret_cast<float2 *>(stdv)[env] = make_float2(sigmoidf_(hd[2]) + 1e-3f, sigmoidf_(hd[3]) + 1e-3f);
+        const float2 m = make_float2(2.0f * (sigmoidf_(hd[0]) - 0.5f), 2.0f * (sigmoidf_(hd[1]) - 0.5f));
+        const float2 sd = make_float2(sigmoidf_(hd[2]) + 1e-3f, sigmoidf_(hd[3]) + 1e-3f);
+        reinterpret_cast<float2 *>(mu)[env] = m;
+        reinterpret_cast<float2 *>(stdv)[env] = sd;
+        if (act.mode >= 0) reinterpret_cast<float2 *>(act.actions)[env] = mlp_action(act, env, m, sd);
     }
-}
-
-// ------------------------------------------------------------------------------------------ sampling
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
-{
-    for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_mlp_action(int N, const float *__restrict__ mu, const float *__restrict__ stdv,
-                                                    int sample, uint64_t seed, uint64_t env_index0, uint32_t step_index,
-                                                    float *__restrict__ actions)
-{
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= N) return;
-    float2 a = reinterpret_cast<const float2 *>(mu)[env];
-    if (sample) {
-        // Normal(mu, std).sample(): Box-Muller on two Philox uniforms keyed by (seed, global env, step)
-        const uint64_t g = env_index0 + (uint64_t)env;
-        uint32_t c[4] = { (uint32_t)g, (uint32_t)(g >> 32), step_index, 0x4D4C50u };
-        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        const float u1 = ((float)(c[0] >> 8) + 0.5f) * 5.9604644775390625e-08f;     // (0, 1)
-        const float u2 = ((float)(c[1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
-        const float rad = sqrtf(-2.0f * logf(u1));
-        const float2 s = reinterpret_cast<const float2 *>(stdv)[env];
-        a.x += s.x * rad * cosf(6.283185307179586f * u2);
-        a.y += s.y * rad * sinf(6.283185307179586f * u2);
-    }
-    reinterpret_cast<float2 *>(actions)[env] = a;
 }
 
 // ------------------------------------------------------------------------------------------ experiences
@@ -547,7 +540,7 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
 }
 
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
-                              float *pooled, float *mu, float *stdv, float *value, hipStream_t s)
+                              float *pooled, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s)
 {
     const dim3 grid((N + 4 * kWave - 1) / (4 * kWave));   // one workgroup per 4 groups of 64 envs
     const size_t lds = (size_t)(NT * KS + NT) * kWave * sizeof(uint4);
@@ -579,7 +572,7 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_head), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_head);
     hipLaunchKernelGGL(k_mlp_head, dim3((N + kHeadWaves * 32 - 1) / (kHeadWaves * 32)), dim3(kHeadWaves * kWave), lds_head, s,
-                       img, N, obs, pooled, mu, stdv, value);
+                       img, N, obs, pooled, mu, stdv, value, act);
     return hipGetLastError();
 }
 
@@ -601,14 +594,6 @@ hipError_t launch_exp_gae(const ExpBuffers &x, int N, const float *next_value, f
                           hipStream_t s)
 {
     hipLaunchKernelGGL(k_exp_gae, dim3((N + 255) / 256), dim3(256), 0, s, x, N, next_value, discount, gae_lambda);
-    return hipGetLastError();
-}
-
-hipError_t launch_mlp_action(int N, const float *mu, const float *stdv, int sample, uint64_t seed, uint64_t env_index0,
-                             uint32_t step_index, float *actions, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_mlp_action, dim3((N + 255) / 256), dim3(256), 0, s, N, mu, stdv, sample, seed, env_index0,
-                       step_index, actions);
     return hipGetLastError();
 }
 

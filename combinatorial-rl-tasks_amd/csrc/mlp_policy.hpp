@@ -34,14 +34,21 @@ struct MlpImages {
 // images are returned in `offs` (the last two only when the critic tensors are given).  h = hidden width (<= 191), F = zone features (6 or 7).
 int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, size_t offs[8]);
 
+// What the head kernel does with (mu, std) besides storing them: nothing (mode < 0), actions = mu (0), or
+// actions = mu + std * eps with eps ~ N(0,1) from Philox4x32-10 keyed by (seed, global env, step) (1) -- the
+// reference's dist.sample() (utils/agent.py:41-44).
+struct MlpAction {
+    int mode;
+    uint32_t step_index;
+    uint64_t seed, env_index0;
+    float *actions;
+};
+inline MlpAction no_mlp_action() { return MlpAction{ -1, 0u, 0ull, 0ull, nullptr }; }
+
 // obs [N,8], zone_obs [N,Z,F] float32 (device) -> mu, std [N,2] float32 (device).
 // pooled: scratch [N][kMlpHP] float32 (device).
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
-                              float *pooled, float *mu, float *stdv, float *value, hipStream_t s);
-// actions[N,2] = mu (sample = 0) or mu + std * eps, eps ~ N(0,1) from Philox4x32-10 keyed by
-// (seed, global env, step) -- the reference's dist.sample() (utils/agent.py:41-44).
-hipError_t launch_mlp_action(int N, const float *mu, const float *stdv, int sample, uint64_t seed, uint64_t env_index0,
-                             uint32_t step_index, float *actions, hipStream_t s);
+                              float *pooled, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s);
 
 // Experience buffers of one collect_experiences() call (base.py:131-216), env-major [N][T][...]
 struct ExpBuffers {

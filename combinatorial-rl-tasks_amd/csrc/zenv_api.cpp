@@ -709,7 +709,7 @@ extern "C" int zenv_mlp_forward(zenv_t *h)
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
-                               h->mlp_std, h->mlp_value, h->stream));
+                               h->mlp_std, h->mlp_value, no_mlp_action(), h->stream));
     return ZENV_OK;
 }
 
@@ -724,10 +724,10 @@ static int run_policy(zenv_t *h, const StepPolicy &pol)
         return ZENV_OK;
     }
     if (!h->mlp_ready) return fail(ZENV_E_STATE, "zenv_mlp_load first");
+    // the head kernel also turns (mu, std) into the action
+    const MlpAction act{ pol.policy == ZENV_POLICY_MLP_SAMPLE ? 1 : 0, pol.step_index, pol.seed, pol.env_index0, pol.out };
     HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
-                               h->mlp_std, h->mlp_value, h->stream));
-    HIP_TRY(launch_mlp_action(h->n_env, h->mlp_mu, h->mlp_std, pol.policy == ZENV_POLICY_MLP_SAMPLE, pol.seed,
-                              pol.env_index0, pol.step_index, pol.out, h->stream));
+                               h->mlp_std, h->mlp_value, act, h->stream));
     return ZENV_OK;
 }
 
@@ -783,7 +783,7 @@ extern "C" int zenv_collect(zenv_t *h, int T, uint64_t policy_seed, uint64_t env
     }
     // next_value = value(obs_T) (:177-187), then the GAE recursion
     HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
-                               h->mlp_std, h->mlp_value, h->stream));
+                               h->mlp_std, h->mlp_value, no_mlp_action(), h->stream));
     HIP_TRY(launch_exp_gae(h->exp, h->n_env, h->mlp_value, discount, gae_lambda, h->stream));
     return ZENV_OK;
 }
