@@ -152,3 +152,20 @@ def test_pinned_host_buffers_and_batched_download(zenv_mod):
         env.results_into((99,), [bufs[0]])
     env.close()
     assert np.isfinite(bufs[0]).all()          # pinned arrays outlive the env
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65])
+def test_persistent_rollout_tiny_and_ragged_batches(zenv_mod, oracle_mod, n):
+    Z, O = zenv_mod, oracle_mod
+    for task, zones in ((0, 25), (2, 6)):
+        cfg = Z.default_config(task, zones, zones_keepout=0.40 if zones == 25 else 0.55, num_steps=90)
+        env = Z.ZoneVecEnv(cfg, n)
+        env.build_bank(31, 8 * n)
+        env.schedule_sequential(stride=n)
+        env.reset()
+        env.rollout(300, Z.POLICY_GREEDY, policy_seed=5)        # 256 + 44 steps: two launches
+        ref = O.rollout(oracle_config_from(O, cfg), 31 + np.arange(n), 300, O.POLICY_GREEDY, seed_stride=n,
+                        policy_seed=5, seed_period=8, n_threads=2)
+        assert np.array_equal(env.get(Z.F_OBS), ref["obs"]) and np.array_equal(env.get(Z.F_ZONE_OBS), ref["zone_obs"])
+        assert np.array_equal(env.get(Z.F_EPISODES), ref["episodes"]) and ref["episodes"].min() >= 3
+        env.close()
