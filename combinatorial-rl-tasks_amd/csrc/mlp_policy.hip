@@ -137,11 +137,14 @@ __device__ __forceinline__ RawRow<F> load_row(const float *__restrict__ obs, con
 // registers; in return a wave fits in 256 registers and the SIMD always has a second wave to issue from
 // while one waits for an MFMA result, an LDS fragment or the next rows (one wave per SIMD measured: matrix
 // pipe 49 % busy, 29 % of the cycles in s_waitcnt, 30 % in issue stalls).
-constexpr int kZoneWaves = 8;
-constexpr int NH = NT / 2;               // output tiles per wave
+#ifndef MLP_SPLIT
+#define MLP_SPLIT 2                      // waves per 64-env group = waves per SIMD
+#endif
+constexpr int kZoneWaves = 4 * MLP_SPLIT;
+constexpr int NH = NT / MLP_SPLIT;       // output tiles per wave
 
 template <int ZT, int F>
-__global__ __launch_bounds__(kZoneWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(kZoneWaves * kWave) __attribute__((amdgpu_waves_per_eu(MLP_SPLIT, MLP_SPLIT)))
 void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, const float *__restrict__ zone_obs,
                 float *__restrict__ pooled)
 {
