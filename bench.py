@@ -211,7 +211,7 @@ def main():
                         "algorithmic_bytes_per_step_launch": algorithmic_bytes(task, zones, 1),
                         "env_steps_per_launch": n_env * chunk}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is an N = 1 figure (rank 0 only)
             cpu = cpu_baseline(cfg, task, zones, keepout, policy)
         ep = env.get(Z.F_EPISODES)
         out = {
@@ -234,7 +234,7 @@ def main():
                     if (returns != 0).any() else 0.0,
                     "parity_spot_check": parity_spot_check(env, cfg, shard, args, policy),
                     "per_step_launch_mode": per_step_rate(env, task, zones, policy, shard)
-                    if args.mode == "persistent" else None,
+                    if (args.mode == "persistent" and not distributed) else None,
                     "mlp_policy": None if (args.no_mlp or distributed) else mlp_policy_rate(env, zones)},
         }
         print(json.dumps(out), flush=True)
