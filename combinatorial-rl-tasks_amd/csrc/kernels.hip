@@ -5,15 +5,19 @@
 //                           Engine.step / mj_step of xmls/point.xml), with the ParallelEnv
 //                           auto-reset of penv.py:8-11 and (optionally) the scripted action
 //                           source of the next step fused in.
+// K1p k_rollout_lane<TASK,ZT> the same step, up to 256 of them per launch, when the action source is on the
+//                           device: env state in registers, one wave steps the envs, one streams the rows.
 // K2  k_reset_lane<TASK>    masked re-init from the HBM layout bank (Engine.reset).
 // K3  k_policy_lane<TASK>   stand-alone scripted action sources (the build's own).
+// K6  k_goal_set/step/clear goal-conditioned variants (TSP_next_city_env.py and its zone-goals siblings).
 //
 // Execution shape: a tile = 64 consecutive envs, lane i <-> env i.  State is struct-of-arrays
 // in 16-byte pairs (1 KiB per wave load), zone arrays are zone-major.  The (N,Z,F) float32
 // zone_obs rows are staged in LDS as compact 16-byte (x/3, y/3, code, aux) entries and expanded
 // to their F floats while they stream out as contiguous dwordx4 bursts.
-// No MFMA: there is no contraction anywhere on this path; the bound is memory bytes.
-// Build with -ffp-contract=off: the float64 state must match the CPU oracle bit for bit.
+// No MFMA: there is no contraction anywhere on this path (the actor network is mlp_policy.hip).
+// Build with -ffp-contract=off: the float64 state must match the CPU oracle bit for bit; every fused
+// multiply-add is an explicit __builtin_fma, mirrored in oracle/zenv_oracle.c.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
