@@ -146,7 +146,7 @@ constexpr int NH = NT / MLP_SPLIT;       // output tiles per wave
 template <int ZT, int F>
 __global__ __launch_bounds__(kZoneWaves * kWave) __attribute__((amdgpu_waves_per_eu(MLP_SPLIT, MLP_SPLIT)))
 void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, const float *__restrict__ zone_obs,
-                float *__restrict__ pooled)
+                __bf16 *__restrict__ pooled)
 {
     extern __shared__ uint4 lds[];
     uint4 *w2s = lds;                       // [NT*KS][64]
@@ -260,7 +260,12 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int e = e_base + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (e < n_env) pooled[(size_t)(env0 + e) * HP + 32 * (n0 + n) + r] = pool[n][i] * inv_z;
+                // bf16: kernel 2 feeds it to an MFMA as it is (half the bytes of a float32 mean, both ways).  Even
+                // lanes store their own and their neighbour's feature as one dword (2-byte stores were slower).
+                const float v = pool[n][i] * inv_z;
+                const float vn = __shfl_down(v, 1);
+                if (e < n_env && !(r & 1))
+                    *reinterpret_cast<uint32_t *>(pooled + (size_t)(env0 + e) * HP + 32 * (n0 + n) + r) = pk_bf16(v, vn);
             }
     }
 }
@@ -296,96 +301,119 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 // (Fetching the next layer's fragments into registers during the current layer's products and committing them
 // to a second LDS buffer afterwards was slower than plain staging: 48 us against 34 us.)
-// 8 waves per workgroup (two per SIMD), 32 envs per wave: the second wave of a SIMD covers the first one's
-// waits for LDS fragments and MFMA results, and the staging copies go twice as wide.
+// 8 waves per workgroup (two per SIMD), 32 envs per wave.  The layers' fragment images are staged into two LDS
+// buffers by LDS-DMA (global_load_lds_dwordx4: no VGPR destination), the next layer's image in flight while the
+// current layer is in the matrix pipe; a raw s_barrier + counted waits, because __syncthreads() would drain the
+// DMA at once (cdna_hip_programming.md, "Pipelining across barriers").
 constexpr int kHeadWaves = 8;
-__device__ __forceinline__ void stage_image8(uint4 *dst, const void *src, int n_frags)
+constexpr int kImgFrags = NT * (KS + 1);      // the largest image (combine_net_), in 1 KiB fragments
+
+__device__ __forceinline__ void stage_issue(uint4 *dst, const void *src, int n_frags)
 {
-    __syncthreads();    // everyone is done with what the buffer held
-    for (int i = threadIdx.x; i < n_frags * kWave; i += kHeadWaves * kWave) dst[i] = reinterpret_cast<const uint4 *>(src)[i];
-    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int i = threadIdx.x; i < n_frags * kWave; i += kHeadWaves * kWave)
+        // the LDS destination is wave-uniform base + lane * 16; the global source is per lane
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const uint4 *>(src) + i),
+                                         (__attribute__((address_space(3))) void *)(dst + (i - lane)), 16, 0, 0);
+}
+// every DMA this wave issued has landed, and every wave of the workgroup is here: the staged buffer may be read
+// and the other buffer may be overwritten
+__device__ __forceinline__ void stage_fence()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 __global__ __launch_bounds__(kHeadWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const float *__restrict__ pooled,
+void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf16 *__restrict__ pooled,
                 float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value, MlpAction act)
 {
-    extern __shared__ uint4 wl[];           // one layer's fragments at a time: up to NT*(KS+1) KiB
+    extern __shared__ uint4 wl2[];          // two buffers of kImgFrags KiB
+    uint4 *const bufA = wl2, *const bufB = wl2 + kImgFrags * kWave;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    // every wave of the workgroup takes part in the staging barriers, also one without envs
+    // every wave of the workgroup takes part in the staging, also one without envs
     const int first = (int)(blockIdx.x * kHeadWaves + wave) * 32;
     const int env = min(first + r, max(N - 1, 0));
     const bool valid = first + r < N;
+    const bool critic = img.wv1 != nullptr;
 
+    stage_issue(bufA, img.w3, NT * KS);
     bf16x8 x[KS], xo;
     {
-        const float4 *pr = reinterpret_cast<const float4 *>(pooled + (size_t)env * HP + 8 * h);
+        // the mean is stored in bf16, 8 consecutive features = one fragment
+        const uint4 *pr = reinterpret_cast<const uint4 *>(pooled + (size_t)env * HP + 8 * h);
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) x[kk] = frag_from_floats(pr[4 * kk], pr[4 * kk + 1]);
+        for (int kk = 0; kk < KS; ++kk) x[kk] = as_frag(pr[2 * kk]);
         const float4 *o = reinterpret_cast<const float4 *>(obs + (size_t)env * 8);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         xo = h == 0 ? frag_from_floats(o[0], o[1]) : frag_from_floats(z4, z4);
     }
     f32x16 acc[NT];
     // ---- e3 = W3 mean(H2)   (zone_net_.4 after the mean; no activation)
-    stage_image8(wl, img.w3, NT * KS);
+    stage_fence();
+    stage_issue(bufB, img.wc, NT * (KS + 1));
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
         acc[m] = zero16();
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(wl[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
+        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(bufA[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], false, x[2 * m], x[2 * m + 1]);
     // ---- c = Wc [e3; obs]   (combine_net_; no activation)
-    stage_image8(wl, img.wc, NT * (KS + 1));
+    stage_fence();
+    stage_issue(bufA, critic ? img.wv1 : img.wa, NT * KS);
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
         acc[m] = zero16();
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(wl[(m * (KS + 1) + kk) * kWave + lane]), x[kk], acc[m]);
-        acc[m] = mfma(as_frag(wl[(m * (KS + 1) + KS) * kWave + lane]), xo, acc[m]);
+        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(bufB[(m * (KS + 1) + kk) * kWave + lane]), x[kk], acc[m]);
+        acc[m] = mfma(as_frag(bufB[(m * (KS + 1) + KS) * kWave + lane]), xo, acc[m]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], false, x[2 * m], x[2 * m + 1]);
     // ---- value = Wv2 relu(Wv1 c)   (critic, flat_model.py:43-47), from the same embedding c
-    if (img.wv1) {
-        stage_image8(wl, img.wv1, NT * KS);
+    if (critic) {
+        stage_fence();
+        stage_issue(bufB, img.wv2, KS);
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
             acc[m] = zero16();
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(wl[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
+            for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(bufA[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
             __builtin_amdgcn_sched_barrier(0);
         }
         bf16x8 xv[KS];
 #pragma unroll
         for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], true, xv[2 * m], xv[2 * m + 1]);
-        stage_image8(wl, img.wv2, KS);
+        stage_fence();
+        stage_issue(bufA, img.wa, NT * KS);
         f32x16 hv = zero16();
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) hv = mfma(as_frag(wl[kk * kWave + lane]), xv[kk], hv);
+        for (int kk = 0; kk < KS; ++kk) hv = mfma(as_frag(bufB[kk * kWave + lane]), xv[kk], hv);
         if (h == 0 && valid) value[env] = hv[0];
     }
     // ---- a = relu(Wa c)   (actor.enc_)
-    stage_image8(wl, img.wa, NT * KS);
+    stage_fence();
+    stage_issue(bufB, img.wh, KS);
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
         acc[m] = zero16();
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(wl[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
+        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(bufA[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], true, x[2 * m], x[2 * m + 1]);
     // ---- heads: rows 0-1 = mu_, rows 2-3 = std_ (lane half 0, registers 0..3)
-    stage_image8(wl, img.wh, KS);
+    stage_fence();
     f32x16 hd = zero16();
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) hd = mfma(as_frag(wl[kk * kWave + lane]), x[kk], hd);
+    for (int kk = 0; kk < KS; ++kk) hd = mfma(as_frag(bufB[kk * kWave + lane]), x[kk], hd);
     if (h == 0 && valid) {
         const float2 m = make_float2(2.0f * (sigmoidf_(hd[0]) - 0.5f), 2.0f * (sigmoidf_(hd[1]) - 0.5f));
         const float2 sd = make_float2(sigmoidf_(hd[2]) + 1e-3f, sigmoidf_(hd[3]) + 1e-3f);
@@ -543,8 +571,9 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
 }
 
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
-                              float *pooled, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s)
+                              void *pooled_v, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s)
 {
+    __bf16 *pooled = static_cast<__bf16 *>(pooled_v);
     const dim3 grid((N + 4 * kWave - 1) / (4 * kWave));   // one workgroup per 4 groups of 64 envs
     const size_t lds = (size_t)(NT * KS + NT) * kWave * sizeof(uint4);
 #define ZENV_MLP(ZT, FF)                                                                                          \
@@ -571,7 +600,7 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
 #undef ZENV_MLP
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const size_t lds_head = (size_t)NT * (KS + 1) * kWave * sizeof(uint4);
+    const size_t lds_head = 2 * (size_t)kImgFrags * kWave * sizeof(uint4);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_head), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_head);
     hipLaunchKernelGGL(k_mlp_head, dim3((N + kHeadWaves * 32 - 1) / (kHeadWaves * 32)), dim3(kHeadWaves * kWave), lds_head, s,

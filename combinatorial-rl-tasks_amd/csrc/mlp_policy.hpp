@@ -46,9 +46,9 @@ struct MlpAction {
 inline MlpAction no_mlp_action() { return MlpAction{ -1, 0u, 0ull, 0ull, nullptr }; }
 
 // obs [N,8], zone_obs [N,Z,F] float32 (device) -> mu, std [N,2] float32 (device).
-// pooled: scratch [N][kMlpHP] float32 (device).
+// pooled: scratch [N][kMlpHP] bf16 (device).
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
-                              float *pooled, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s);
+                              void *pooled, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s);
 
 // Experience buffers of one collect_experiences() call (base.py:131-216), env-major [N][T][...]
 struct ExpBuffers {

@@ -69,7 +69,8 @@ struct zenv {
     // actor network (zenv_mlp_load)
     void *mlp_mem = nullptr;
     MlpImages mlp{};
-    float *mlp_pooled = nullptr, *mlp_mu = nullptr, *mlp_std = nullptr, *mlp_value = nullptr;
+    void *mlp_pooled = nullptr;
+    float *mlp_mu = nullptr, *mlp_std = nullptr, *mlp_value = nullptr;
     bool mlp_ready = false;
     // goal-conditioned variant (zenv_goal_enable)
     bool goal_enabled = false;
@@ -383,7 +384,7 @@ extern "C" int zenv_destroy(zenv_t *h)
     for (void *m : h->bank_mem)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
-    for (void *m : { h->mlp_mem, (void *)h->mlp_pooled, (void *)h->mlp_mu, (void *)h->mlp_std, (void *)h->mlp_value,
+    for (void *m : { h->mlp_mem, h->mlp_pooled, (void *)h->mlp_mu, (void *)h->mlp_std, (void *)h->mlp_value,
                      (void *)h->p.visit_zone, (void *)h->p.term_xy, (void *)h->p.goal, (void *)h->p.goal_last,
                      (void *)h->p.goal_xy, (void *)h->p.shaped, (void *)h->p.need_goal, (void *)h->p.available,
                      (void *)h->goal_in, (void *)h->goal_bad, h->exp_mem })
@@ -690,7 +691,7 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     HIP_TRY(hipMalloc(&h->mlp_mem, img.size() * 2));
     if (!h->mlp_value) HIP_TRY(hipMalloc((void **)&h->mlp_value, N * sizeof(float)));
     HIP_TRY(hipMemsetAsync(h->mlp_value, 0, N * sizeof(float), h->stream));
-    if (!h->mlp_pooled) HIP_TRY(hipMalloc((void **)&h->mlp_pooled, N * kMlpHP * sizeof(float)));
+    if (!h->mlp_pooled) HIP_TRY(hipMalloc(&h->mlp_pooled, N * kMlpHP * sizeof(uint16_t)));
     if (!h->mlp_mu) HIP_TRY(hipMalloc((void **)&h->mlp_mu, N * 2 * sizeof(float)));
     if (!h->mlp_std) HIP_TRY(hipMalloc((void **)&h->mlp_std, N * 2 * sizeof(float)));
     HIP_TRY(hipMemcpy(h->mlp_mem, img.data(), img.size() * 2, hipMemcpyHostToDevice));
