@@ -27,7 +27,7 @@ E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE = -1, -2, -3, -4, -5
  F_LAST_LEN, F_EPISODES, F_VISIT_COUNT, F_SEED, F_ACTIONS, F_POLICY_MU, F_POLICY_STD, F_POLICY_VALUE,
  F_SHAPED_REWARD, F_NEED_GOAL, F_AVAILABLE_GOALS, F_GOAL,
  F_EXP_OBS, F_EXP_ZONE_OBS, F_EXP_ACTION, F_EXP_LOG_PROB, F_EXP_VALUE, F_EXP_REWARD, F_EXP_MASK,
- F_EXP_ADVANTAGE, F_EXP_RETURN) = range(29)
+ F_EXP_ADVANTAGE, F_EXP_RETURN, F_ORDER_VAL) = range(30)
 
 
 MLP_TENSORS = ("zone_w1", "zone_b1", "zone_w2", "zone_b2", "zone_w3", "zone_b3", "comb_w", "comb_b",
@@ -93,6 +93,8 @@ _PROTOTYPES = {
     "zenv_rollout": (C.c_int, [_H, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "zenv_collect": (C.c_int, [_H, C.c_int, C.c_uint64, C.c_uint64, C.c_float, C.c_float]),
+    "zenv_order_enable": (C.c_int, [_H]),
+    "zenv_route_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "zenv_goal_enable": (C.c_int, [_H]),
     "zenv_set_goals": (C.c_int, [_H, C.c_void_p]),
     "zenv_mlp_load": (C.c_int, [_H, C.c_void_p]),

@@ -58,6 +58,10 @@ struct DevParams {
     double *shaped;         // info['shaped_reward']
     uint8_t *need_goal;     // info['need_next_goal']
     uint32_t *available;    // get_available_goals() as a bit mask
+    // solver-ordered variant (TSP_order_env.py), null unless zenv_order_enable(): position of every zone in
+    // the remaining route (-1: visited) and the observation's order feature 0.5^position
+    int8_t *order_pos;      // [N][Z]
+    float *order_val;       // [N][Z]
     int64_t *seed;
     // schedule
     int32_t *slot_first, *episode_idx;

@@ -1,7 +1,9 @@
 // host_sampler.cpp -- see host_sampler.hpp.
 #include "host_sampler.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <vector>
 #include <cstring>
 
 #include "det_math.hpp"
@@ -311,6 +313,39 @@ int sample_layout(const zenv_config &cfg, int64_t seed, Layout &out)
 }
 
 void det_sincos(double x, double &s, double &c) { det_sincos_inl(x, s, c); }
+
+void route_ranks(double robot_x, double robot_y, const double (*zone_xy)[2], int Z, int32_t *rank)
+{
+    // node 0 = the robot (depot), nodes 1..Z = zones
+    const int n = Z + 1;
+    std::vector<double> x(n), y(n);
+    x[0] = robot_x; y[0] = robot_y;
+    for (int z = 0; z < Z; ++z) { x[z + 1] = zone_xy[z][0]; y[z + 1] = zone_xy[z][1]; }
+    auto d = [&](int a, int b) { return std::sqrt((x[a] - x[b]) * (x[a] - x[b]) + (y[a] - y[b]) * (y[a] - y[b])); };
+    std::vector<int> tour(1, 0);
+    std::vector<char> used(n, 0);
+    used[0] = 1;
+    for (int step = 1; step < n; ++step) {           // nearest neighbour, lowest index on ties
+        int best = -1;
+        for (int c = 1; c < n; ++c)
+            if (!used[c] && (best < 0 || d(tour.back(), c) < d(tour.back(), best))) best = c;
+        used[best] = 1;
+        tour.push_back(best);
+    }
+    bool improved = true;                            // 2-opt on the closed tour, depot fixed at position 0
+    while (improved) {
+        improved = false;
+        for (int i = 1; i < n - 1; ++i)
+            for (int j = i + 1; j < n; ++j) {
+                const int a = tour[i - 1], b = tour[i], c = tour[j], e = tour[(j + 1) % n];
+                if (d(a, c) + d(b, e) < d(a, b) + d(c, e) - 1e-12) {
+                    std::reverse(tour.begin() + i, tour.begin() + j + 1);
+                    improved = true;
+                }
+            }
+    }
+    for (int k = 1; k < n; ++k) rank[tour[k] - 1] = k - 1;
+}
 
 double sqrt_threshold(double r)
 {

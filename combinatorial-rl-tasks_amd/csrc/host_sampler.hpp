@@ -54,6 +54,12 @@ struct Layout {
 // Returns 0 or ZENV_E_LAYOUT.
 int sample_layout(const zenv_config &cfg, int64_t seed, Layout &out);
 
+// A visiting order for the solver-ordered variant (TSP_order_env.py:49-50 calls OR-tools, which is not available
+// here): closed tour from the robot, nearest-neighbour construction (what OR-tools' PATH_CHEAPEST_ARC starts
+// from) improved by 2-opt to a local optimum.  rank[z] = position of zone z in the route.  Callers with a real
+// solver pass their own ranks through zenv_bank_set's aux column.
+void route_ranks(double robot_x, double robot_y, const double (*zone_xy)[2], int Z, int32_t *rank);
+
 // deterministic sin/cos shared in spirit with the device code (same algorithm, same bits)
 void det_sincos(double x, double &s, double &c);
 

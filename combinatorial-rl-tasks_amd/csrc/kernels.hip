@@ -1852,6 +1852,106 @@ __global__ __launch_bounds__(256) void k_goal_step(DevParams p)
     p.available[env] = p.task == ZENV_TASK_COLOUR_MATCH ? full : (~p.vis[env] & full);
 }
 
+// =========================================================================== K7: solver-ordered TSP
+// TSPOrderEnv (main/envs/TSP_order_env.py:13-113): the zones carry a visiting order (a route from a TSP solver,
+// here the bank's aux column: rank of every zone), the observation gets the feature 0.5^(position in the remaining
+// route) per zone (:37-47) and info['shaped_reward'] is the progress towards the first zone of the remaining route
+// (:52-75).  Like K6 it runs after the step kernel, on the zone visited in the step and the terminal position.
+__device__ __forceinline__ int current_bank_slot(const DevParams &p, int env)
+{
+    if (p.sched_mode == SCHED_SEQUENTIAL) {
+        const long long s = (long long)p.slot_first[env] + (long long)(p.episode_idx[env] - 1) * (long long)p.sched_stride;
+        return (int)(s % (long long)p.bank_size);
+    }
+    return (int)(p.seed[env] - p.seed_min);
+}
+__device__ __forceinline__ void env_world_pos(const DevParams &p, int env, double &rx, double &ry)
+{
+    EnvRegs e;
+    const double2 qa = p.qa[env], fa = p.fa[env], fb = p.fb[env];
+    e.q0 = qa.x; e.q1 = qa.y; e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
+    world_pos(e, rx, ry);
+}
+// route[0] = the unvisited zone at position 0; dist_to_goal (:52-57), 0 for an empty route
+__device__ __forceinline__ double order_goal_dist(const DevParams &p, int env, const int8_t *pos, double rx, double ry,
+                                                  bool from_goal_xy)
+{
+    int g = -1;
+    for (int z = 0; z < p.Z; ++z)
+        if (pos[z] == 0) g = z;
+    p.goal[env] = g;
+    if (g < 0) return 0.0;
+    const double2 zz = from_goal_xy ? p.goal_xy[env] : p.zxy[(size_t)g * p.N + env];
+    if (!from_goal_xy) p.goal_xy[env] = zz;
+    const double dx = zz.x - rx, dy = zz.y - ry;
+    return sqrt(dx * dx + dy * dy);
+}
+__device__ __forceinline__ void order_load_route(const DevParams &p, int env)
+{
+    // reset(): generate_route(), last_dist_to_goal = dist_to_goal() (:108-113)
+    int8_t *pos = p.order_pos + (size_t)env * p.Z;
+    float *val = p.order_val + (size_t)env * p.Z;
+    const int32_t *rank = p.bank_aux + (size_t)current_bank_slot(p, env) * p.Z;
+    for (int z = 0; z < p.Z; ++z) {
+        pos[z] = (int8_t)rank[z];
+        val[z] = __builtin_ldexpf(1.0f, -rank[z]);            // np.power(0.5, route.index(i))
+    }
+    double rx, ry;
+    env_world_pos(p, env, rx, ry);
+    p.goal_last[env] = order_goal_dist(p, env, pos, rx, ry, false);
+}
+
+__global__ __launch_bounds__(256) void k_order_reset(DevParams p, const uint8_t *__restrict__ mask)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.N || (mask && !mask[env])) return;
+    order_load_route(p, env);
+    p.shaped[env] = 0.0;
+    p.visit_zone[env] = -1;
+}
+
+__global__ __launch_bounds__(256) void k_order_step(DevParams p)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.N) return;
+    int8_t *pos = p.order_pos + (size_t)env * p.Z;
+    float *val = p.order_val + (size_t)env * p.Z;
+    const bool done = p.done_out[env] != 0;
+    const bool was_reset = done && !p.done_state[env];
+    const int v = p.visit_zone[env];
+    if (v >= 0) {
+        // set_mocaps: self.route.remove(h_index) (:90)
+        const int pv = pos[v];
+        for (int z = 0; z < p.Z; ++z)
+            if (pos[z] > pv) pos[z] -= 1;
+        pos[v] = -1;
+    }
+    double rx, ry;
+    if (was_reset) {
+        const double2 t = p.term_xy[env];                      // where the finished episode ended
+        rx = t.x; ry = t.y;
+    } else {
+        env_world_pos(p, env, rx, ry);
+    }
+    // shaped_reward() (:63-72): after a visit the reference re-bases on the NEW first zone and returns 0
+    double sh = 0.0;
+    if (v >= 0) {
+        // the new route[0] belongs to the finished episode's map: its centre must come from zxy only when that
+        // map is still loaded
+        if (!was_reset) p.goal_last[env] = order_goal_dist(p, env, pos, rx, ry, false);
+    } else {
+        const double d = order_goal_dist(p, env, pos, rx, ry, true);
+        sh = p.goal_last[env] - d;
+        p.goal_last[env] = d;
+    }
+    p.shaped[env] = sh;
+    if (was_reset) {
+        order_load_route(p, env);                              // the next episode's route and observation feature
+    } else {
+        for (int z = 0; z < p.Z; ++z) val[z] = pos[z] >= 0 ? __builtin_ldexpf(1.0f, -pos[z]) : 0.f;
+    }
+}
+
 // =========================================================================== K2: reset
 template <int TASK>
 __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t *__restrict__ mask)
@@ -1959,6 +2059,18 @@ hipError_t launch_rollout(const DevParams &p, int n_steps, int auto_reset, const
     case ZENV_TASK_TIMED_TSP: launch_rollout_task<ZENV_TASK_TIMED_TSP>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop); break;
     default: launch_rollout_task<ZENV_TASK_COLOUR_MATCH>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_order_reset(const DevParams &p, const uint8_t *mask, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_order_reset, dim3((p.N + 255) / 256), dim3(256), 0, s, p, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_order_step(const DevParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_order_step, dim3((p.N + 255) / 256), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -74,6 +74,7 @@ struct zenv {
     bool mlp_ready = false;
     // goal-conditioned variant (zenv_goal_enable)
     bool goal_enabled = false;
+    bool order_enabled = false;   // solver-ordered variant (zenv_order_enable)
     int32_t *goal_in = nullptr, *goal_bad = nullptr;
     // experience buffers (zenv_collect)
     ExpBuffers exp{};
@@ -184,6 +185,7 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_EXP_MASK: return { h->exp.mask, h->exp.obs ? N * h->exp.T * 4 : 0 };
     case ZENV_F_EXP_ADVANTAGE: return { h->exp.advantage, h->exp.obs ? N * h->exp.T * 4 : 0 };
     case ZENV_F_EXP_RETURN: return { h->exp.returnn, h->exp.obs ? N * h->exp.T * 4 : 0 };
+    case ZENV_F_ORDER_VAL: return { p.order_val, p.order_val ? N * p.Z * 4 : 0 };
     default: return { nullptr, 0 };
     }
 }
@@ -387,7 +389,8 @@ extern "C" int zenv_destroy(zenv_t *h)
     for (void *m : { h->mlp_mem, h->mlp_pooled, (void *)h->mlp_mu, (void *)h->mlp_std, (void *)h->mlp_value,
                      (void *)h->p.visit_zone, (void *)h->p.term_xy, (void *)h->p.goal, (void *)h->p.goal_last,
                      (void *)h->p.goal_xy, (void *)h->p.shaped, (void *)h->p.need_goal, (void *)h->p.available,
-                     (void *)h->goal_in, (void *)h->goal_bad, h->exp_mem })
+                     (void *)h->goal_in, (void *)h->goal_bad, h->exp_mem, (void *)h->p.order_pos,
+                     (void *)h->p.order_val })
         if (m) (void)hipFree(m);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -472,6 +475,8 @@ extern "C" int zenv_bank_build_seeds(zenv_t *h, const int64_t *seed_list, int co
                 zone[(i * Z + z) * 2 + 1] = L.zone_xy[z][1];
                 aux[i * Z + z] = L.aux[z];
             }
+            // solver-ordered variant: the aux column of a PointTSP bank carries the route (rank per zone)
+            if (h->order_enabled && status[i] == 0) route_ranks(L.robot_x, L.robot_y, L.zone_xy, Z, &aux[i * Z]);
         }
     };
     if (n_threads == 1) {
@@ -521,6 +526,21 @@ extern "C" int zenv_bank_set(zenv_t *h, const double *robot_xyrot, const double 
             if (h->cfg.task == ZENV_TASK_COLOUR_MATCH && (aux_in[i] < 0 || aux_in[i] > 2))
                 return fail(ZENV_E_ARG, "colour %d outside 0..2", aux_in[i]);
             aux[i] = aux_in[i];
+        }
+    }
+    if (h->order_enabled) {
+        // solver-ordered variant: the aux column is the route (rank per zone); the caller's must be a
+        // permutation of 0..Z-1, a missing one is filled with the built-in tour
+        for (size_t i = 0; i < S; ++i) {
+            if (!aux_in) {
+                route_ranks(robot_xyrot[3 * i], robot_xyrot[3 * i + 1],
+                            reinterpret_cast<const double(*)[2]>(zone_xy + i * Z * 2), Z, &aux[i * Z]);
+                continue;
+            }
+            uint64_t seen = 0;
+            for (int z = 0; z < Z; ++z)
+                if (aux[i * Z + z] >= 0 && aux[i * Z + z] < Z) seen |= 1ull << aux[i * Z + z];
+            if (seen != (Z >= 64 ? ~0ull : (1ull << Z) - 1)) return fail(ZENV_E_ARG, "route %zu is not a permutation of 0..%d", i, Z - 1);
         }
     }
     return upload_bank(h, robot4, zone, aux, seeds);
@@ -598,6 +618,7 @@ extern "C" int zenv_reset(zenv_t *h, const uint8_t *mask)
     }
     HIP_TRY(launch_reset(h->p, dmask, h->stream));
     if (h->goal_enabled) HIP_TRY(launch_goal_clear(h->p, dmask, h->stream));
+    if (h->order_enabled) HIP_TRY(launch_order_reset(h->p, dmask, h->stream));
     h->was_reset = true;
     return ZENV_OK;
 }
@@ -619,7 +640,49 @@ extern "C" int zenv_step(zenv_t *h, const float *actions, int actions_on_device,
     }
     HIP_TRY(launch_step(h->p, d_act, auto_reset, no_policy(), h->stream));
     if (h->goal_enabled) HIP_TRY(launch_goal_step(h->p, h->stream));
+    if (h->order_enabled) HIP_TRY(launch_order_step(h->p, h->stream));
     h->step_count += 1;
+    return ZENV_OK;
+}
+
+// ============================================================================ solver-ordered variant
+extern "C" int zenv_route_ranks(const double *robot_xy, const double *zone_xy, int num_zones, int32_t *rank)
+{
+    if (!robot_xy || !zone_xy || !rank) return fail(ZENV_E_ARG, "null argument");
+    if (num_zones < 1 || num_zones > ZENV_MAX_ZONES) return fail(ZENV_E_ARG, "num_zones outside [1,%d]", ZENV_MAX_ZONES);
+    route_ranks(robot_xy[0], robot_xy[1], reinterpret_cast<const double(*)[2]>(zone_xy), num_zones, rank);
+    return ZENV_OK;
+}
+
+extern "C" int zenv_order_enable(zenv_t *h)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (h->cfg.task != ZENV_TASK_TSP) return fail(ZENV_E_ARG, "the solver-ordered variant is a PointTSP variant");
+    if (h->goal_enabled) return fail(ZENV_E_STATE, "a handle is goal-conditioned or solver-ordered, not both");
+    if (h->bank_ready) return fail(ZENV_E_STATE, "call zenv_order_enable before building the bank (routes ride in it)");
+    if (h->order_enabled) return ZENV_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t N = (size_t)h->n_env, Z = (size_t)h->p.Z;
+    DevParams &p = h->p;
+    HIP_TRY(hipMalloc((void **)&p.visit_zone, N * 4));
+    HIP_TRY(hipMalloc((void **)&p.term_xy, N * 16));
+    HIP_TRY(hipMalloc((void **)&p.goal, N * 4));
+    HIP_TRY(hipMalloc((void **)&p.goal_last, N * 8));
+    HIP_TRY(hipMalloc((void **)&p.goal_xy, N * 16));
+    HIP_TRY(hipMalloc((void **)&p.shaped, N * 8));
+    HIP_TRY(hipMalloc((void **)&p.order_pos, N * Z));
+    HIP_TRY(hipMalloc((void **)&p.order_val, N * Z * 4));
+    HIP_TRY(hipMemsetAsync(p.term_xy, 0, N * 16, h->stream));
+    HIP_TRY(hipMemsetAsync(p.goal_xy, 0, N * 16, h->stream));
+    HIP_TRY(hipMemsetAsync(p.goal_last, 0, N * 8, h->stream));
+    HIP_TRY(hipMemsetAsync(p.shaped, 0, N * 8, h->stream));
+    HIP_TRY(hipMemsetAsync(p.goal, 0xFF, N * 4, h->stream));
+    HIP_TRY(hipMemsetAsync(p.visit_zone, 0xFF, N * 4, h->stream));
+    HIP_TRY(hipMemsetAsync(p.order_pos, 0xFF, N * Z, h->stream));
+    HIP_TRY(hipMemsetAsync(p.order_val, 0, N * Z * 4, h->stream));
+    h->order_enabled = true;
     return ZENV_OK;
 }
 
@@ -628,6 +691,7 @@ extern "C" int zenv_goal_enable(zenv_t *h)
 {
     if (!h) return fail(ZENV_E_ARG, "null handle");
     if (h->goal_enabled) return ZENV_OK;
+    if (h->order_enabled) return fail(ZENV_E_STATE, "a handle is goal-conditioned or solver-ordered, not both");
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -812,7 +876,8 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     if (steps < 0) return fail(ZENV_E_ARG, "steps must be >= 0");
     if (!policy_known(policy)) return fail(ZENV_E_ARG, "unknown policy %d", policy);
     if (policy_is_mlp(policy) && !h->mlp_ready) return fail(ZENV_E_STATE, "zenv_mlp_load first");
-    if (h->goal_enabled) return fail(ZENV_E_STATE, "goal-conditioned envs are stepped with zenv_step");
+    if (h->goal_enabled || h->order_enabled)
+        return fail(ZENV_E_STATE, "goal-conditioned / solver-ordered envs are stepped with zenv_step");
     int rc = use_device(h);
     if (rc) return rc;
     // the actor network is its own launch sequence: policy, then step, every step

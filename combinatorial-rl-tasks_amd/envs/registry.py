@@ -1,6 +1,6 @@
 """The gym registry of main/envs/__init__.py:7-141 for the ids on the MI355X hot path."""
 from .zone_envs import (ColourMatchEnv, ColourMatchNextCityEnv, TimedTSPEnv, TimedTSPNextCityEnv, TSPEnv,
-                        TSPNextCityEnv)
+                        TSPNextCityEnv, TSPOrderEnv)
 
 config_point = {                      # __init__.py:7-14
     "robot_base": "xmls/point.xml", "num_cities": 15, "walled": False,
@@ -21,13 +21,14 @@ REGISTRY = {
     "PointTTSP-v0": (TimedTSPEnv, config_point),           # :127-129
     "PointTTSP-v1": (TimedTSPEnv, config_point_easy),      # :131-133
     "ColourMatch-v0": (ColourMatchEnv, config_point_colour),   # :136-138
+    "PointTSP-v2": (TSPOrderEnv, config_point),            # :98-100 solver-ordered (own tour instead of OR-tools)
     "PointTSP-v3": (TSPNextCityEnv, config_point),         # :104-106 goal-conditioned
     "PointTTSP-v3": (TimedTSPNextCityEnv, config_point),   # zone-goals/envs/__init__.py:140-142
     "ColourMatch-v3": (ColourMatchNextCityEnv, config_point_colour),   # zone-goals/envs/__init__.py:151-153
 }
 
 # registered by the reference but outside this build (other robots, solver/goal variants)
-OUT_OF_SCOPE = ("PointTSP-v2", "PointTSP-v4", "PointTSP-v5", "CarTSP-v0", "DoggoTSP-v0")
+OUT_OF_SCOPE = ("PointTSP-v4", "PointTSP-v5", "CarTSP-v0", "DoggoTSP-v0")
 
 
 def make(env_id, **kwargs):

@@ -221,6 +221,59 @@ class TSPNextCityEnv(TSPEnv):
         return np.array([(mask >> i) & 1 for i in range(self.num_cities)], bool)
 
 
+class TSPOrderEnv(TSPEnv):
+    """PointTSP-v2 (main/envs/TSP_order_env.py:13-113): the observation carries the visiting order of the cities
+    (7th row feature 0.5^i for the i-th city of the remaining route) and info['shaped_reward'] is the progress
+    towards the next city of the route.  The reference gets the route from OR-tools (:49-50, not available
+    here); this class uses the library's nearest-neighbour + 2-opt tour, or ``route_fn(robot_xyrot, zone_xy)
+    -> rank[Z]`` when the caller brings a solver."""
+
+    def __init__(self, config, route_fn=None, **kw):
+        self._route_fn = route_fn
+        super().__init__(config, **kw)
+        self._vec.enable_order()
+
+    def build_observation_space(self):
+        super().build_observation_space()
+        for i in range(self.num_cities):                                   # :31-35: 6 + the order feature
+            self.obs_space_dict[f"zones_lidar_{i}"] = Box(-np.inf, np.inf, (7,), dtype=np.float32)
+        self.observation_space = Dict(self.obs_space_dict)
+
+    def reset(self):
+        if self._seed is None:
+            self.seed(None)
+        s = int(self._seed)
+        from ..vec_env import sample_layout
+        robot, zxy, _, _ = sample_layout(self._cfg, s)
+        rank = None if self._route_fn is None else np.asarray(self._route_fn(robot, zxy), np.int32)
+        self._vec.set_bank(robot[None], zxy[None], aux=None if rank is None else rank[None], seeds=[s])
+        self._vec.schedule_sequential()
+        self._vec.reset()
+        self._seed = s + 1
+        self.done = False
+        self.steps = 0
+        return self.obs()
+
+    def step(self, action):
+        obs, reward, done, info = super().step(action)
+        info["shaped_reward"] = float(self._vec.get(nat.F_SHAPED_REWARD)[0])   # :78
+        return obs, reward, done, info
+
+    def obs(self):
+        out = super().obs()
+        val = self._vec.get(nat.F_ORDER_VAL)[0].astype(np.float64)
+        for i in range(self.num_cities):
+            out[f"zones_lidar_{i}"] = np.concatenate((out[f"zones_lidar_{i}"], val[i:i + 1]))
+        return out
+
+    @property
+    def route(self):
+        """Indices of the cities still to visit, in order (TSP_order_env.py: self.route)."""
+        val = self._vec.get(nat.F_ORDER_VAL)[0]
+        idx = [i for i in range(self.num_cities) if val[i] > 0]
+        return sorted(idx, key=lambda i: -val[i])
+
+
 class TimedTSPNextCityEnv(TSPNextCityEnv):
     """zone-goals/envs/TTSP_next_city_env.py:14-51: TSPNextCityEnv with per-city deadlines."""
     _TASK = nat.TASK_TIMED_TSP

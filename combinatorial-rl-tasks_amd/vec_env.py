@@ -21,7 +21,7 @@ _FIELD_DTYPES = {
     nat.F_EPISODES: np.int32, nat.F_VISIT_COUNT: np.int32, nat.F_SEED: np.int64,
     nat.F_ACTIONS: np.float32, nat.F_POLICY_MU: np.float32, nat.F_POLICY_STD: np.float32,
     nat.F_POLICY_VALUE: np.float32, nat.F_SHAPED_REWARD: np.float64, nat.F_NEED_GOAL: np.uint8,
-    nat.F_AVAILABLE_GOALS: np.uint32, nat.F_GOAL: np.int32,
+    nat.F_AVAILABLE_GOALS: np.uint32, nat.F_GOAL: np.int32, nat.F_ORDER_VAL: np.float32,
 }
 
 
@@ -84,6 +84,16 @@ def sample_layout(cfg, seed):
     check(lib().zenv_sample_layout(C.byref(cfg), int(seed), robot.ctypes.data, zones.ctypes.data,
                                    aux.ctypes.data, C.byref(restarts)))
     return robot, zones, aux, restarts.value
+
+
+def route_ranks(robot_xy, zone_xy):
+    """The built-in visiting order of a layout (TSPOrderEnv without OR-tools): rank[z] = position of zone z in a
+    nearest-neighbour + 2-opt tour from the robot."""
+    r = np.ascontiguousarray(robot_xy, np.float64)[:2].copy()
+    z = np.ascontiguousarray(zone_xy, np.float64)
+    rank = np.zeros(z.shape[0], np.int32)
+    check(lib().zenv_route_ranks(r.ctypes.data, z.ctypes.data, z.shape[0], rank.ctypes.data))
+    return rank
 
 
 def fixed_seed_sequence(rng_seed, min_seed, max_seed, count):
@@ -212,6 +222,16 @@ class ZoneVecEnv:
                                  C.byref(kern) if time_step_kernel else None))
         return total.value, (kern.value if time_step_kernel else None)
 
+    # ------------------------------------------------------------------ solver-ordered variant (8(f) row 3)
+    def enable_order(self):
+        """TSPOrderEnv semantics (TSP_order_env.py:13-113); call before build_bank / set_bank -- an episode's
+        route is the bank's aux column (built-in nearest-neighbour + 2-opt tour, or the caller's ranks)."""
+        check(lib().zenv_order_enable(self._h))
+
+    def order_info(self):
+        """(shaped_reward float64 [N], order feature float32 [N,Z]: 0.5^(position in the remaining route))."""
+        return self.get(nat.F_SHAPED_REWARD), self.get(nat.F_ORDER_VAL)
+
     # ------------------------------------------------------------------ goal-conditioned variant (8(f) row 3)
     def enable_goals(self):
         """TSPNextCityEnv / TimedTSPNextCityEnv semantics (TSP_next_city_env.py:41-109): after this every
@@ -302,6 +322,8 @@ class ZoneVecEnv:
         N = self.num_envs
         if field == nat.F_OBS:
             return (N, nat.OBS_DIM)
+        if field == nat.F_ORDER_VAL:
+            return (N, self.num_zones)
         if field == nat.F_ZONE_OBS:
             return (N, self.num_zones, self.zone_feat)
         if field in (nat.F_ACTIONS, nat.F_POLICY_MU, nat.F_POLICY_STD):

@@ -76,6 +76,7 @@ enum {
     ZENV_F_EXP_MASK = 26,        /* float32 [N,T]    1 - done of the previous step (:149-150) */
     ZENV_F_EXP_ADVANTAGE = 27,   /* float32 [N,T]    GAE (:190-196) */
     ZENV_F_EXP_RETURN = 28,      /* float32 [N,T]    value + advantage (:226) */
+    ZENV_F_ORDER_VAL = 29,       /* float32 [N,Z]    TSPOrderEnv's 7th row feature 0.5^(position in the route), 0 when visited */
     ZENV_F_COUNT = 13
 };
 
@@ -205,6 +206,18 @@ int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_
  * the goal arrays are not part of zenv_get_state(). */
 int zenv_goal_enable(zenv_t *h);
 int zenv_set_goals(zenv_t *h, const int32_t *goals);
+
+/* ---- solver-ordered variant: TSPOrderEnv, main/envs/TSP_order_env.py:13-113 (PointTSP-v2) ----
+ * TSP handles only; call before building the bank.  The route of an episode is the bank's aux column (rank of
+ * every zone in the visiting order): zenv_bank_build* fill it with a nearest-neighbour + 2-opt tour from the
+ * robot (OR-tools, which the reference calls at :49-50, is not available), zenv_bank_set takes the caller's.
+ * Every zenv_step() then also yields info['shaped_reward'] (ZENV_F_SHAPED_REWARD, :63-72) and the order feature
+ * of every zone (ZENV_F_ORDER_VAL, :37-47) -- the reference's (Z,7) row is [zone_obs row (6), order value].
+ * Exclusive with zenv_goal_enable; zenv_rollout() is refused on such a handle. */
+int zenv_order_enable(zenv_t *h);
+/* The built-in route of a layout (host only): rank[z] = position of zone z in the nearest-neighbour + 2-opt tour
+ * that starts at the robot. */
+int zenv_route_ranks(const double *robot_xy, const double *zone_xy, int num_zones, int32_t *rank);
 
 /* ---- the reference's actor network on the device ----
  * ZoneEnvModel (main/src/env_model.py:48-79) + the actor of ACModel (flat_model.py:24-37,

@@ -69,6 +69,7 @@ class Env(C.Structure):
         ("goal_dist", C.c_int32), ("steps", C.c_int32), ("done", C.c_int32),
         ("layout_restarts", C.c_int32),
         ("goal_zone", C.c_int32), ("last_visit", C.c_int32), ("last_dist", C.c_double),
+        ("route", C.c_int32 * MAX_Z), ("route_len", C.c_int32),
     ]
 
 
@@ -114,6 +115,10 @@ def lib():
                                   C.c_void_p, C.c_void_p]
         L.orc_rollout.restype = C.c_int64
         L.orc_set_goal.argtypes = [C.POINTER(Env), C.c_int]
+        L.orc_order_reset.argtypes = [C.POINTER(Env), C.c_void_p]
+        L.orc_step_order.argtypes = [C.POINTER(Env), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.orc_order_vals.argtypes = [C.POINTER(Env), C.c_void_p]
         L.orc_step_goal.argtypes = [C.POINTER(Env), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.orc_rollout_wrapped.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -201,6 +206,24 @@ class OracleEnv:
         if rc != 0:
             raise AssertionError("no goal set" if rc == -2 else "Environment must be reset before stepping")
         return r.value, bool(d.value), bool(g.value), sh.value, bool(nd.value)
+
+    # solver-ordered variant (TSP_order_env.py)
+    def order_reset(self, rank):
+        r = np.ascontiguousarray(rank, np.int32)
+        if lib().orc_order_reset(C.byref(self.e), r.ctypes.data) != 0:
+            raise ValueError("rank out of range")
+
+    def step_order(self, action):
+        a = (C.c_float * 2)(float(action[0]), float(action[1]))
+        r, d, g, sh = C.c_double(), C.c_int(), C.c_int(), C.c_double()
+        if lib().orc_step_order(C.byref(self.e), a, C.byref(r), C.byref(d), C.byref(g), C.byref(sh)) != 0:
+            raise AssertionError("Environment must be reset before stepping")
+        return r.value, bool(d.value), bool(g.value), sh.value
+
+    def order_vals(self):
+        v = np.empty(self.Z, np.float32)
+        lib().orc_order_vals(C.byref(self.e), v.ctypes.data)
+        return v
 
     def available_goals(self):
         if self.cfg.task == TASK_COLOUR:

@@ -474,6 +474,55 @@ int orc_step(orc_env *e, const float action[2], double *reward, int *done, int *
     return 0;
 }
 
+/* ---- solver-ordered variant ---- */
+static double order_dist(const orc_env *e)
+{
+    /* TSP_order_env.py:52-57 */
+    if (e->route_len == 0) return 0.0;
+    int g = e->route[0];
+    double dx = e->zone_xy[g][0] - e->xpos[0], dy = e->zone_xy[g][1] - e->xpos[1];
+    return sqrt(dx * dx + dy * dy);
+}
+
+int orc_order_reset(orc_env *e, const int32_t *rank)
+{
+    const int Z = e->cfg.num_zones;
+    for (int z = 0; z < Z; z++) {
+        if (rank[z] < 0 || rank[z] >= Z) return -1;
+        e->route[rank[z]] = z;
+    }
+    e->route_len = Z;
+    e->last_dist = order_dist(e);                      /* :112 */
+    return 0;
+}
+
+int orc_step_order(orc_env *e, const float action[2], double *reward, int *done, int *goal_met, double *shaped_reward)
+{
+    int rc = orc_step(e, action, reward, done, goal_met);
+    if (rc) return rc;
+    if (e->last_visit >= 0) {
+        /* set_mocaps: self.route.remove(h_index) (:90) */
+        int k = 0;
+        for (int i = 0; i < e->route_len; i++)
+            if (e->route[i] != e->last_visit) e->route[k++] = e->route[i];
+        e->route_len = k;
+        e->last_dist = order_dist(e);                  /* shaped_reward(): :64-66 */
+        *shaped_reward = 0.0;
+    } else {
+        double d = order_dist(e);                      /* :68-71 */
+        *shaped_reward = e->last_dist - d;
+        e->last_dist = d;
+    }
+    return 0;
+}
+
+void orc_order_vals(const orc_env *e, float *vals)
+{
+    /* obs_zones: np.power(0.5, self.route.index(i)) if i in self.route else 0 (:41-45) */
+    for (int z = 0; z < e->cfg.num_zones; z++) vals[z] = 0.f;
+    for (int i = 0; i < e->route_len; i++) vals[e->route[i]] = (float)ldexp(1.0, -i);
+}
+
 /* ---- goal-conditioned variant ---- */
 static double dist_to_goal(const orc_env *e)
 {

@@ -79,6 +79,9 @@ typedef struct orc_env {
     int32_t goal_zone;         /* -1 = None */
     int32_t last_visit;        /* zone visited by the last step, -1 = none */
     double last_dist;          /* last_dist_to_goal */
+    /* solver-ordered variant (TSP_order_env.py): route_len zones still to visit, in order */
+    int32_t route[ORC_MAX_Z];
+    int32_t route_len;
 } orc_env;
 
 /* ---- numpy-legacy RandomState restatement (exposed for pinning tests) ---- */
@@ -131,6 +134,14 @@ int64_t orc_rollout(const orc_config *cfg, int n_env, int n_steps, int policy,
 int orc_set_goal(orc_env *e, int goal);
 int orc_step_goal(orc_env *e, const float action[2], double *reward, int *done, int *goal_met,
                   double *shaped_reward, int *need_next_goal);
+
+/* ---- solver-ordered variant: TSPOrderEnv main/envs/TSP_order_env.py:13-113 (TSP task) ----
+ * orc_order_reset: after orc_reset, the route generate_route() would have produced (rank[z] = position of zone z;
+ * the solver itself, OR-tools, is outside the tree) and last_dist_to_goal (:108-113).  orc_step_order: orc_step
+ * plus info['shaped_reward'] (:63-75).  orc_order_vals: the 7th row feature 0.5^index, 0 when not in the route. */
+int orc_order_reset(orc_env *e, const int32_t *rank);
+int orc_step_order(orc_env *e, const float action[2], double *reward, int *done, int *goal_met, double *shaped_reward);
+void orc_order_vals(const orc_env *e, float *vals);
 
 /* Same, with a bank of seed_period maps per env replayed in order: episode k uses seed
  * seeds0[i] + (k % seed_period)*seed_stride (seed_period = 0: no wrap). */

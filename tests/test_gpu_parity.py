@@ -430,3 +430,64 @@ def test_goal_conditioned_variant_lockstep(zenv_mod, oracle_mod, env_id):
     with pytest.raises(Z.ZenvError):
         env.rollout(3, Z.POLICY_GREEDY)
     env.close()
+
+
+def test_solver_ordered_variant_lockstep(zenv_mod, oracle_mod):
+    """TSPOrderEnv (TSP_order_env.py:13-113) -- route per episode (the bank's aux column: the
+    built-in tour for even envs, an arbitrary caller-supplied permutation for odd ones), order feature
+    0.5^(position in the remaining route), shaped reward towards the route's first zone; auto-reset on."""
+    Z, O = zenv_mod, oracle_mod
+    n, T, nz = 120, 300, 15
+    cfg = Z.config_for_id("PointTSP-v0", num_steps=140)
+    env = Z.ZoneVecEnv(cfg, n)
+    env.enable_order()
+    rs = np.random.RandomState(3)
+    robots, zones, ranks = [], [], []
+    for i in range(n):
+        robot, zxy, _, _ = Z.sample_layout(cfg, 50 + i)
+        robots.append(robot); zones.append(zxy)
+        ranks.append(Z.route_ranks(robot, zxy) if i % 2 == 0 else rs.permutation(nz).astype(np.int32))
+    env.set_bank(np.array(robots), np.array(zones), aux=np.array(ranks), seeds=50 + np.arange(n))
+    env.schedule_sequential()
+    env.reset()
+    refs = [O.OracleEnv(oracle_config_from(O, cfg)) for _ in range(n)]
+    for i, e in enumerate(refs):
+        e.reset(50 + i)
+        assert np.allclose(e.layout[1], zones[i], atol=0, rtol=0)
+        e.order_reset(ranks[i])
+    sh, val = env.order_info()
+    assert np.array_equal(val, np.stack([e.order_vals() for e in refs])) and not sh.any()
+    # the built-in tour visits every zone once and is never longer than the plain nearest-neighbour tour
+    r0 = ranks[0]
+    assert sorted(r0) == list(range(nz))
+    n_visits = n_resets = 0
+    for t in range(T):
+        o, zo = env.observations()
+        # steer to the first zone of the remaining route (order feature == 1), with noise
+        tgt_idx = np.argmax(val, axis=1)
+        d = zo[np.arange(n), tgt_idx, :2] * 3.0 - o[:, 1:3] * 3.0
+        ang = np.arctan2(d[:, 1], d[:, 0]) - np.arctan2(o[:, 4], o[:, 3])
+        ang = (ang + np.pi) % (2 * np.pi) - np.pi
+        a = np.stack([np.where(np.abs(ang) < 0.6, 1.0, 0.0), np.clip(2 * ang, -1, 1)], 1).astype(np.float32)
+        a += rs.normal(0, 0.05, a.shape).astype(np.float32)
+        env.step(a, auto_reset=True)
+        _, _, r, dn, _ = env.results()
+        sh, val = env.order_info()
+        for i, e in enumerate(refs):
+            r_ref, d_ref, _, sh_ref = e.step_order(a[i])
+            assert (r[i], dn[i]) == (np.float32(r_ref), d_ref) and sh[i] == sh_ref, (t, i, sh[i], sh_ref)
+            n_visits += r_ref >= 1.0
+            if d_ref:
+                e.reset(50 + i)
+                e.order_reset(ranks[i])
+                n_resets += 1
+        assert np.array_equal(val, np.stack([e.order_vals() for e in refs])), t
+    assert n_visits > n and n_resets > n
+    with pytest.raises(Z.ZenvError):
+        env.enable_goals()                                    # one variant per handle
+    env.close()
+    env = Z.ZoneVecEnv(cfg, 4)
+    env.build_bank(1, 4)
+    with pytest.raises(Z.ZenvError):
+        env.enable_order()                                    # routes ride in the bank: enable first
+    env.close()

@@ -452,3 +452,47 @@ def test_actor_network_restatement_is_self_consistent():
     after = (h2 @ td["zone_w3"].T + td["zone_b3"]).sum(1) / 15            # env_model.py:78
     before = (h2.sum(1) / 15) @ td["zone_w3"].T + td["zone_b3"]            # mlp_policy.hip
     assert (after - before).abs().max() < 1e-12
+
+
+def test_solver_ordered_semantics_and_route_heuristic(oracle_mod, zenv_mod):
+    """TSPOrderEnv truth table (TSP_order_env.py:37-75, written from the source) on the oracle, and the host
+    route heuristic of the product (no GPU needed): a permutation, never longer than nearest neighbour."""
+    O, Z = oracle_mod, zenv_mod
+    cfg = O.default_config(O.TASK_TSP, 5, num_steps=400)
+    e = O.OracleEnv(cfg)
+    e.reset(1000003)
+    robot, zones = e.layout
+    rank = np.array([2, 0, 4, 1, 3], np.int32)                # route = [1, 3, 0, 4, 2]
+    e.order_reset(rank)
+    assert list(e.order_vals()) == [0.25, 1.0, 0.0625, 0.5, 0.125]            # :41-45: 0.5 ** route.index(i)
+    assert e.e.last_dist == math.hypot(zones[1][0] - robot[0], zones[1][1] - robot[1])   # :112
+    total, visits = 0.0, []
+    for t in range(400):
+        o, zo = e.obs()
+        tgt = int(np.argmax(e.order_vals()))
+        g = zo[tgt, :2] * 3.0 - o[1:3] * 3.0
+        ang = (math.atan2(g[1], g[0]) - math.atan2(o[4], o[3]) + math.pi) % (2 * math.pi) - math.pi
+        r, d, gm, sh = e.step_order([1.0 if abs(ang) < 0.6 else 0.0, max(-1.0, min(1.0, 2 * ang))])
+        if r >= 1.0:
+            visits.append(e.e.last_visit)
+            assert sh == 0.0                                   # :64-66: re-based on the new first zone, reward 0
+            vals = e.order_vals()
+            assert vals[e.e.last_visit] == 0.0 and (e.e.route_len == 0 or vals.max() == 1.0)
+        if d:
+            break
+    assert visits[:2] == [1, 3]                                # the agent follows the route
+    # the product's host heuristic
+    for seed in range(5):
+        robot, zxy, _, _ = Z.sample_layout(Z.default_config(0, 15), 100 + seed)
+        rk = Z.route_ranks(robot, zxy)
+        assert sorted(rk) == list(range(15))
+        order = np.argsort(rk)
+
+        def tour_len(order):
+            pts = np.vstack([robot[:2], zxy[order], robot[:2]])
+            return np.sqrt(((pts[1:] - pts[:-1]) ** 2).sum(1)).sum()
+        nn, cur, left = [], robot[:2], list(range(15))
+        while left:
+            j = min(left, key=lambda z: np.hypot(*(zxy[z] - cur)))
+            nn.append(j); left.remove(j); cur = zxy[j]
+        assert tour_len(order) <= tour_len(np.array(nn)) + 1e-9
