@@ -1,0 +1,33 @@
+"""Long parity soak (not a test): persistent rollouts of many envs over many steps and episodes against the
+oracle's batch driver, all three tasks, both scripted policies, wrapping map bank."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import combinatorial_rl_tasks_amd as Z
+from oracle import oracle as O
+from tests.helpers import oracle_config_from
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
+depth = 6
+bad = 0
+for task, zones, keep in ((0, 25, 0.40), (1, 25, 0.40), (2, 6, 0.55), (0, 15, 0.55), (1, 15, 0.55), (0, 5, 0.55)):
+    for pol_d, pol_o in ((Z.POLICY_GREEDY, O.POLICY_GREEDY), (Z.POLICY_UNIFORM, O.POLICY_UNIFORM)):
+        cfg = Z.default_config(task, zones, zones_keepout=keep, num_steps=700)
+        env = Z.ZoneVecEnv(cfg, n)
+        env.build_bank(1, depth * n, n_threads=16)
+        env.schedule_sequential(stride=n)
+        env.reset()
+        t0 = time.time()
+        env.rollout(T, pol_d, policy_seed=77, env_index0=5)
+        ref = O.rollout(oracle_config_from(O, cfg), 1 + np.arange(n), T, pol_o, seed_stride=n, policy_seed=77,
+                        env_index0=5, n_threads=16, seed_period=depth)
+        ok = (np.array_equal(env.get(Z.F_OBS), ref["obs"]) and np.array_equal(env.get(Z.F_ZONE_OBS), ref["zone_obs"])
+              and np.array_equal(env.get(Z.F_EPISODES), ref["episodes"])
+              and np.array_equal(env.get(Z.F_LAST_RETURN), ref["last_return"])
+              and np.array_equal(env.get(Z.F_LAST_LEN), ref["last_len"]))
+        bad += not ok
+        print("task %d Z %2d policy %d: %s  (%d env-steps, %d episodes, %.1fs)" % (
+            task, zones, pol_d, "bit-identical" if ok else "MISMATCH", n * T, int(ref["episodes"].sum()), time.time() - t0),
+            flush=True)
+        env.close()
+print("soak:", "all bit-identical" if not bad else f"{bad} MISMATCHES")
