@@ -1,8 +1,8 @@
-"""Long parity soak (not a test): persistent rollouts of many envs over many steps and episodes against the
+"""Long parity soak (run by hand on the GPU box: python tests/soak_parity.py [N] [T]; not collected by pytest): persistent rollouts of many envs over many steps and episodes against the
 oracle's batch driver, all three tasks, both scripted policies, wrapping map bank."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 import combinatorial_rl_tasks_amd as Z
 from oracle import oracle as O
 from tests.helpers import oracle_config_from
