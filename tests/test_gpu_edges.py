@@ -169,3 +169,36 @@ def test_persistent_rollout_tiny_and_ragged_batches(zenv_mod, oracle_mod, n):
         assert np.array_equal(env.get(Z.F_OBS), ref["obs"]) and np.array_equal(env.get(Z.F_ZONE_OBS), ref["zone_obs"])
         assert np.array_equal(env.get(Z.F_EPISODES), ref["episodes"]) and ref["episodes"].min() >= 3
         env.close()
+
+
+def test_c_abi_demo_matches_python_path(zenv_mod, tmp_path):
+    """examples/c_abi_demo.c (plain C caller of include/zenv.h, no Python in the loop) produces the same numbers
+    as the same sequence of calls through the ctypes facade."""
+    import os
+    import subprocess
+    Z = zenv_mod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "combinatorial-rl-tasks_amd", "lib")
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"),
+                    "-o", exe, "-L", lib_dir, "-lzenv_hip", "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined"],
+                   check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout.split()
+    got = {out[i]: float(out[i + 1]) for i in range(0, len(out), 2)}
+    n = 256
+    env = Z.ZoneVecEnv(Z.config_for_id("PointTSP-v0"), n)
+    env.build_bank(1000000, n, n_threads=4)
+    env.schedule_sequential()
+    env.reset()
+    a = np.zeros((n, 2), np.float32)
+    a[:, 0] = 1.0
+    a[:, 1] = (np.arange(n) % 3 - 1) * 0.5
+    for _ in range(40):
+        env.step(a, auto_reset=True)
+    env.rollout(100, Z.POLICY_GREEDY, policy_seed=7)
+    o, zo, r, _, _ = env.results()
+    assert got["steps"] == 140
+    assert abs(got["obs_sum"] - float(o.astype(np.float64).sum())) < 1e-6
+    assert abs(got["zone_obs_sum"] - float(zo.astype(np.float64).sum())) < 1e-6
+    assert abs(got["reward_sum"] - float(r.astype(np.float64).sum())) < 1e-6
+    env.close()

@@ -177,3 +177,24 @@ def test_spaces_and_wrappers_host_logic():
     env.reset()
     g = np.random.default_rng(10000)
     assert Fake.seeds == [int(g.integers(1, 101, size=1)[0]) for _ in range(2)]
+
+
+def test_header_is_valid_c_and_cpp():
+    """include/zenv.h is the whole boundary: it must compile as C99 and as C++ on its own."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "zenv.h")
+    for cmd in (["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr]):
+        subprocess.run(cmd, check=True)
+
+
+def test_c_demo_compiles_and_links(zenv_mod, tmp_path):
+    """examples/c_abi_demo.c builds with plain gcc against the header and links against the shared library
+    (running it needs a GPU: tests/test_gpu_edges.py)."""
+    import subprocess
+    lib_dir = os.path.join(ROOT, "combinatorial-rl-tasks_amd", "lib")
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "c_abi_demo.c"), "-o", exe, "-L", lib_dir, "-lzenv_hip",
+                    "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined"], check=True)
+    assert os.path.exists(exe)
