@@ -23,6 +23,7 @@ struct DevParams {
     int32_t task, Z, F, N;
     int32_t num_steps, max_cd, frameskip, bank_size;
     int32_t sched_mode, sched_stride;
+    int32_t kernel, pad_kernel;   // ZENV_KERNEL_*
     int64_t seed_min, seed_max;
     // model constants (derived on the host once; see zenv_api.cpp:derive_constants)
     double h, gear, fmax, kv, mc;

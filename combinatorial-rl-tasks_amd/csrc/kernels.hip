@@ -1952,6 +1952,209 @@ __global__ __launch_bounds__(256) void k_order_step(DevParams p)
     }
 }
 
+// =========================================================================== K1w: wave-per-env step
+// The layout north_star describes literally (cfg.kernel = ZENV_KERNEL_WAVE_PER_ENV): one wave64 per env,
+// lane z owns zone z; the first-eligible-zone choice, the deadline check and the reset's colour packing are
+// wave ballots; the env's scalar state (joint state, counters, the 8-float obs) is wave-uniform, so every
+// lane carries the same physics and lane 0 stores it.  Same arithmetic, same results as K1 (the zone test
+// is the exact float64 one in every lane).  It is here to be measured against K1: for the
+// reference's Z <= 25 the 10 float64 substeps dominate and they run once per WAVE instead of once per
+// LANE, so the chip does 64x the physics issue for the same batch.  Scripted policies run as the
+// stand-alone K3 launch (zenv_rollout falls back to the unfused loop for this layout).
+template <int TASK>
+__global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const float *__restrict__ actions,
+                                                         int auto_reset)
+{
+    constexpr int F = TaskTraits<TASK>::F;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int env = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int N = p.N, Z = p.Z;
+    if (env >= N) return;
+    const bool zl = lane < Z;
+    const size_t zi = (size_t)lane * N + env;
+    const GlobalRowSink sink{ p.zone_obs + (size_t)env * Z * F };
+
+    if (p.done_state[env]) {
+        // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
+        if (zl) sink.put<TASK>(lane, make_float4(0.f, 0.f, -1.f, 0.f));
+        if (lane == 0) {
+            const float o[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+            store_obs8(p, env, o);
+            if (p.visit_zone) p.visit_zone[env] = -1;
+            p.reward[env] = 0.f;
+            p.done_out[env] = 1;
+            p.goal_met[env] = 0;
+        }
+        return;
+    }
+
+    EnvRegs e;
+    {
+        const double2 qa = p.qa[env], qb = p.qb[env], qc = p.qc[env], fa = p.fa[env], fb = p.fb[env];
+        e.q0 = qa.x; e.q1 = qa.y; e.q2 = qb.x;
+        e.v0 = qb.y; e.v1 = qc.x; e.v2 = qc.y;
+        e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
+    }
+    e.steps = p.steps[env];
+    e.vis = 0u; e.colpack = 0ull; e.goal_dist = 0;
+    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+        e.colpack = p.colpack[env];
+        e.goal_dist = p.goal_dist[env];
+    } else {
+        e.vis = p.vis[env];
+    }
+    double ep_ret = p.ep_return[env];
+    const float2 act = reinterpret_cast<const float2 *>(actions)[env];
+    const int k = e.steps + 1;
+    const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
+
+    // ---- set_mocaps() of the first substep on the pre-physics pose: lane z tests zone z
+    double rx, ry;
+    world_pos(e, rx, ry);
+    double2 zz = make_double2(0.0, 0.0);
+    int aux = 0;
+    if (zl) {
+        zz = p.zxy[zi];
+        if (TASK == ZENV_TASK_TIMED_TSP) aux = p.tmax[zi];
+        if (TASK == ZENV_TASK_COLOUR_MATCH) aux = p.cooldown[zi];
+    }
+    const double dx = zz.x - rx, dy = zz.y - ry;
+    const bool inside = zl && (dx * dx + dy * dy <= p.hit_d2);
+    bool elig;
+    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+        if (aux > 0) aux -= 1;                                   // colour_match_env.py:98-100
+        elig = aux == 0;
+    } else {
+        elig = !((e.vis >> lane) & 1u);
+    }
+    const unsigned long long hits = __ballot(inside && elig);
+    const int first = hits ? __ffsll((long long)hits) - 1 : -1;  // lowest index wins, one per step
+    if (first >= 0) {
+        if (TASK == ZENV_TASK_COLOUR_MATCH) {
+            int col = (int)((e.colpack >> (2 * first)) & 3ull);
+            col = (col == 2) ? 0 : col + 1;                      // Blue->Green->Red->Blue
+            e.colpack = (e.colpack & ~(3ull << (2 * first))) | ((uint64_t)col << (2 * first));
+            if (lane == first) aux = p.max_cd;
+        } else {
+            e.vis |= 1u << first;
+        }
+    }
+    if (TASK == ZENV_TASK_COLOUR_MATCH && zl) p.cooldown[zi] = (uint8_t)aux;
+    const bool visited = (e.vis >> lane) & 1u;
+    bool timed_out = false;
+    if (TASK == ZENV_TASK_TIMED_TSP) timed_out = __ballot(zl && !visited && (aux - k) <= 0) != 0ull;   // TTSP_env.py:67
+
+    // ---- reward / goal / termination (Engine.step order)
+    double r = 0.0;
+    bool goal;
+    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+        if (first >= 0) {
+            const int nd = hamming_to_goal(e.colpack, Z);
+            r = (double)(e.goal_dist - nd);
+            e.goal_dist = nd;
+        }
+        goal = e.goal_dist == 0;
+    } else {
+        r = first >= 0 ? 1.0 : 0.0;
+        goal = (e.vis & full) == full;
+    }
+    bool done = false;
+    if (goal) {
+        r += (double)(p.num_steps - e.steps) * p.tsr;
+        done = true;
+    }
+    e.steps = k;
+    if (k >= p.num_steps) done = true;
+    if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
+    ep_ret = ep_ret + r;
+
+    // ---- Engine.step: ctrl = clip(action, ctrlrange); frameskip x mj_step (wave-uniform)
+    const double c0 = det_clamp((double)act.x, -1.0, 1.0);
+    const double c1 = det_clamp((double)act.y, -1.0, 1.0);
+    for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
+
+    if (lane == 0) {
+        p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
+        if (p.visit_zone) p.visit_zone[env] = first;
+        p.reward[env] = (float)r;
+        p.done_out[env] = done ? 1 : 0;
+        p.goal_met[env] = goal ? 1 : 0;
+        if (done) {
+            p.last_return[env] = ep_ret;
+            p.last_len[env] = k;
+            p.episodes[env] += 1;
+            if (!auto_reset) p.done_state[env] = 1;
+        }
+    }
+
+    if (done && auto_reset) {
+        // ---- auto-reset (penv.py:8-11): lane z fetches zone z of the next layout
+        if (lane == 0 && p.term_xy) {
+            double tx, ty;
+            world_pos(e, tx, ty);
+            p.term_xy[env] = make_double2(tx, ty);
+        }
+        int slot = 0;
+        if (lane == 0) slot = next_bank_slot(p, env);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        const double *br = p.bank_robot + 4 * (size_t)slot;
+        int code = 0;
+        float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (zl) {
+            const size_t bi = (size_t)slot * Z + lane;
+            zz = reinterpret_cast<const double2 *>(p.bank_zone)[bi];
+            p.zxy[zi] = zz;
+            int a = 0;
+            if (TASK == ZENV_TASK_TIMED_TSP) {
+                a = p.bank_aux[bi];
+                p.tmax[zi] = a;
+            } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                code = p.bank_aux[bi];
+                p.cooldown[zi] = 0;
+            }
+            en = make_entry<TASK>(p, zz.x, zz.y, code, a, 0);
+            sink.put<TASK>(lane, en);
+        }
+        const float nx = __shfl_down(en.x, 1), ny = __shfl_down(en.y, 1);
+        if (zl && !(lane & 1))
+            p.zpf[(size_t)(lane >> 1) * N + env] =
+                make_float4(en.x, en.y, lane + 1 < Z ? nx : 0.f, lane + 1 < Z ? ny : 0.f);
+        EnvRegs fresh;
+        fresh.x0 = br[0]; fresh.y0 = br[1]; fresh.bq0 = br[2]; fresh.bq3 = br[3];
+        fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
+        fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
+        fresh.vis = 0u;
+        fresh.colpack = 0ull;
+        fresh.goal_dist = 0;
+        if (TASK == ZENV_TASK_COLOUR_MATCH) {
+            const unsigned long long m0 = __ballot(zl && (code & 1)), m1 = __ballot(zl && (code & 2));
+            fresh.colpack = spread_even_bits((uint32_t)m0) | (spread_even_bits((uint32_t)m1) << 1);
+            fresh.goal_dist = hamming_to_goal(fresh.colpack, Z);
+        }
+        fresh.steps = 0;
+        e = fresh;
+        ep_ret = 0.0;
+        if (lane == 0) {
+            p.seed[env] = p.bank_seed[slot];
+            store_frame(p, env, e);
+        }
+    } else if (zl) {
+        // this step's row of zone z
+        int code = visited ? 1 : 0, a = aux;
+        if (TASK == ZENV_TASK_COLOUR_MATCH) code = (int)((e.colpack >> (2 * lane)) & 3ull);
+        sink.put<TASK>(lane, make_entry<TASK>(p, zz.x, zz.y, code, a, k));
+    }
+
+    if (lane == 0) {
+        float o[8];
+        emit_obs8(p, e, o);
+        store_obs8(p, env, o);
+        store_dyn(p, env, e);
+        store_counters(p, env, TASK, e);
+        p.ep_return[env] = ep_ret;
+    }
+}
+
 // =========================================================================== K2: reset
 template <int TASK>
 __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t *__restrict__ mask)
@@ -2011,6 +2214,22 @@ static void launch_step_task(const DevParams &p, const float *actions, int auto_
 hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset, const StepPolicy &pol,
                        hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
+    if (p.kernel == ZENV_KERNEL_WAVE_PER_ENV) {
+        // no fused policy in this layout: the caller runs K3 (zenv_api.cpp keeps pol.policy < 0 here)
+        const dim3 grid((p.N + 3) / 4), block(4 * kWave);
+        switch (p.task) {
+        case ZENV_TASK_TSP:
+            hipExtLaunchKernelGGL((k_step_wave<ZENV_TASK_TSP>), grid, block, 0, s, ev_start, ev_stop, 0, p, actions, auto_reset);
+            break;
+        case ZENV_TASK_TIMED_TSP:
+            hipExtLaunchKernelGGL((k_step_wave<ZENV_TASK_TIMED_TSP>), grid, block, 0, s, ev_start, ev_stop, 0, p, actions, auto_reset);
+            break;
+        default:
+            hipExtLaunchKernelGGL((k_step_wave<ZENV_TASK_COLOUR_MATCH>), grid, block, 0, s, ev_start, ev_stop, 0, p, actions, auto_reset);
+            break;
+        }
+        return hipGetLastError();
+    }
     switch (p.task) {
     case ZENV_TASK_TSP: launch_step_task<ZENV_TASK_TSP>(p, actions, auto_reset, pol, s, ev_start, ev_stop); break;
     case ZENV_TASK_TIMED_TSP: launch_step_task<ZENV_TASK_TIMED_TSP>(p, actions, auto_reset, pol, s, ev_start, ev_stop); break;
@@ -2030,7 +2249,10 @@ static inline size_t rollout_lds_bytes(const DevParams &p)
            + 4 * sizeof(int);                                                      // counters
 }
 
-bool rollout_kernel_available(const DevParams &p) { return p.Z == 5 || p.Z == 6 || p.Z == 15 || p.Z == 25; }
+bool rollout_kernel_available(const DevParams &p)
+{
+    return p.kernel == ZENV_KERNEL_LANE_PER_ENV && (p.Z == 5 || p.Z == 6 || p.Z == 15 || p.Z == 25);
+}
 
 template <int TASK>
 static void launch_rollout_task(const DevParams &p, int n_steps, int auto_reset, const StepPolicy &pol, hipStream_t s,

@@ -92,14 +92,16 @@ int validate_config(const zenv_config &c)
     if (c.max_cd < 1 || c.max_cd > 255) return fail(ZENV_E_ARG, "max_cd %d outside [1,255]", c.max_cd);
     if (c.frameskip < 1 || c.frameskip > 1000) return fail(ZENV_E_ARG, "bad frameskip %d", c.frameskip);
     if (!(c.mass > 0) || !(c.inertia_zz > 0) || !(c.timestep > 0)) return fail(ZENV_E_ARG, "bad model constants");
-    if (c.kernel != ZENV_KERNEL_LANE_PER_ENV)
-        return fail(ZENV_E_ARG, "kernel layout %d not available in this build", c.kernel);
+    if (c.kernel != ZENV_KERNEL_LANE_PER_ENV && c.kernel != ZENV_KERNEL_WAVE_PER_ENV)
+        return fail(ZENV_E_ARG, "unknown kernel layout %d", c.kernel);
     return ZENV_OK;
 }
 
 void derive_constants(const zenv_config &c, DevParams &p)
 {
     p.task = c.task;
+    p.kernel = c.kernel;
+    p.pad_kernel = 0;
     p.Z = c.num_zones;
     p.F = zenv_zone_feat(&c);
     p.num_steps = c.num_steps;
@@ -881,7 +883,9 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     int rc = use_device(h);
     if (rc) return rc;
     // the actor network is its own launch sequence: policy, then step, every step
-    const bool fused = (flags & ZENV_ROLLOUT_UNFUSED) == 0 && !policy_is_mlp(policy);
+    // ... and so is every policy of the wave-per-env layout (K1w has no fused policy)
+    const bool fused = (flags & ZENV_ROLLOUT_UNFUSED) == 0 && !policy_is_mlp(policy) &&
+                       h->p.kernel == ZENV_KERNEL_LANE_PER_ENV;
     const bool persistent = fused && (flags & ZENV_ROLLOUT_PER_STEP) == 0 && rollout_kernel_available(h->p);
     const bool per_kernel = ms_step_kernel_avg != nullptr && steps > 0;
     if (event_stride < 1) event_stride = 1;

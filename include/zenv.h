@@ -91,7 +91,8 @@ enum {
 /* kernel layouts */
 enum {
     ZENV_KERNEL_LANE_PER_ENV = 0,  /* SoA state, one lane per env, LDS-transposed obs tile */
-    ZENV_KERNEL_WAVE_PER_ENV = 1   /* one wave64 per env, lane z owns zone z (north-star layout) */
+    ZENV_KERNEL_WAVE_PER_ENV = 1   /* one wave64 per env, lane z owns zone z (north-star layout): same results,
+                                    * ~10x the step time; kept selectable for comparison */
 };
 
 /* Replaces the config dicts of envs/__init__.py:7-50 merged into Engine.DEFAULT

@@ -83,7 +83,7 @@ def test_argument_validation(zenv_mod):
         Z.ZoneVecEnv(Z.default_config(0, 15), 0)
     assert ei.value.code == E.E_ARG
     for bad in (dict(num_zones=33), dict(num_zones=0), dict(num_steps=0), dict(max_cd=256), dict(frameskip=0),
-                dict(kernel=E.KERNEL_WAVE_PER_ENV), dict(task=3)):
+                dict(kernel=2), dict(task=3)):
         cfg = Z.default_config(0, 15)
         for k, v in bad.items():
             setattr(cfg, k, v)
