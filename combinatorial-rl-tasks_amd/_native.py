@@ -17,6 +17,7 @@ OBS_DIM = 8
 TASK_TSP, TASK_TIMED_TSP, TASK_COLOUR_MATCH = 0, 1, 2
 POLICY_UNIFORM, POLICY_GREEDY, POLICY_MLP_MEAN, POLICY_MLP_SAMPLE = 0, 1, 2, 3
 KERNEL_LANE_PER_ENV, KERNEL_WAVE_PER_ENV = 0, 1
+HIP_STREAM_LEGACY = 1       # hipStreamLegacy: the null stream as an explicit handle (hip_runtime_api.h)
 ROLLOUT_UNFUSED = 1
 ROLLOUT_PER_STEP = 2
 ROLLOUT_CHUNK = 256

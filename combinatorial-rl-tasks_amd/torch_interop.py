@@ -54,9 +54,28 @@ class TorchZoneEnv:
         assert t.data_ptr() == self.env.device_ptr(field), "torch copied instead of aliasing"
         return t
 
+    def _alias_raw(self, field, shape):
+        t = self._torch.as_tensor(_DeviceView(self.env.device_ptr(field), shape, np.float32), device=self.device)
+        assert t.data_ptr() == self.env.device_ptr(field), "torch copied instead of aliasing"
+        return t
+
     def reset(self, mask=None):
         self.env.reset(mask)
         return {"obs": self.obs, "zone_obs": self.zone_obs}
+
+    def load_state_dict(self, state_dict):
+        """Put an ACModel state_dict (main/src/flat_model.py:24-52 names; torch tensors on any device) into the
+        device actor-critic that ``collect`` and the ``POLICY_MLP_*`` action sources run."""
+        from .vec_env import mlp_tensors_from_state_dict
+        self.env.load_mlp(mlp_tensors_from_state_dict(state_dict))
+
+    def collect(self, frames_per_proc, policy_seed=1, env_index0=0, discount=0.99, gae_lambda=0.95):
+        """collect_experiences (torch_ac/algos/base.py:131-227) on the device; returns exps.* as float32 CUDA
+        tensors [N, T, ...] ALIASING the handle's experience buffers (overwritten by the next collect).  Enqueued
+        on the shared stream like everything else: no synchronisation, no host copy."""
+        self.env.collect_on_device(frames_per_proc, policy_seed, env_index0, discount, gae_lambda)
+        return {name: self._alias_raw(field, shape)
+                for name, (field, shape) in self.env.experience_layout(frames_per_proc).items()}
 
     def step(self, actions, auto_reset=True):
         """actions: float32 CUDA tensor (N, 2) on the env's device (contiguous).  Asynchronous: the

@@ -290,28 +290,42 @@ class ZoneVecEnv:
         actor-critic.  Returns a dict of env-major arrays [N, T, ...] -- reshape(N*T, ...) gives exps.* of the
         reference (:211-227): obs, zone_obs, action, log_prob, value, reward, mask, advantage, returnn."""
         T = int(frames_per_proc)
-        check(lib().zenv_collect(self._h, T, int(policy_seed), int(env_index0), float(discount), float(gae_lambda)))
-        N, Z, F = self.num_envs, self.num_zones, self.zone_feat
-        shapes = {"obs": (nat.F_EXP_OBS, (N, T, 8)), "zone_obs": (nat.F_EXP_ZONE_OBS, (N, T, Z, F)),
-                  "action": (nat.F_EXP_ACTION, (N, T, 2)), "log_prob": (nat.F_EXP_LOG_PROB, (N, T, 2)),
-                  "value": (nat.F_EXP_VALUE, (N, T)), "reward": (nat.F_EXP_REWARD, (N, T)),
-                  "mask": (nat.F_EXP_MASK, (N, T)), "advantage": (nat.F_EXP_ADVANTAGE, (N, T)),
-                  "returnn": (nat.F_EXP_RETURN, (N, T))}
+        self.collect_on_device(T, policy_seed, env_index0, discount, gae_lambda)
         out = {}
-        for name, (field, shape) in shapes.items():
+        for name, (field, shape) in self.experience_layout(T).items():
             a = np.empty(shape, np.float32)
             assert a.nbytes == lib().zenv_field_bytes(self._h, field)
             check(lib().zenv_get(self._h, field, a.ctypes.data, 0))
             out[name] = a
         return out
 
+    def collect_on_device(self, frames_per_proc, policy_seed=1, env_index0=0, discount=0.99, gae_lambda=0.95):
+        """The same rollout, results left in the handle's device buffers (``experience_layout`` names them)."""
+        check(lib().zenv_collect(self._h, int(frames_per_proc), int(policy_seed), int(env_index0),
+                                 float(discount), float(gae_lambda)))
+
+    def experience_layout(self, frames_per_proc):
+        """name -> (field id, shape) of the float32 buffers one collect of T frames per env fills."""
+        N, Z, F, T = self.num_envs, self.num_zones, self.zone_feat, int(frames_per_proc)
+        return {"obs": (nat.F_EXP_OBS, (N, T, 8)), "zone_obs": (nat.F_EXP_ZONE_OBS, (N, T, Z, F)),
+                "action": (nat.F_EXP_ACTION, (N, T, 2)), "log_prob": (nat.F_EXP_LOG_PROB, (N, T, 2)),
+                "value": (nat.F_EXP_VALUE, (N, T)), "reward": (nat.F_EXP_REWARD, (N, T)),
+                "mask": (nat.F_EXP_MASK, (N, T)), "advantage": (nat.F_EXP_ADVANTAGE, (N, T)),
+                "returnn": (nat.F_EXP_RETURN, (N, T))}
+
     def sync(self):
         check(lib().zenv_sync(self._h))
 
     def set_stream(self, hip_stream=None):
         """Enqueue all further work on the caller's HIP stream (an integer hipStream_t, e.g.
-        ``torch.cuda.current_stream().cuda_stream``); None = the handle's own stream again."""
-        check(lib().zenv_set_stream(self._h, None if not hip_stream else C.c_void_p(int(hip_stream))))
+        ``torch.cuda.current_stream().cuda_stream``); None = the handle's own stream again.  0 is the null
+        stream (torch's default stream): it goes down as hipStreamLegacy, since NULL means "own stream"
+        in the C ABI."""
+        if hip_stream is None:
+            ptr = None
+        else:
+            ptr = C.c_void_p(int(hip_stream) if int(hip_stream) else nat.HIP_STREAM_LEGACY)
+        check(lib().zenv_set_stream(self._h, ptr))
 
     @property
     def step_count(self):

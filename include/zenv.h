@@ -266,7 +266,8 @@ void *zenv_host_alloc(int64_t bytes);
 int zenv_host_free(void *ptr);
 int zenv_get_many(zenv_t *h, int n_fields, const int *fields, void *const *dst);
 /* Enqueue everything from now on onto the caller's HIP stream (hipStream_t passed as void*; NULL =
- * back to the handle's own stream).  The handle first drains the stream it was using.  This is how
+ * back to the handle's own stream; the null stream is named by hipStreamLegacy).  The handle first
+ * drains the stream it was using.  This is how
  * a device-resident policy (base.py:139-145 without the .cpu().numpy() round trip) shares one
  * stream with the env: step, read the obs buffers of zenv_device_ptr(), compute actions, step. */
 int zenv_set_stream(zenv_t *h, void *hip_stream);

@@ -188,3 +188,67 @@ def test_collect_experiences(zenv_mod, oracle_mod, env_id, goals):
         assert np.abs(adv - x["advantage"]).max() < 1e-5 and np.abs(x["value"] + adv - x["returnn"]).max() < 1e-5
         assert (x["mask"] == 0).any() and (x["mask"] == 1).any()
     env.close()
+
+
+def _load_ppo_example():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "ppo_torch.py")
+    spec = importlib.util.spec_from_file_location("ppo_torch_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_device_experiences_feed_a_torch_update(zenv_mod):
+    """TorchZoneEnv.collect hands exps.* over as CUDA tensors aliasing the handle's buffers; a torch ACModel with
+    the reference's parameter names (examples/ppo_torch.py) agrees with what the device actor-critic recorded
+    (float32 torch vs bf16 MFMA: the module-level tolerances), and PPO updates on them run and move the policy."""
+    import torch
+    Z = zenv_mod
+    from combinatorial_rl_tasks_amd.torch_interop import TorchZoneEnv
+    ex = _load_ppo_example()
+    torch.manual_seed(0)
+    n, T = 384, 12
+    env = Z.ZoneVecEnv("PointTSP-v0", n)
+    env.build_bank(3, 4 * n)
+    env.schedule_sequential(stride=n)
+    tenv = TorchZoneEnv(env)
+    tenv.reset()
+    model = ex.ActorCritic(env.zone_feat).cuda()
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.bias.normal_(0, 0.1)
+    tenv.load_state_dict(model.state_dict())
+    exps = tenv.collect(T, policy_seed=5)
+    assert all(v.is_cuda and v.dtype == torch.float32 for v in exps.values())
+    assert exps["obs"].data_ptr() == env.device_ptr(Z._native.F_EXP_OBS) and tuple(exps["zone_obs"].shape) == (n, T, 15, 6)
+    host = {k: v.cpu().numpy() for k, v in exps.items()}
+    with torch.no_grad():
+        dist, value = model(exps["obs"].reshape(n * T, 8), exps["zone_obs"].reshape(n * T, 15, 6))
+        lp = dist.log_prob(exps["action"].reshape(n * T, 2)).reshape(n, T, 2)
+    assert (value.reshape(n, T) - exps["value"]).abs().max().item() < 4e-2
+    assert (lp - exps["log_prob"]).abs().max().item() < 0.5 and (lp - exps["log_prob"]).abs().mean().item() < 0.05
+    ret = host["value"] + host["advantage"]
+    assert np.abs(ret - host["returnn"]).max() < 1e-5
+    # three updates through the example's loop: finite losses, parameters and the device policy move
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.Adam(model.parameters(), 3e-4)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for u in range(3):
+        tenv.load_state_dict(model.state_dict())
+        exps = tenv.collect(T, policy_seed=6 + u)
+        st = ex.ppo_update(model, opt, exps, 2, 1024, 0.2, 0.003, 0.5, 0.5, gen)
+        assert all(np.isfinite(v) for v in st.values()), st
+    assert any(not torch.equal(before[k], v) for k, v in model.state_dict().items())
+    env.close()
+
+
+def test_ppo_example_runs(zenv_mod):
+    ex = _load_ppo_example()
+    logs = []
+    _, hist = ex.train("ColourMatch-v0", procs=256, frames_per_proc=8, updates=2, epochs=1, batch_size=1024,
+                       log=logs.append)
+    assert len(hist) == 2 and all(np.isfinite(h["policy_loss"]) and np.isfinite(h["value_loss"]) for h in hist)
+    assert hist[-1]["frames"] == 2 * 256 * 8 and hist[0]["collect_fps"] > 0
