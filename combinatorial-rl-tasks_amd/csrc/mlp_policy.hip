@@ -12,7 +12,8 @@
 // operand of  Y = A X  or the A operand of  Z = X^T B  -- when the other operand's k order follows the
 // accumulator order (cdna_hip_programming.md section 3, "an accumulator tile as the next MFMA's
 // operand").  So activations never leave registers:
-//   kernel 1 (k_mlp_zone), a wave pair per 64 envs, batch = the envs' 64 Z zone rows, 32 per tile:
+//   kernel 1 (k_mlp_zone1; k_mlp_zone is its predecessor), a wave per 64 envs, batch = the envs' 64 Z zone rows,
+//   32 per tile:
 //     X1   = relu(W1 X0)            features in registers, zone row on the lane     (6 MFMA / tile)
 //     H2^T = relu(X1^T W2^T)        zone row in registers, feature on the lane      (72 MFMA / tile)
 //     mean over the zone rows of an env = one more product P += S relu(H2^T) with a 0/1 selection
@@ -39,6 +40,25 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 constexpr int kWave = 64;
 constexpr int NT = kMlpNT, KS = kMlpKS, HP = kMlpHP;
+
+// Diagnostic builds only (scripts/probes/k4_stamps.hip): s_memtime stamps of one wave of block 0, per row tile.
+#ifdef MLP_STAMP
+__device__ unsigned long long *g_k4_stamps;
+#define KSTAMP(slot)                                                                                       \
+    do {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (blockIdx.x == 0 && wave == (MLP_STAMP) && stamp_it < 64) {                                     \
+            unsigned long long t_;                                                                         \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+            if (lane == 0) g_k4_stamps[stamp_it * 16 + (slot)] = t_;                                       \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    } while (0)
+#define ZT_STAMP_ARGS , wave, stamp_it++
+#else
+#define KSTAMP(slot) do { } while (0)
+#define ZT_STAMP_ARGS
+#endif
 
 __device__ __forceinline__ bf16x8 as_frag(const uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ f32x16 mfma(const bf16x8 a, const bf16x8 b, const f32x16 c)
@@ -97,38 +117,45 @@ __device__ __forceinline__ bf16x8 frag_from_floats(const float4 lo, const float4
 }
 
 // ------------------------------------------------------------------------------------------ kernel 1
-// raw inputs of one 32-row tile as a lane holds them: lane half 0 the env's obs, half 1 the zone row
-template <int F>
+// raw inputs of one 32-row tile as a lane holds them: lane half 0 the env's obs, half 1 the zone row.
+// The SAME three load instructions in both lane halves (no divergent branches: with one branch per half the
+// compiler's wait for the loads landed right behind their issue -- a full memory round trip exposed per tile),
+// never past the end of a row; the values are only looked at by row_frag(), one tile later.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 struct RawRow {
-    float v[8];
+    f32x4u a;       // floats 0-3
+    f32x2u b, c;    // floats 4-5; obs: floats 6-7, zone row: its last two floats
     bool valid;
 };
 template <int ZT, int F>
-__device__ __forceinline__ RawRow<F> load_row(const float *__restrict__ obs, const float *__restrict__ zrows, int env0,
-                                               int Z, int row, int n_rows, int h)
+__device__ __forceinline__ RawRow load_row(const float *__restrict__ obs, const float *__restrict__ zrows, int env0,
+                                           int Z, int row, int n_rows, int h)
 {
-    RawRow<F> x;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x.v[j] = 0.f;
+    RawRow x;
     x.valid = row < n_rows;
+    const int rr = x.valid ? row : 0;   // any readable row; row_frag() zeroes it
+    const float *p = h ? zrows + (size_t)rr * F : obs + (size_t)(env0 + rr / Z) * 8;
+    x.a = *reinterpret_cast<const f32x4u *>(p);
+    x.b = *reinterpret_cast<const f32x2u *>(p + 4);
+    x.c = *reinterpret_cast<const f32x2u *>(p + (h ? F - 2 : 6));
 #if defined(MLP_EXP) && (MLP_EXP & 16)     // diagnostic: no global loads for the rows
-    if (x.valid) x.v[h] = 1.0f;
-    return x;
+    x.a = f32x4u{ 1.f, 0.f, 0.f, 0.f }; x.b = f32x2u{ 0.f, 0.f }; x.c = x.b;
 #endif
-    if (x.valid) {
-        if (h == 0) {
-            const float4 *o = reinterpret_cast<const float4 *>(obs + (size_t)(env0 + row / Z) * 8);
-            const float4 a = o[0], b = o[1];
-            x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
-            x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
-        } else {
-            const float *zr = zrows + (size_t)row * F;
-#pragma unroll
-            for (int f = 0; f < F; ++f) x.v[f] = zr[f];
-            x.v[7] = 1.0f;   // k = 15: the bias slot
-        }
-    }
     return x;
+}
+// the tile's B operand of layer 1: k = 0..7 obs (half 0) / k = 8..14 zone row, k = 15 the bias slot (half 1)
+template <int F>
+__device__ __forceinline__ bf16x8 row_frag(const RawRow &x, int h)
+{
+    float v6 = x.c.x, v7 = x.c.y;
+    if (h) {
+        v6 = F == 7 ? x.c.y : 0.f;
+        v7 = 1.0f;
+    }
+    const bool ok = x.valid;
+    return frag_from_8(ok ? x.a.x : 0.f, ok ? x.a.y : 0.f, ok ? x.a.z : 0.f, ok ? x.a.w : 0.f, ok ? x.b.x : 0.f,
+                       ok ? x.b.y : 0.f, ok ? v6 : 0.f, ok ? v7 : 0.f);
 }
 
 // 8 waves per workgroup, two per SIMD: wave w works on the 64-env group (w & 3) of the workgroup and on
@@ -176,18 +203,24 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
     // the same moments, changed nothing: 165.6 us per step at any offset; neither did a static priority for the
     // younger half of the workgroup.)
 
+#ifdef MLP_STAMP
+    int stamp_it = 0;
+#endif
     // two groups of 32 envs: a group's zone rows all pool into ONE 32-env accumulator tile set
     for (int e_base = 0; e_base < n_env; e_base += 32) {
         const int g_lo = e_base * Z, g_hi = min(e_base + 32, n_env) * Z;     // the group's rows
         f32x16 pool[NH];
 #pragma unroll
         for (int n = 0; n < NH; ++n) pool[n] = zero16();
-        RawRow<F> nxt = load_row<ZT, F>(obs, zrows, env0, Z, g_lo + r, n_rows, h);
+        RawRow nxt = load_row<ZT, F>(obs, zrows, env0, Z, g_lo + r, n_rows, h);
 
         for (int b = g_lo; b < g_hi; b += 32) {
-            const bf16x8 x0 = frag_from_8(nxt.v[0], nxt.v[1], nxt.v[2], nxt.v[3], nxt.v[4], nxt.v[5], nxt.v[6], nxt.v[7]);
+            KSTAMP(0);
+            const bf16x8 x0 = row_frag<F>(nxt, h);
             // the next tile's rows are fetched while this one is in the matrix pipe (fetching three tiles ahead
-            // was slower)
+            // was slower); issued strictly behind the use of the previous ones, so that the wait in front of
+            // row_frag() never covers a load younger than a whole tile
+            __builtin_amdgcn_sched_barrier(0);
             nxt = load_row<ZT, F>(obs, zrows, env0, Z, b + 32 + r, min(n_rows, g_hi), h);
             // layer 2's first fragments: issued here so that they land during layer 1
             bf16x8 wf[NH + 1][KS];          // statically indexed: two tiles' worth live at a time
@@ -205,6 +238,7 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
                 acc_to_frags(acc1, true, xa[2 * m], xa[2 * m + 1]);
             }
 #endif
+            KSTAMP(1);
             // ---- mean over an env's rows = one more product: P += S relu(H2^T), S[env slot][row] = 1 when
             // the row belongs to env e_base + slot.  Lane (slot r, half h) element j of k-step s is tile row
             // 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the accumulator order of H2^T.
@@ -223,6 +257,7 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
             // Software-pipelined over the wave's output tiles: region n issues the LDS reads of tile n+1's
             // fragments, then tile n's 12 MFMAs, then tile n-1's conversion + pooling MFMAs.
             f32x16 acc2[NH];
+            KSTAMP(2);
 #pragma unroll
             for (int n = 0; n <= NH; ++n) {
                 if (n < NH) {
@@ -252,7 +287,11 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
                 }
                 // region boundary: keeps the scheduler from hoisting every later tile's fragment reads up here
                 __builtin_amdgcn_sched_barrier(0);
+                KSTAMP(3 + n);
             }
+#ifdef MLP_STAMP
+            ++stamp_it;
+#endif
         }
         // ---- the group's means: accumulator register i of lane half h is env slot (i&3) + 8 (i>>2) + 4 h
 #pragma unroll
@@ -266,6 +305,237 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
                 const float vn = __shfl_down(v, 1);
                 if (e < n_env && !(r & 1))
                     *reinterpret_cast<uint32_t *>(pooled + (size_t)(env0 + e) * HP + 32 * (n0 + n) + r) = pk_bf16(v, vn);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ kernel 1, v2
+// k_mlp_zone1: ONE wave per SIMD (4 per workgroup, 512 registers each), software-pipelined by hand so that
+// everything a matrix instruction does not depend on sits in its shadow.  What the stamps of the two-wave
+// kernel showed (scripts/probes/k4_stamps.hip): a SIMD issues ONE vector instruction stream -- a VALU
+// instruction costs 4 issue cycles, an MFMA 8 of its 32 -- and the two waves' streams simply added up (the
+// layer-1 chain MFMA -> wait -> 16 conversions -> next MFMA ran 1000 cycles per tile, the selection matrix
+// 430), so the matrix pipe idled half of the time.  Here:
+//   * tiles are ZONE-major: tile t = zone t of the group's 32 envs, so row r of every tile belongs to env
+//     slot r -- the selection matrix of the pooling product is the identity, a per-lane constant, and the
+//     obs half of the layer-1 operand is loaded once per group;
+//   * layer 1 of tile t+1 (6 MFMAs + 96 conversions) is issued inside the layer-2 chains of tile t, and
+//     the conversion + pooling of output tile n-1 inside the chain of output tile n (also across tiles);
+//   * the pooled accumulators (96 registers) live in AGPRs (inline-asm MFMA, "+a"), the W2 fragments are
+//     read from LDS straight into AGPRs by the register allocator; VGPRs hold the activations only.
+__device__ __forceinline__ void pool_mfma(f32x16 &p, const bf16x8 a, const bf16x8 b)
+{
+    // s_nop: the operands come from VALU instructions the hazard recogniser cannot see through the asm
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(p) : "v"(a), "v"(b));
+}
+
+// Pins a fragment to the accumulation registers (a value defined by an "a"-constrained asm can only be allocated
+// there); MFMA A/B operands and ds_read destinations may be AGPRs, so this costs no instruction -- it only keeps
+// the weight fragments from competing with the activations for the 256 VGPRs.
+__device__ __forceinline__ bf16x8 in_agpr(bf16x8 f)
+{
+    asm("" : "+a"(f));
+    return f;
+}
+
+struct ZoneRow {    // one zone row as loaded: floats 0-3, 4-5, and its last two
+    f32x4u a;
+    f32x2u b, c;
+};
+template <int F>
+__device__ __forceinline__ ZoneRow load_zone_row(const float *__restrict__ rows, int t)
+{
+    const float *p = rows + (size_t)t * F;
+    ZoneRow x;
+    x.a = *reinterpret_cast<const f32x4u *>(p);
+    x.b = *reinterpret_cast<const f32x2u *>(p + 4);
+    x.c = *reinterpret_cast<const f32x2u *>(p + F - 2);
+    return x;
+}
+// layer 1's B operand: lane half 0 the env's obs (k = 0..7, constant over the group's tiles), half 1 the
+// zone row (k = 8..14) and the bias slot (k = 15)
+template <int F>
+__device__ __forceinline__ bf16x8 zone_frag(const ZoneRow &x, const uint4 obs_frag, bool valid, int h)
+{
+    uint4 u;
+    u.x = pk_bf16(x.a.x, x.a.y);
+    u.y = pk_bf16(x.a.z, x.a.w);
+    u.z = pk_bf16(x.b.x, x.b.y);
+    u.w = pk_bf16(F == 7 ? x.c.y : 0.f, 1.0f);
+    if (!valid) u = make_uint4(0u, 0u, 0u, 0u);
+    if (h == 0) u = obs_frag;
+    return as_frag(u);
+}
+
+constexpr int kZone1Waves = 4;
+
+// One 32-row tile: layer-2 chains on xa, pooling into pool[], and layer 1 of the NEXT tile (operand x0n) into
+// xb.  pend = the previous tile's last chain, still to be converted and pooled; wf0 = fragments of output
+// tile 0, read by the previous tile.
+__device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lane, const bf16x8 (&w1f)[NT],
+                                          const bf16x8 (&ind)[2], const bf16x8 (&xa)[KS], bf16x8 (&xb)[KS],
+                                          const bf16x8 x0n, f32x16 &pend, f32x16 (&pool)[NT], bf16x8 (&wf0)[KS]
+#ifdef MLP_STAMP
+                                          , int wave, int stamp_it
+#endif
+                                          )
+{
+    bf16x8 wf[2][KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) wf[0][kk] = wf0[kk];
+    f32x16 acc[2];
+    acc[1] = pend;
+    // layer 1 of the next tile runs one region ahead of its conversion: an MFMA result is 64 cycles away
+    f32x16 a1 = mfma(w1f[0], x0n, zero16());
+    KSTAMP(0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int nn = (n + 1) % NT;
+        // the next chain's fragments first: they have this whole region to arrive
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#if defined(MLP_EXP) && (MLP_EXP & 4)      // diagnostic: one fragment read per chain instead of twelve
+            wf[(n + 1) & 1][kk] = kk == 0 ? as_frag(w2s[(nn * KS + kk) * kWave + lane]) : wf[n & 1][kk];
+#else
+            wf[(n + 1) & 1][kk] = as_frag(w2s[(nn * KS + kk) * kWave + lane]);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x16 prev = acc[(n + 1) & 1];                   // the chain before this one (n = 0: pend)
+        acc[n & 1] = zero16();
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) acc[n & 1] = mfma(xa[kk], in_agpr(wf[n & 1][kk]), acc[n & 1]);
+        {
+            bf16x8 f0, f1;
+#if defined(MLP_EXP) && (MLP_EXP & 1)      // diagnostic: no conversion of the previous chain
+            f0 = xa[0]; f1 = xa[1];
+            asm volatile("" ::"v"(prev));
+#else
+            acc_to_frags(prev, true, f0, f1);
+#endif
+#if !defined(MLP_EXP) || !(MLP_EXP & 8)    // diagnostic (bit 3): no pooling products
+            pool_mfma(pool[(n + NT - 1) % NT], ind[0], f0);
+            pool_mfma(pool[(n + NT - 1) % NT], ind[1], f1);
+#else
+            asm volatile("" ::"v"(f0), "v"(f1));
+#endif
+        }
+#if defined(MLP_EXP) && (MLP_EXP & 2)      // diagnostic: no conversion of layer 1
+        xb[2 * n] = xa[2 * n]; xb[2 * n + 1] = xa[2 * n + 1];
+        asm volatile("" ::"v"(a1));
+#else
+        acc_to_frags(a1, true, xb[2 * n], xb[2 * n + 1]);
+#endif
+        // (materialised here: otherwise the conversions sink into the next tile's block, behind its branch)
+        asm volatile("" : "+v"(xb[2 * n]), "+v"(xb[2 * n + 1]));
+        if (n + 1 < NT) a1 = mfma(w1f[n + 1], x0n, zero16());   // layer 1, next tile, output tile n + 1
+        __builtin_amdgcn_sched_barrier(0);
+        KSTAMP(1 + n);
+    }
+    pend = acc[(NT - 1) & 1];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) wf0[kk] = in_agpr(wf[NT & 1][kk]);   // (read a whole chain ago: no wait)
+}
+
+template <int ZT, int F>
+__global__ __launch_bounds__(kZone1Waves * kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, const float *__restrict__ zone_obs,
+                 __bf16 *__restrict__ pooled)
+{
+    extern __shared__ uint4 lds[];
+    uint4 *w2s = lds;                       // [NT*KS][64]
+    uint4 *w1s = lds + NT * KS * kWave;     // [NT][64]
+    for (int i = threadIdx.x; i < NT * KS * kWave; i += kZone1Waves * kWave)
+        w2s[i] = reinterpret_cast<const uint4 *>(img.w2)[i];
+    for (int i = threadIdx.x; i < NT * kWave; i += kZone1Waves * kWave) w1s[i] = reinterpret_cast<const uint4 *>(img.w1)[i];
+    __syncthreads();
+
+    const int Z = ZT > 0 ? ZT : Z_rt;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int env0 = (blockIdx.x * kZone1Waves + wave) * kWave;
+    if (env0 >= N) return;
+    const int n_env = min(kWave, N - env0);
+    const float inv_z = 1.0f / (float)Z;
+#ifdef MLP_STAMP
+    int stamp_it = 0;
+#endif
+    bf16x8 w1f[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) w1f[m] = in_agpr(as_frag(w1s[m * kWave + lane]));
+    // the identity as the pooling product's A operand: lane (slot r, half h) element j of k-step s is tile row
+    // 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the accumulator order of H2^T
+    bf16x8 ind[2];
+#pragma unroll
+    for (int sgm = 0; sgm < 2; ++sgm)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            ind[sgm][j] = (16 * sgm + 8 * (j >> 2) + 4 * h + (j & 3) == r) ? (__bf16)1.0f : (__bf16)0.0f;
+
+    for (int e_base = 0; e_base < n_env; e_base += 32) {
+        const bool valid = e_base + r < n_env;
+        const int env = env0 + e_base + (valid ? r : 0);
+        const float *rows = zone_obs + (size_t)env * Z * F;
+        uint4 obs_frag;
+        {
+            const float4 *o = reinterpret_cast<const float4 *>(obs + (size_t)env * 8);
+            const float4 a = o[0], b = o[1];
+            obs_frag = make_uint4(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w));
+            if (!valid) obs_frag = make_uint4(0u, 0u, 0u, 0u);
+        }
+        f32x16 pool[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            pool[n] = zero16();
+            asm volatile("" : "+a"(pool[n]));      // AGPR-resident from here on (see pool_mfma)
+        }
+        f32x16 pend = zero16();
+        bf16x8 wf0[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) wf0[kk] = in_agpr(as_frag(w2s[kk * kWave + lane]));
+        // prologue: layer 1 of tile 0 (not overlapped: once per Z tiles)
+        ZoneRow nxt = load_zone_row<F>(rows, 0);
+        bf16x8 xa[KS], xb[KS];
+        {
+            const bf16x8 x0 = zone_frag<F>(nxt, obs_frag, valid, h);
+            nxt = load_zone_row<F>(rows, min(1, Z - 1));
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                const f32x16 acc1 = mfma(w1f[m], x0, zero16());
+                acc_to_frags(acc1, true, xa[2 * m], xa[2 * m + 1]);
+            }
+        }
+        for (int t = 0; t < Z; t += 2) {
+            {
+                const bf16x8 x0n = zone_frag<F>(nxt, obs_frag, valid, h);          // tile t + 1
+                __builtin_amdgcn_sched_barrier(0);
+                nxt = load_zone_row<F>(rows, min(t + 2, Z - 1));
+                zone_tile(w2s, lane, w1f, ind, xa, xb, x0n, pend, pool, wf0 ZT_STAMP_ARGS);
+            }
+            if (t + 1 < Z) {
+                const bf16x8 x0n = zone_frag<F>(nxt, obs_frag, valid, h);          // tile t + 2
+                __builtin_amdgcn_sched_barrier(0);
+                nxt = load_zone_row<F>(rows, min(t + 3, Z - 1));
+                zone_tile(w2s, lane, w1f, ind, xb, xa, x0n, pend, pool, wf0 ZT_STAMP_ARGS);
+            }
+        }
+        // the last chain of the last tile
+        {
+            bf16x8 f0, f1;
+            acc_to_frags(pend, true, f0, f1);
+            pool_mfma(pool[NT - 1], ind[0], f0);
+            pool_mfma(pool[NT - 1], ind[1], f1);
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // asm MFMA results -> v_accvgpr_read
+        // ---- the group's means: accumulator register i of lane half h is env slot (i&3) + 8 (i>>2) + 4 h
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = e_base + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float v = pool[n][i] * inv_z;
+                const float vn = __shfl_down(v, 1);
+                if (e < n_env && !(r & 1))
+                    *reinterpret_cast<uint32_t *>(pooled + (size_t)(env0 + e) * HP + 32 * n + r) = pk_bf16(v, vn);
             }
     }
 }
@@ -570,6 +840,9 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
     return 0;
 }
 
+#ifndef MLP_KERNEL
+#define MLP_KERNEL 1      // 1: k_mlp_zone1 (one pipelined wave per SIMD), 0: k_mlp_zone (wave pair per SIMD)
+#endif
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
                               void *pooled_v, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s)
 {
@@ -580,8 +853,14 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
     do {                                                                                                          \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone<ZT, FF>),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-        hipLaunchKernelGGL((k_mlp_zone<ZT, FF>), grid, dim3(kZoneWaves * kWave), lds, s, img, N, Z, obs, zone_obs,  \
-                           pooled);                                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone1<ZT, FF>),                           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+        if (MLP_KERNEL == 1)                                                                                      \
+            hipLaunchKernelGGL((k_mlp_zone1<ZT, FF>), grid, dim3(kZone1Waves * kWave), lds, s, img, N, Z, obs,     \
+                               zone_obs, pooled);                                                                 \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_mlp_zone<ZT, FF>), grid, dim3(kZoneWaves * kWave), lds, s, img, N, Z, obs,       \
+                               zone_obs, pooled);                                                                 \
     } while (0)
     if (F == 6) {
         switch (Z) {
