@@ -43,14 +43,21 @@ constexpr int NT = kMlpNT, KS = kMlpKS, HP = kMlpHP;
 
 // Diagnostic builds only (scripts/probes/k4_stamps.hip): s_memtime stamps of one wave of block 0, per row tile.
 #ifdef MLP_STAMP
+#ifndef MLP_STAMP_SLOTS
+#define MLP_STAMP_SLOTS 0xFFFF      // bit s: stamp slot s is recorded
+#endif
 __device__ unsigned long long *g_k4_stamps;
 #define KSTAMP(slot)                                                                                       \
     do {                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        if (blockIdx.x == 0 && wave == (MLP_STAMP) && stamp_it < 64) {                                     \
+        if (blockIdx.x == 0 && wave == (MLP_STAMP) && stamp_it < 64 && (MLP_STAMP_SLOTS >> (slot)) & 1) {  \
             unsigned long long t_;                                                                         \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
             if (lane == 0) g_k4_stamps[stamp_it * 16 + (slot)] = t_;                                       \
+            if ((slot) == 0) {      /* the 100 MHz clock beside it: what frequency do the ticks run at? */ \
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+                if (lane == 0) g_k4_stamps[stamp_it * 16 + 15] = t_;                                       \
+            }                                                                                              \
         }                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
     } while (0)
@@ -368,6 +375,10 @@ __device__ __forceinline__ bf16x8 zone_frag(const ZoneRow &x, const uint4 obs_fr
 }
 
 constexpr int kZone1Waves = 4;
+#ifndef MLP_GAPS
+#define MLP_GAPS 6          // MFMA gaps that carry VALU work in a region ...
+#define MLP_PER_GAP 6       // ... and instructions per gap (32 per region: 16 + 16 conversions)
+#endif
 
 // One 32-row tile: layer-2 chains on xa, pooling into pool[], and layer 1 of the NEXT tile (operand x0n) into
 // xb.  pend = the previous tile's last chain, still to be converted and pooled; wf0 = fragments of output
@@ -428,6 +439,16 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
         // (materialised here: otherwise the conversions sink into the next tile's block, behind its branch)
         asm volatile("" : "+v"(xb[2 * n]), "+v"(xb[2 * n + 1]));
         if (n + 1 < NT) a1 = mfma(w1f[n + 1], x0n, zero16());   // layer 1, next tile, output tile n + 1
+#if !defined(MLP_EXP) || !(MLP_EXP & 32)
+        // order of the region: two chain MFMAs ahead of the first conversion (which waits for the previous chain's
+        // last result -- the new chain must not queue behind it), then six VALU instructions per MFMA gap
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+        for (int gsl = 0; gsl < MLP_GAPS; ++gsl) {
+            __builtin_amdgcn_sched_group_barrier(0x002, MLP_PER_GAP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         KSTAMP(1 + n);
     }

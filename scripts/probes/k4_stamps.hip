@@ -82,6 +82,8 @@ int main()
     for (int it = 3; it < 50; ++it) d.push_back((long long)(st[it * 16] - st[(it - 1) * 16]));
     std::sort(d.begin(), d.end());
     printf("  whole tile (stamp 0 -> next stamp 0): median %lld   min %lld   max %lld\n", d[d.size() / 2], d.front(), d.back());
+    printf("  shader clock over tiles 4..44: %.3f GHz\n",
+           (double)(st[44 * 16] - st[4 * 16]) / ((double)(st[44 * 16 + 15] - st[4 * 16 + 15]) * 10.0));
     return 0;
 #endif
 }
