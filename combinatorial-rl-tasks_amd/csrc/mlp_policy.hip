@@ -17,7 +17,8 @@
 //     X1   = relu(W1 X0)            features in registers, zone row on the lane     (6 MFMA / tile)
 //     H2^T = relu(X1^T W2^T)        zone row in registers, feature on the lane      (72 MFMA / tile)
 //     mean over the zone rows of an env = one more product P += S relu(H2^T) with a 0/1 selection
-//     matrix S[env slot][zone row] built in registers (12 MFMA / tile), accumulated per 32 envs.
+//     matrix S[env slot][zone row] (12 MFMA / tile), accumulated per 32 envs; tiles are zone-major in
+//     k_mlp_zone1 (tile t = zone t of 32 envs), which makes S the identity.
 //     The third zone_net_ layer has no activation, so the mean commutes with it and moves into
 //     kernel 2 -- 25x fewer rows for that layer (float reassociation only).
 //   kernel 2 (k_mlp_head), one wave per 64 envs, batch = envs:  e3 = W3 mean(H2); c = Wc [e3; obs];
