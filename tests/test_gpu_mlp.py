@@ -252,3 +252,20 @@ def test_ppo_example_runs(zenv_mod):
                        log=logs.append)
     assert len(hist) == 2 and all(np.isfinite(h["policy_loss"]) and np.isfinite(h["value_loss"]) for h in hist)
     assert hist[-1]["frames"] == 2 * 256 * 8 and hist[0]["collect_fps"] > 0
+
+
+def test_evaluate_with_a_checkpoint(zenv_mod):
+    """evaluate.py's protocol with an ACModel state_dict as the agent: the actor runs on the device; with argmax the
+    runs of one map are identical (deterministic), with dist.sample() (Agent.get_actions) they are not."""
+    import torch
+    from combinatorial_rl_tasks_amd.evaluate import evaluate
+    ex = _load_ppo_example()
+    torch.manual_seed(3)
+    sd = ex.ActorCritic(6).state_dict()
+    det = evaluate("PointTSP-v1", sd, n_maps=6, n_runs_per_map=3, argmax=True, max_steps=120)
+    ret = np.array(det["return"])
+    length = np.array(det["length"])
+    assert ret.shape == (6, 3) and np.isfinite(ret).all()
+    assert (ret == ret[:, :1]).all() and (length == length[:, :1]).all()
+    smp = evaluate("PointTSP-v1", sd, n_maps=6, n_runs_per_map=3, policy_seed=9, max_steps=120)
+    assert np.array(smp["return"]).shape == (6, 3)
