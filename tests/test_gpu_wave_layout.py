@@ -108,3 +108,58 @@ def test_wave_layout_goal_conditioned(zenv_mod):
         env.close()
     for (s0, d0, g0), (s1, d1, g1) in zip(*out):
         assert np.array_equal(s0, s1) and np.array_equal(d0, d1) and np.array_equal(g0, g1)
+
+
+@pytest.mark.parametrize("task,zones,seed", [(0, 25, 0), (1, 15, 1), (2, 6, 2), (1, 25, 3), (2, 25, 4)])
+def test_random_api_sequences_agree_between_layouts(zenv_mod, task, zones, seed):
+    """Differential test: K1w shares no step / reset / rollout code with K1 + K1p.  Random sequences of API calls
+    (rollouts in every launch mode, host actions, masked resets, frozen envs, snapshots) must leave the same
+    results behind in both layouts after every call."""
+    Z = zenv_mod
+    E = Z._native
+    n = 200
+    rs = np.random.RandomState(100 + seed)
+    envs = []
+    for kernel in (E.KERNEL_LANE_PER_ENV, E.KERNEL_WAVE_PER_ENV):
+        cfg = Z.default_config(task, zones, zones_keepout=0.40 if zones == 25 else 0.55, num_steps=40, kernel=kernel)
+        env = Z.ZoneVecEnv(cfg, n)
+        env.build_bank(11, 96)
+        env.schedule_fixed_seeds(np.arange(n, dtype=np.uint64) * 7 + seed, 11, 106)
+        env.reset()
+        envs.append(env)
+    fields = (Z.F_OBS, Z.F_ZONE_OBS, Z.F_REWARD, Z.F_DONE, Z.F_GOAL_MET, Z.F_EPISODES, Z.F_LAST_RETURN, Z.F_LAST_LEN,
+              Z.F_VISIT_COUNT, Z.F_EP_RETURN, Z.F_EP_LEN, Z.F_SEED)
+    snap = None
+    for it in range(40):
+        op = rs.randint(6)
+        if op == 0:
+            k, pol, auto = int(rs.randint(1, 70)), int(rs.randint(2)), bool(rs.randint(2))
+            mode = ("persistent", "per_step", "unfused")[rs.randint(3)]
+            for env in envs:
+                env.rollout(k, pol, policy_seed=it, env_index0=3, auto_reset=auto, mode=mode)
+        elif op == 1:
+            auto = bool(rs.randint(2))
+            for _ in range(int(rs.randint(1, 8))):
+                a = rs.uniform(-1.2, 1.2, (n, 2)).astype(np.float32)
+                for env in envs:
+                    env.step(a, auto_reset=auto)
+        elif op == 2:
+            m = (rs.uniform(size=n) < 0.3).astype(np.uint8)
+            for env in envs:
+                env.reset(mask=m)
+        elif op == 3:
+            for env in envs:
+                env.policy(Z.POLICY_GREEDY)
+                env.step(None, auto_reset=True)
+        elif op == 4:
+            snap = [env.get_state() for env in envs]
+        elif op == 5 and snap is not None:
+            for env, s in zip(envs, snap):
+                env.set_state(s)
+        for f in fields:
+            assert np.array_equal(envs[0].get(f), envs[1].get(f), equal_nan=True), (it, op, f)
+        a, b = envs[0].debug_state(), envs[1].debug_state()
+        for key in a:
+            assert np.array_equal(a[key], b[key]), (it, op, key)
+    for env in envs:
+        env.close()
