@@ -102,6 +102,7 @@ int main()
 {
     unsigned long long *d; float *sink;
     hipMalloc(&d, 8); hipMalloc(&sink, 256 * 256 * 4);
-    run<0>(d, sink); run<1>(d, sink); run<2>(d, sink); run<3>(d, sink);
+    // (mode 0 is not run: with identical operands in both regions of an iteration the compiler merges the two chains)
+    run<1>(d, sink); run<2>(d, sink); run<3>(d, sink);
     return 0;
 }
