@@ -32,7 +32,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k(unsigned long long *out, float *sink, int iters)
 {
     extern __shared__ uint4 lds[];
+#ifdef RANDOM_DATA      // bf16 values of magnitude ~1/8..1/2 with random mantissas and signs: every operand bit toggles
+    for (int i = threadIdx.x; i < 24 * 64; i += blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + 12345u;
+        auto nx = [&]() { h = h * 1664525u + 1013904223u; return ((h >> 8) & 0x80FF80FFu) | 0x3E003E00u; };
+        lds[i] = make_uint4(nx(), nx(), nx(), nx());
+    }
+#else
     for (int i = threadIdx.x; i < 24 * 64; i += blockDim.x) lds[i] = make_uint4(0x3C003C00u + i, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
+#endif
     __syncthreads();
     const int lane = threadIdx.x & 63;
     bf16x8 xa[12], wf[2][12], xb[12], w1 = pin_a(as_frag(lds[lane])), x0 = as_frag(lds[64 + lane]), ind0 = x0, ind1 = x0;
@@ -95,6 +103,9 @@ static void run(unsigned long long *d, float *sink)
     unsigned long long c = 0;
     hipMemcpy(&c, d, 8, hipMemcpyDeviceToHost);
     const int n_mfma = MODE >= 2 ? 15 : 13;
+#ifdef RANDOM_DATA
+    printf("[random operands] ");
+#endif
     printf("mode %d: %.0f cycles per region (%d MFMA = %d cycles of matrix pipe)\n", MODE, (double)c / iters, n_mfma, 32 * n_mfma);
 }
 
