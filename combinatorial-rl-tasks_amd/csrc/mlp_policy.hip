@@ -382,11 +382,12 @@ constexpr int kZone1Waves = 4;
 #endif
 
 // One 32-row tile: layer-2 chains on xa, pooling into pool[], and layer 1 of the NEXT tile (operand x0n) into
-// xb.  pend = the previous tile's last chain, still to be converted and pooled; wf0 = fragments of output
+// xb; x0nn is the operand of the tile after that.  pend = the previous tile's last chain, still to be converted and pooled; wf0 = fragments of output
 // tile 0, read by the previous tile.
 __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lane, const bf16x8 (&w1f)[NT],
                                           const bf16x8 (&ind)[2], const bf16x8 (&xa)[KS], bf16x8 (&xb)[KS],
-                                          const bf16x8 x0n, f32x16 &pend, f32x16 (&pool)[NT], bf16x8 (&wf0)[KS]
+                                          const bf16x8 x0n, const bf16x8 x0nn, f32x16 &a1, f32x16 &pend,
+                                          f32x16 (&pool)[NT], bf16x8 (&wf0)[KS]
 #ifdef MLP_STAMP
                                           , int wave, int stamp_it
 #endif
@@ -397,8 +398,9 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
     for (int kk = 0; kk < KS; ++kk) wf[0][kk] = wf0[kk];
     f32x16 acc[2];
     acc[1] = pend;
-    // layer 1 of the next tile runs one region ahead of its conversion: an MFMA result is 64 cycles away
-    f32x16 a1 = mfma(w1f[0], x0n, zero16());
+    // layer 1 of the next tile (operand x0n) runs one region ahead of its conversion -- an MFMA result is 64
+    // cycles away; a1 arrives holding its output tile 0, issued by the previous call, and leaves holding output
+    // tile 0 of the tile after next (operand x0nn), so that the tile boundary has matrix work in flight
     KSTAMP(0);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -439,7 +441,8 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
 #endif
         // (materialised here: otherwise the conversions sink into the next tile's block, behind its branch)
         asm volatile("" : "+v"(xb[2 * n]), "+v"(xb[2 * n + 1]));
-        if (n + 1 < NT) a1 = mfma(w1f[n + 1], x0n, zero16());   // layer 1, next tile, output tile n + 1
+        a1 = n + 1 < NT ? mfma(w1f[n + 1], x0n, zero16())       // layer 1, next tile, output tile n + 1
+                        : mfma(w1f[0], x0nn, zero16());         // ... and output tile 0 of the tile after it
 #if !defined(MLP_EXP) || !(MLP_EXP & 32)
         // order of the region: two chain MFMAs ahead of the first conversion (which waits for the previous chain's
         // last result -- the new chain must not queue behind it), then six VALU instructions per MFMA gap
@@ -466,9 +469,27 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
     extern __shared__ uint4 lds[];
     uint4 *w2s = lds;                       // [NT*KS][64]
     uint4 *w1s = lds + NT * KS * kWave;     // [NT][64]
-    for (int i = threadIdx.x; i < NT * KS * kWave; i += kZone1Waves * kWave)
-        w2s[i] = reinterpret_cast<const uint4 *>(img.w2)[i];
-    for (int i = threadIdx.x; i < NT * kWave; i += kZone1Waves * kWave) w1s[i] = reinterpret_cast<const uint4 *>(img.w1)[i];
+    {
+        // all of a thread's 18 + 2 loads in flight at once: as a load -> wait -> ds_write loop the staging was 18
+        // dependent L2 round trips (~14 us of a 115 us kernel with no wave doing anything else)
+        constexpr int kThreads = kZone1Waves * kWave, kPer = NT * KS * kWave / kThreads;
+        static_assert(NT * KS * kWave % kThreads == 0, "W2 image divides evenly over the workgroup");
+        uint4 t2[kPer], t1[2];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) t2[j] = reinterpret_cast<const uint4 *>(img.w2)[threadIdx.x + kThreads * j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = threadIdx.x + kThreads * j;
+            t1[j] = i < NT * kWave ? reinterpret_cast<const uint4 *>(img.w1)[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) w2s[threadIdx.x + kThreads * j] = t2[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = threadIdx.x + kThreads * j;
+            if (i < NT * kWave) w1s[i] = t1[j];
+        }
+    }
     __syncthreads();
 
     const int Z = ZT > 0 ? ZT : Z_rt;
@@ -517,6 +538,8 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
         // prologue: layer 1 of tile 0 (not overlapped: once per Z tiles)
         ZoneRow nxt = load_zone_row<F>(rows, 0);
         bf16x8 xa[KS], xb[KS];
+        bf16x8 x0n;
+        f32x16 a1;
         {
             const bf16x8 x0 = zone_frag<F>(nxt, obs_frag, valid, h);
             nxt = load_zone_row<F>(rows, min(1, Z - 1));
@@ -525,19 +548,24 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
                 const f32x16 acc1 = mfma(w1f[m], x0, zero16());
                 acc_to_frags(acc1, true, xa[2 * m], xa[2 * m + 1]);
             }
+            x0n = zone_frag<F>(nxt, obs_frag, valid, h);                           // tile 1
+            nxt = load_zone_row<F>(rows, min(2, Z - 1));
+            a1 = mfma(w1f[0], x0n, zero16());
         }
         for (int t = 0; t < Z; t += 2) {
             {
-                const bf16x8 x0n = zone_frag<F>(nxt, obs_frag, valid, h);          // tile t + 1
-                __builtin_amdgcn_sched_barrier(0);
-                nxt = load_zone_row<F>(rows, min(t + 2, Z - 1));
-                zone_tile(w2s, lane, w1f, ind, xa, xb, x0n, pend, pool, wf0 ZT_STAMP_ARGS);
-            }
-            if (t + 1 < Z) {
-                const bf16x8 x0n = zone_frag<F>(nxt, obs_frag, valid, h);          // tile t + 2
+                const bf16x8 x0nn = zone_frag<F>(nxt, obs_frag, valid, h);         // tile t + 2
                 __builtin_amdgcn_sched_barrier(0);
                 nxt = load_zone_row<F>(rows, min(t + 3, Z - 1));
-                zone_tile(w2s, lane, w1f, ind, xb, xa, x0n, pend, pool, wf0 ZT_STAMP_ARGS);
+                zone_tile(w2s, lane, w1f, ind, xa, xb, x0n, x0nn, a1, pend, pool, wf0 ZT_STAMP_ARGS);
+                x0n = x0nn;
+            }
+            if (t + 1 < Z) {
+                const bf16x8 x0nn = zone_frag<F>(nxt, obs_frag, valid, h);         // tile t + 3
+                __builtin_amdgcn_sched_barrier(0);
+                nxt = load_zone_row<F>(rows, min(t + 4, Z - 1));
+                zone_tile(w2s, lane, w1f, ind, xb, xa, x0n, x0nn, a1, pend, pool, wf0 ZT_STAMP_ARGS);
+                x0n = x0nn;
             }
         }
         // the last chain of the last tile
