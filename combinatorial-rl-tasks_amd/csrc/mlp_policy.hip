@@ -41,6 +41,9 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 constexpr int kWave = 64;
 constexpr int NT = kMlpNT, KS = kMlpKS, HP = kMlpHP;
+#ifndef MLP_KERNEL
+#define MLP_KERNEL 1      // 1: k_mlp_zone1 (one pipelined wave per SIMD; shipped), 0: k_mlp_zone (its predecessor, a
+#endif                    //    wave pair per SIMD -- compiled only on request, for comparison)
 
 // Diagnostic builds only (scripts/probes/k4_stamps.hip): s_memtime stamps of one wave of block 0, per row tile.
 #ifdef MLP_STAMP
@@ -131,6 +134,7 @@ __device__ __forceinline__ bf16x8 frag_from_floats(const float4 lo, const float4
 // never past the end of a row; the values are only looked at by row_frag(), one tile later.
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+#if MLP_KERNEL == 0
 struct RawRow {
     f32x4u a;       // floats 0-3
     f32x2u b, c;    // floats 4-5; obs: floats 6-7, zone row: its last two floats
@@ -316,6 +320,8 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
             }
     }
 }
+
+#endif   // MLP_KERNEL == 0
 
 // ------------------------------------------------------------------------------------------ kernel 1, v2
 // k_mlp_zone1: ONE wave per SIMD (4 per workgroup, 512 registers each), software-pipelined by hand so that
@@ -890,27 +896,24 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
     return 0;
 }
 
-#ifndef MLP_KERNEL
-#define MLP_KERNEL 1      // 1: k_mlp_zone1 (one pipelined wave per SIMD), 0: k_mlp_zone (wave pair per SIMD)
-#endif
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
                               void *pooled_v, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s)
 {
     __bf16 *pooled = static_cast<__bf16 *>(pooled_v);
     const dim3 grid((N + 4 * kWave - 1) / (4 * kWave));   // one workgroup per 4 groups of 64 envs
     const size_t lds = (size_t)(NT * KS + NT) * kWave * sizeof(uint4);
+#if MLP_KERNEL == 1
+#define ZENV_MLP_KERNEL k_mlp_zone1
+    const dim3 block(kZone1Waves * kWave);
+#else
+#define ZENV_MLP_KERNEL k_mlp_zone
+    const dim3 block(kZoneWaves * kWave);
+#endif
 #define ZENV_MLP(ZT, FF)                                                                                          \
     do {                                                                                                          \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone<ZT, FF>),                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ZENV_MLP_KERNEL<ZT, FF>),                       \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone1<ZT, FF>),                           \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-        if (MLP_KERNEL == 1)                                                                                      \
-            hipLaunchKernelGGL((k_mlp_zone1<ZT, FF>), grid, dim3(kZone1Waves * kWave), lds, s, img, N, Z, obs,     \
-                               zone_obs, pooled);                                                                 \
-        else                                                                                                      \
-            hipLaunchKernelGGL((k_mlp_zone<ZT, FF>), grid, dim3(kZoneWaves * kWave), lds, s, img, N, Z, obs,       \
-                               zone_obs, pooled);                                                                 \
+        hipLaunchKernelGGL((ZENV_MLP_KERNEL<ZT, FF>), grid, block, lds, s, img, N, Z, obs, zone_obs, pooled);      \
     } while (0)
     if (F == 6) {
         switch (Z) {
@@ -927,6 +930,7 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
         }
     }
 #undef ZENV_MLP
+#undef ZENV_MLP_KERNEL
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds_head = 2 * (size_t)kImgFrags * kWave * sizeof(uint4);

@@ -68,7 +68,11 @@ int main()
     printf("K4 + K5 with stamps (wave %d): %.1f us per forward\n", (int)(MLP_STAMP), ms / 20 * 1e3);
     std::vector<unsigned long long> st(64 * 16);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
-    const int n_slots = MLP_KERNEL == 1 ? 7 : 4 + NH;
+#if MLP_KERNEL == 1
+    const int n_slots = 7;
+#else
+    const int n_slots = 4 + NH;
+#endif
     const char *names[] = { "tile start -> x0, rows issued, L1 done", "L1 done -> selection matrix", "", "", "", "", "" };
     (void)names;
     printf("slot deltas (cycles, median over tiles 2..49; s_memtime + lgkmcnt(0) at each stamp perturbs):\n");
