@@ -183,7 +183,7 @@ def main():
     if rank == 0:
         total_env_steps = world * n_env * args.steps
         value = total_env_steps / elapsed
-        persistent = args.mode == "persistent" and zones in (5, 6, 15, 25)
+        persistent = args.mode == "persistent" and zones in (5, 6, 10, 15, 20, 25)
         chunk = min(Z._native.ROLLOUT_CHUNK, max(args.steps, 1)) if persistent else 1
         alg = algorithmic_bytes(task, zones, chunk)
         roofline = None

@@ -2204,7 +2204,9 @@ static void launch_step_task(const DevParams &p, const float *actions, int auto_
     switch (p.Z) {
     case 5: ZENV_LAUNCH(5); break;
     case 6: ZENV_LAUNCH(6); break;
+    case 10: ZENV_LAUNCH(10); break;
     case 15: ZENV_LAUNCH(15); break;
+    case 20: ZENV_LAUNCH(20); break;
     case 25: ZENV_LAUNCH(25); break;
     default: ZENV_LAUNCH(0); break;
     }
@@ -2251,7 +2253,7 @@ static inline size_t rollout_lds_bytes(const DevParams &p)
 
 bool rollout_kernel_available(const DevParams &p)
 {
-    return p.kernel == ZENV_KERNEL_LANE_PER_ENV && (p.Z == 5 || p.Z == 6 || p.Z == 15 || p.Z == 25);
+    return p.kernel == ZENV_KERNEL_LANE_PER_ENV && (p.Z == 5 || p.Z == 6 || p.Z == 10 || p.Z == 15 || p.Z == 20 || p.Z == 25);
 }
 
 template <int TASK>
@@ -2266,7 +2268,9 @@ static void launch_rollout_task(const DevParams &p, int n_steps, int auto_reset,
     switch (p.Z) {
     case 5: ZENV_LAUNCH(5); break;
     case 6: ZENV_LAUNCH(6); break;
+    case 10: ZENV_LAUNCH(10); break;
     case 15: ZENV_LAUNCH(15); break;
+    case 20: ZENV_LAUNCH(20); break;
     default: ZENV_LAUNCH(25); break;
     }
 #undef ZENV_LAUNCH

@@ -181,7 +181,7 @@ int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0
 /* K closed-loop steps a_t = policy(obs_t, t); step(a_t) on the handle's stream, HIP-event
  * timed.  Default (flags 0): the persistent rollout kernel -- one launch advances every env by
  * up to ZENV_ROLLOUT_CHUNK steps with the env state in registers, publishing obs / zone_obs / reward / done /
- * goal_met to memory on every step (zone counts 5, 6, 15, 25; other counts use the next mode).
+ * goal_met to memory on every step (zone counts 5, 6, 10, 15, 20, 25; other counts use the next mode).
  * ZENV_ROLLOUT_PER_STEP: one step-kernel launch per step, the kernel of step t also emitting
  * a_{t+1} (fused action source).  ZENV_ROLLOUT_UNFUSED: per-step launches with the stand-alone
  * policy kernel before each.  Results are identical in all three.  ms_total: whole loop (events

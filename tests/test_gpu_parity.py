@@ -83,7 +83,8 @@ def test_policy_kernels_match_oracle(zenv_mod, oracle_mod, task):
 
 @pytest.mark.parametrize("mode", ["persistent", "per_step", "unfused"])
 @pytest.mark.parametrize("task,zones,keepout", [(0, 25, 0.40), (1, 25, 0.40), (2, 6, 0.55), (0, 5, 0.55),
-                                                (1, 7, 0.55), (0, 15, 0.55), (2, 25, 0.40), (1, 6, 0.55)])
+                                                (1, 7, 0.55), (0, 15, 0.55), (2, 25, 0.40), (1, 6, 0.55),
+                                                (2, 10, 0.55), (1, 20, 0.45)])
 def test_closed_loop_rollout_matches_oracle(zenv_mod, oracle_mod, task, zones, keepout, mode):
     """Device-resident closed loop (persistent rollout kernel / step kernel with fused action
     source / policy kernel + step kernel; auto-reset onto fresh seeds) against the oracle's
