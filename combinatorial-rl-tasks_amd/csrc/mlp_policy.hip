@@ -750,33 +750,26 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
 }
 
 // ------------------------------------------------------------------------------------------ experiences
-// collect_experiences (main/src/torch_ac/algos/base.py:131-216) on the device.  Buffers are env-major
-// [N][T][...], the layout of exps.* there ("k-th block of T consecutive frames = k-th env", :125-128).
-__global__ __launch_bounds__(256) void k_exp_record(ExpBuffers x, int N, int ZF, int t, const float *__restrict__ obs,
-                                                    const float *__restrict__ zone_obs,
-                                                    const float *__restrict__ actions, const float *__restrict__ mu,
-                                                    const float *__restrict__ stdv, const float *__restrict__ value)
+// collect_experiences (main/src/torch_ac/algos/base.py:131-216) on the device.  The per-frame scalars are env-major
+// [N][T][...], the layout of exps.* there ("k-th block of T consecutive frames = k-th env", :125-128); the
+// observations are TIME-major [T][N][...]: the step kernel writes obs_{t+1} / zone_obs_{t+1} straight into slot t+1
+// (zenv_collect points it there), so recording them costs no copy -- the caller sees the transposed view.
+__global__ __launch_bounds__(256) void k_exp_record(ExpBuffers x, int N, int t, const float *__restrict__ actions,
+                                                    const float *__restrict__ mu, const float *__restrict__ stdv,
+                                                    const float *__restrict__ value)
 {
-    // one wave per env: the zone rows are the bulk (Z*F floats)
-    const int lane = threadIdx.x & 63;
-    const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
     const size_t slot = (size_t)env * x.T + t;
-    const float *zsrc = zone_obs + (size_t)env * ZF;
-    float *zdst = x.zone_obs + slot * ZF;
-    for (int i = lane; i < ZF; i += 64) zdst[i] = zsrc[i];
-    if (lane < 8) x.obs[slot * 8 + lane] = obs[(size_t)env * 8 + lane];
-    if (lane < 2) {
-        const float a = actions[(size_t)env * 2 + lane], m = mu[(size_t)env * 2 + lane], sd = stdv[(size_t)env * 2 + lane];
-        x.action[slot * 2 + lane] = a;
-        // Normal(mu, std).log_prob(a), per action dimension (base.py:160)
-        const float zz = (a - m) / sd;
-        x.log_prob[slot * 2 + lane] = -0.5f * zz * zz - logf(sd) - 0.91893853320467274178f;
-    }
-    if (lane == 0) {
-        x.value[slot] = value[env];
-        x.mask[slot] = x.cur_mask[env];                 // self.masks[i] = self.mask (:149), BEFORE this step
-    }
+    const float2 a = reinterpret_cast<const float2 *>(actions)[env], m = reinterpret_cast<const float2 *>(mu)[env];
+    const float2 sd = reinterpret_cast<const float2 *>(stdv)[env];
+    reinterpret_cast<float2 *>(x.action)[slot] = a;
+    // Normal(mu, std).log_prob(a), per action dimension (base.py:160)
+    const float z0 = (a.x - m.x) / sd.x, z1 = (a.y - m.y) / sd.y;
+    reinterpret_cast<float2 *>(x.log_prob)[slot] = make_float2(-0.5f * z0 * z0 - logf(sd.x) - 0.91893853320467274178f,
+                                                               -0.5f * z1 * z1 - logf(sd.y) - 0.91893853320467274178f);
+    x.value[slot] = value[env];
+    x.mask[slot] = x.cur_mask[env];                     // self.masks[i] = self.mask (:149), BEFORE this step
 }
 
 // after the env step: rewards[i] (shaped_reward when the env provides it, :153-159) and the new self.mask
@@ -941,10 +934,10 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
     return hipGetLastError();
 }
 
-hipError_t launch_exp_record(const ExpBuffers &x, int N, int ZF, int t, const float *obs, const float *zone_obs,
-                             const float *actions, const float *mu, const float *stdv, const float *value, hipStream_t s)
+hipError_t launch_exp_record(const ExpBuffers &x, int N, int t, const float *actions, const float *mu, const float *stdv,
+                             const float *value, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_exp_record, dim3((N + 3) / 4), dim3(256), 0, s, x, N, ZF, t, obs, zone_obs, actions, mu, stdv, value);
+    hipLaunchKernelGGL(k_exp_record, dim3((N + 255) / 256), dim3(256), 0, s, x, N, t, actions, mu, stdv, value);
     return hipGetLastError();
 }
 

@@ -50,18 +50,19 @@ inline MlpAction no_mlp_action() { return MlpAction{ -1, 0u, 0ull, 0ull, nullptr
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
                               void *pooled, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s);
 
-// Experience buffers of one collect_experiences() call (base.py:131-216), env-major [N][T][...]
+// Experience buffers of one collect_experiences() call (base.py:131-216): scalars env-major [N][T][...],
+// observations time-major [T][N][...] (written in place by the step kernel)
 struct ExpBuffers {
     int T;
-    float *obs;        // [N][T][8]
-    float *zone_obs;   // [N][T][Z*F]
+    float *obs;        // [T][N][8]
+    float *zone_obs;   // [T][N][Z*F]
     float *action;     // [N][T][2]
     float *log_prob;   // [N][T][2]
     float *value, *reward, *mask, *advantage, *returnn;   // [N][T]
     float *cur_mask;   // [N]  self.mask, carried from one call to the next
 };
-hipError_t launch_exp_record(const ExpBuffers &x, int N, int ZF, int t, const float *obs, const float *zone_obs,
-                             const float *actions, const float *mu, const float *stdv, const float *value, hipStream_t s);
+hipError_t launch_exp_record(const ExpBuffers &x, int N, int t, const float *actions, const float *mu, const float *stdv,
+                             const float *value, hipStream_t s);
 hipError_t launch_exp_reward(const ExpBuffers &x, int N, int t, const float *reward, const double *shaped,
                              const uint8_t *done, hipStream_t s);
 hipError_t launch_exp_gae(const ExpBuffers &x, int N, const float *next_value, float discount, float gae_lambda,

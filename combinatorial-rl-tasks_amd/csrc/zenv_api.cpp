@@ -836,12 +836,24 @@ extern "C" int zenv_collect(zenv_t *h, int T, uint64_t policy_seed, uint64_t env
         if (keep_mask.empty()) keep_mask.assign(N, 1.0f);      // base.py:96 self.mask = ones
         HIP_TRY(hipMemcpy(x.cur_mask, keep_mask.data(), N * 4, hipMemcpyHostToDevice));
     }
+    // The observations are recorded where they are produced: the policy of frame t reads slot t, the step kernel
+    // of frame t writes obs_{t+1} into slot t+1 (the last one into the handle's own buffers again).
+    struct ObsRedirect {
+        zenv_t *h;
+        float *obs, *zone_obs;
+        ~ObsRedirect() { h->p.obs = obs; h->p.zone_obs = zone_obs; }
+    } home{ h, h->p.obs, h->p.zone_obs };
+    HIP_TRY(hipMemcpyAsync(h->exp.obs, home.obs, N * 8 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->exp.zone_obs, home.zone_obs, N * ZF * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     for (int t = 0; t < T; ++t) {
+        h->p.obs = h->exp.obs + (size_t)t * N * 8;
+        h->p.zone_obs = h->exp.zone_obs + (size_t)t * N * ZF;
         StepPolicy pol{ ZENV_POLICY_MLP_SAMPLE, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };
         rc = run_policy(h, pol);                               // dist, value = acmodel(obs); action = dist.sample()
         if (rc) return rc;
-        HIP_TRY(launch_exp_record(h->exp, h->n_env, (int)ZF, t, h->p.obs, h->p.zone_obs, h->p.actions, h->mlp_mu,
-                                  h->mlp_std, h->mlp_value, h->stream));
+        HIP_TRY(launch_exp_record(h->exp, h->n_env, t, h->p.actions, h->mlp_mu, h->mlp_std, h->mlp_value, h->stream));
+        h->p.obs = t + 1 < T ? h->exp.obs + (size_t)(t + 1) * N * 8 : home.obs;
+        h->p.zone_obs = t + 1 < T ? h->exp.zone_obs + (size_t)(t + 1) * N * ZF : home.zone_obs;
         HIP_TRY(launch_step(h->p, h->p.actions, 1, no_policy(), h->stream));     // ParallelEnv.step: auto-reset
         if (h->goal_enabled) HIP_TRY(launch_goal_step(h->p, h->stream));
         HIP_TRY(launch_exp_reward(h->exp, h->n_env, t, h->p.reward, h->goal_enabled ? h->p.shaped : nullptr,

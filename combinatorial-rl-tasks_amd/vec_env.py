@@ -288,15 +288,16 @@ class ZoneVecEnv:
     def collect(self, frames_per_proc, policy_seed=1, env_index0=0, discount=0.99, gae_lambda=0.95):
         """BaseAlgo.collect_experiences (main/src/torch_ac/algos/base.py:131-227) on the device with the loaded
         actor-critic.  Returns a dict of env-major arrays [N, T, ...] -- reshape(N*T, ...) gives exps.* of the
-        reference (:211-227): obs, zone_obs, action, log_prob, value, reward, mask, advantage, returnn."""
+        reference (:211-227): obs, zone_obs, action, log_prob, value, reward, mask, advantage, returnn (obs and
+        zone_obs are transposed views of time-major buffers: reshape copies them once)."""
         T = int(frames_per_proc)
         self.collect_on_device(T, policy_seed, env_index0, discount, gae_lambda)
         out = {}
-        for name, (field, shape) in self.experience_layout(T).items():
+        for name, (field, shape, time_major) in self.experience_layout(T).items():
             a = np.empty(shape, np.float32)
             assert a.nbytes == lib().zenv_field_bytes(self._h, field)
             check(lib().zenv_get(self._h, field, a.ctypes.data, 0))
-            out[name] = a
+            out[name] = a.swapaxes(0, 1) if time_major else a
         return out
 
     def collect_on_device(self, frames_per_proc, policy_seed=1, env_index0=0, discount=0.99, gae_lambda=0.95):
@@ -305,13 +306,15 @@ class ZoneVecEnv:
                                  float(discount), float(gae_lambda)))
 
     def experience_layout(self, frames_per_proc):
-        """name -> (field id, shape) of the float32 buffers one collect of T frames per env fills."""
+        """name -> (field id, shape in memory, time_major) of the float32 buffers one collect of T frames per env
+        fills.  The observations are time-major [T, N, ...] in memory (the step kernel writes them in place);
+        ``collect`` hands out their [N, T, ...] view."""
         N, Z, F, T = self.num_envs, self.num_zones, self.zone_feat, int(frames_per_proc)
-        return {"obs": (nat.F_EXP_OBS, (N, T, 8)), "zone_obs": (nat.F_EXP_ZONE_OBS, (N, T, Z, F)),
-                "action": (nat.F_EXP_ACTION, (N, T, 2)), "log_prob": (nat.F_EXP_LOG_PROB, (N, T, 2)),
-                "value": (nat.F_EXP_VALUE, (N, T)), "reward": (nat.F_EXP_REWARD, (N, T)),
-                "mask": (nat.F_EXP_MASK, (N, T)), "advantage": (nat.F_EXP_ADVANTAGE, (N, T)),
-                "returnn": (nat.F_EXP_RETURN, (N, T))}
+        return {"obs": (nat.F_EXP_OBS, (T, N, 8), True), "zone_obs": (nat.F_EXP_ZONE_OBS, (T, N, Z, F), True),
+                "action": (nat.F_EXP_ACTION, (N, T, 2), False), "log_prob": (nat.F_EXP_LOG_PROB, (N, T, 2), False),
+                "value": (nat.F_EXP_VALUE, (N, T), False), "reward": (nat.F_EXP_REWARD, (N, T), False),
+                "mask": (nat.F_EXP_MASK, (N, T), False), "advantage": (nat.F_EXP_ADVANTAGE, (N, T), False),
+                "returnn": (nat.F_EXP_RETURN, (N, T), False)}
 
     def sync(self):
         check(lib().zenv_sync(self._h))

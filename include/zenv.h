@@ -67,8 +67,8 @@ enum {
     ZENV_F_AVAILABLE_GOALS = 18, /* uint32  [N] get_available_goals() as a bit mask, bit z = zone z unvisited */
     ZENV_F_GOAL = 19,            /* int32   [N] goal zone, -1 = none */
     /* experience buffers of the last zenv_collect(), env-major: [N][T][...] (base.py:125-128, :211-227) */
-    ZENV_F_EXP_OBS = 20,         /* float32 [N,T,8] */
-    ZENV_F_EXP_ZONE_OBS = 21,    /* float32 [N,T,Z,F] */
+    ZENV_F_EXP_OBS = 20,         /* float32 [T,N,8]    time-major: written in place by the step kernel ... */
+    ZENV_F_EXP_ZONE_OBS = 21,    /* float32 [T,N,Z,F]  ... the other ZENV_F_EXP_* are env-major [N,T,...] */
     ZENV_F_EXP_ACTION = 22,      /* float32 [N,T,2] */
     ZENV_F_EXP_LOG_PROB = 23,    /* float32 [N,T,2]  Normal(mu, std).log_prob(action) */
     ZENV_F_EXP_VALUE = 24,       /* float32 [N,T] */
