@@ -664,6 +664,7 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
     const int env = min(first + r, max(N - 1, 0));
     const bool valid = first + r < N;
     const bool critic = img.wv1 != nullptr;
+    float value_out = 0.f;
 
     stage_issue(bufA, img.w3, NT * KS);
     bf16x8 x[KS], xo;
@@ -721,7 +722,8 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
         f32x16 hv = zero16();
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) hv = mfma(as_frag(bufB[kk * kWave + lane]), xv[kk], hv);
-        if (h == 0 && valid) value[env] = hv[0];
+        value_out = hv[0];
+        if (h == 0 && valid) value[env] = value_out;
     }
     // ---- a = relu(Wa c)   (actor.enc_)
     stage_fence();
@@ -745,34 +747,39 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
         const float2 sd = make_float2(sigmoidf_(hd[2]) + 1e-3f, sigmoidf_(hd[3]) + 1e-3f);
         reinterpret_cast<float2 *>(mu)[env] = m;
         reinterpret_cast<float2 *>(stdv)[env] = sd;
-        if (act.mode >= 0) reinterpret_cast<float2 *>(act.actions)[env] = mlp_action(act, env, m, sd);
+        if (act.mode >= 0) {
+            const float2 a = mlp_action(act, env, m, sd);
+            reinterpret_cast<float2 *>(act.actions)[env] = a;
+            const MlpRecord &rc = act.rec;
+            if (rc.action) {
+                const size_t slot = (size_t)env * rc.T + rc.t;
+                reinterpret_cast<float2 *>(rc.action)[slot] = a;
+                // Normal(mu, std).log_prob(a), per action dimension (base.py:160)
+                const float z0 = (a.x - m.x) / sd.x, z1 = (a.y - m.y) / sd.y;
+                reinterpret_cast<float2 *>(rc.log_prob)[slot] =
+                    make_float2(-0.5f * z0 * z0 - logf(sd.x) - 0.91893853320467274178f,
+                                -0.5f * z1 * z1 - logf(sd.y) - 0.91893853320467274178f);
+                rc.value[slot] = value_out;
+                if (rc.t == 0) {
+                    rc.mask[slot] = rc.cur_mask[env];            // self.masks[i] = self.mask (:149), BEFORE this step
+                } else {
+                    rc.mask[slot] = rc.prev_done[env] ? 0.f : 1.f;                 // self.mask = 1 - done (:150)
+                    rc.reward[slot - 1] = rc.prev_shaped ? (float)rc.prev_shaped[env] : rc.prev_reward[env];
+                }
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------ experiences
 // collect_experiences (main/src/torch_ac/algos/base.py:131-216) on the device.  The per-frame scalars are env-major
-// [N][T][...], the layout of exps.* there ("k-th block of T consecutive frames = k-th env", :125-128); the
-// observations are TIME-major [T][N][...]: the step kernel writes obs_{t+1} / zone_obs_{t+1} straight into slot t+1
-// (zenv_collect points it there), so recording them costs no copy -- the caller sees the transposed view.
-__global__ __launch_bounds__(256) void k_exp_record(ExpBuffers x, int N, int t, const float *__restrict__ actions,
-                                                    const float *__restrict__ mu, const float *__restrict__ stdv,
-                                                    const float *__restrict__ value)
-{
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= N) return;
-    const size_t slot = (size_t)env * x.T + t;
-    const float2 a = reinterpret_cast<const float2 *>(actions)[env], m = reinterpret_cast<const float2 *>(mu)[env];
-    const float2 sd = reinterpret_cast<const float2 *>(stdv)[env];
-    reinterpret_cast<float2 *>(x.action)[slot] = a;
-    // Normal(mu, std).log_prob(a), per action dimension (base.py:160)
-    const float z0 = (a.x - m.x) / sd.x, z1 = (a.y - m.y) / sd.y;
-    reinterpret_cast<float2 *>(x.log_prob)[slot] = make_float2(-0.5f * z0 * z0 - logf(sd.x) - 0.91893853320467274178f,
-                                                               -0.5f * z1 * z1 - logf(sd.y) - 0.91893853320467274178f);
-    x.value[slot] = value[env];
-    x.mask[slot] = x.cur_mask[env];                     // self.masks[i] = self.mask (:149), BEFORE this step
-}
+// [N][T][...], the layout of exps.* there ("k-th block of T consecutive frames = k-th env", :125-128), written by
+// the head kernel's epilogue (MlpRecord); the observations are TIME-major [T][N][...]: the step kernel writes
+// obs_{t+1} / zone_obs_{t+1} straight into slot t+1 (zenv_collect points it there), so recording them costs no
+// copy -- the caller sees the transposed view.
 
-// after the env step: rewards[i] (shaped_reward when the env provides it, :153-159) and the new self.mask
+// after the LAST env step of a call: rewards[T-1] (shaped_reward when the env provides it, :153-159) and the new
+// self.mask (the earlier frames' rewards are recorded by the next frame's head kernel)
 __global__ __launch_bounds__(256) void k_exp_reward(ExpBuffers x, int N, int t, const float *__restrict__ reward,
                                                     const double *__restrict__ shaped, const uint8_t *__restrict__ done)
 {
@@ -931,13 +938,6 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
                               (int)lds_head);
     hipLaunchKernelGGL(k_mlp_head, dim3((N + kHeadWaves * 32 - 1) / (kHeadWaves * 32)), dim3(kHeadWaves * kWave), lds_head, s,
                        img, N, obs, pooled, mu, stdv, value, act);
-    return hipGetLastError();
-}
-
-hipError_t launch_exp_record(const ExpBuffers &x, int N, int t, const float *actions, const float *mu, const float *stdv,
-                             const float *value, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_exp_record, dim3((N + 255) / 256), dim3(256), 0, s, x, N, t, actions, mu, stdv, value);
     return hipGetLastError();
 }
 

@@ -37,13 +37,25 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
 // What the head kernel does with (mu, std) besides storing them: nothing (mode < 0), actions = mu (0), or
 // actions = mu + std * eps with eps ~ N(0,1) from Philox4x32-10 keyed by (seed, global env, step) (1) -- the
 // reference's dist.sample() (utils/agent.py:41-44).
+// rec (zenv_collect only): the head kernel also writes frame t of the experience buffers -- action, per-dimension
+// log_prob, value, mask -- and the reward of frame t-1, which the step kernel left behind in the env's own
+// reward / done buffers (collect_experiences, base.py:146-160; env-major [N][T] arrays).
+struct MlpRecord {
+    float *action, *log_prob, *value, *mask, *reward;   // null action: nothing is recorded
+    const float *cur_mask;                               // mask of frame 0 (self.mask of the previous call)
+    const float *prev_reward;                            // frame t-1 ...
+    const double *prev_shaped;                           // ... or its shaped_reward (goal-conditioned envs), else null
+    const uint8_t *prev_done;
+    int T, t;
+};
 struct MlpAction {
     int mode;
     uint32_t step_index;
     uint64_t seed, env_index0;
     float *actions;
+    MlpRecord rec;
 };
-inline MlpAction no_mlp_action() { return MlpAction{ -1, 0u, 0ull, 0ull, nullptr }; }
+inline MlpAction no_mlp_action() { return MlpAction{ -1, 0u, 0ull, 0ull, nullptr, MlpRecord{} }; }
 
 // obs [N,8], zone_obs [N,Z,F] float32 (device) -> mu, std [N,2] float32 (device).
 // pooled: scratch [N][kMlpHP] bf16 (device).
@@ -61,8 +73,6 @@ struct ExpBuffers {
     float *value, *reward, *mask, *advantage, *returnn;   // [N][T]
     float *cur_mask;   // [N]  self.mask, carried from one call to the next
 };
-hipError_t launch_exp_record(const ExpBuffers &x, int N, int t, const float *actions, const float *mu, const float *stdv,
-                             const float *value, hipStream_t s);
 hipError_t launch_exp_reward(const ExpBuffers &x, int N, int t, const float *reward, const double *shaped,
                              const uint8_t *done, hipStream_t s);
 hipError_t launch_exp_gae(const ExpBuffers &x, int N, const float *next_value, float discount, float gae_lambda,

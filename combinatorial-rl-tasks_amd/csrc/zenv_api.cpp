@@ -784,7 +784,7 @@ static bool policy_known(int policy) { return policy >= ZENV_POLICY_UNIFORM && p
 static bool policy_is_mlp(int policy) { return policy == ZENV_POLICY_MLP_MEAN || policy == ZENV_POLICY_MLP_SAMPLE; }
 
 // a_t = pi(obs_t, t) into pol.out, for every kind of action source
-static int run_policy(zenv_t *h, const StepPolicy &pol)
+static int run_policy(zenv_t *h, const StepPolicy &pol, const MlpRecord *rec = nullptr)
 {
     if (!policy_is_mlp(pol.policy)) {
         HIP_TRY(launch_policy(h->p, pol, h->stream));
@@ -792,7 +792,8 @@ static int run_policy(zenv_t *h, const StepPolicy &pol)
     }
     if (!h->mlp_ready) return fail(ZENV_E_STATE, "zenv_mlp_load first");
     // the head kernel also turns (mu, std) into the action
-    const MlpAction act{ pol.policy == ZENV_POLICY_MLP_SAMPLE ? 1 : 0, pol.step_index, pol.seed, pol.env_index0, pol.out };
+    const MlpAction act{ pol.policy == ZENV_POLICY_MLP_SAMPLE ? 1 : 0, pol.step_index, pol.seed, pol.env_index0, pol.out,
+                         rec ? *rec : MlpRecord{} };
     HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
                                h->mlp_std, h->mlp_value, act, h->stream));
     return ZENV_OK;
@@ -849,17 +850,20 @@ extern "C" int zenv_collect(zenv_t *h, int T, uint64_t policy_seed, uint64_t env
         h->p.obs = h->exp.obs + (size_t)t * N * 8;
         h->p.zone_obs = h->exp.zone_obs + (size_t)t * N * ZF;
         StepPolicy pol{ ZENV_POLICY_MLP_SAMPLE, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };
-        rc = run_policy(h, pol);                               // dist, value = acmodel(obs); action = dist.sample()
+        // dist, value = acmodel(obs); action = dist.sample(); the head kernel also records frame t (and the reward
+        // of frame t-1, still in the env's reward / done buffers)
+        const MlpRecord rec{ h->exp.action, h->exp.log_prob, h->exp.value, h->exp.mask, h->exp.reward, h->exp.cur_mask,
+                             h->p.reward, h->goal_enabled ? h->p.shaped : nullptr, h->p.done_out, T, t };
+        rc = run_policy(h, pol, &rec);
         if (rc) return rc;
-        HIP_TRY(launch_exp_record(h->exp, h->n_env, t, h->p.actions, h->mlp_mu, h->mlp_std, h->mlp_value, h->stream));
         h->p.obs = t + 1 < T ? h->exp.obs + (size_t)(t + 1) * N * 8 : home.obs;
         h->p.zone_obs = t + 1 < T ? h->exp.zone_obs + (size_t)(t + 1) * N * ZF : home.zone_obs;
         HIP_TRY(launch_step(h->p, h->p.actions, 1, no_policy(), h->stream));     // ParallelEnv.step: auto-reset
         if (h->goal_enabled) HIP_TRY(launch_goal_step(h->p, h->stream));
-        HIP_TRY(launch_exp_reward(h->exp, h->n_env, t, h->p.reward, h->goal_enabled ? h->p.shaped : nullptr,
-                                  h->p.done_out, h->stream));
         h->step_count += 1;
     }
+    HIP_TRY(launch_exp_reward(h->exp, h->n_env, T - 1, h->p.reward, h->goal_enabled ? h->p.shaped : nullptr,
+                              h->p.done_out, h->stream));
     // next_value = value(obs_T) (:177-187), then the GAE recursion
     HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
                                h->mlp_std, h->mlp_value, no_mlp_action(), h->stream));
