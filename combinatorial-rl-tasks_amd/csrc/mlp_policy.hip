@@ -752,7 +752,7 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
             reinterpret_cast<float2 *>(act.actions)[env] = a;
             const MlpRecord &rc = act.rec;
             if (rc.action) {
-                const size_t slot = (size_t)env * rc.T + rc.t;
+                const size_t slot = (size_t)rc.t * rc.N + env;      // time-major [T][N]
                 reinterpret_cast<float2 *>(rc.action)[slot] = a;
                 // Normal(mu, std).log_prob(a), per action dimension (base.py:160)
                 const float z0 = (a.x - m.x) / sd.x, z1 = (a.y - m.y) / sd.y;
@@ -764,7 +764,7 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
                     rc.mask[slot] = rc.cur_mask[env];            // self.masks[i] = self.mask (:149), BEFORE this step
                 } else {
                     rc.mask[slot] = rc.prev_done[env] ? 0.f : 1.f;                 // self.mask = 1 - done (:150)
-                    rc.reward[slot - 1] = rc.prev_shaped ? (float)rc.prev_shaped[env] : rc.prev_reward[env];
+                    rc.reward[slot - rc.N] = rc.prev_shaped ? (float)rc.prev_shaped[env] : rc.prev_reward[env];
                 }
             }
         }
@@ -772,11 +772,11 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
 }
 
 // ------------------------------------------------------------------------------------------ experiences
-// collect_experiences (main/src/torch_ac/algos/base.py:131-216) on the device.  The per-frame scalars are env-major
-// [N][T][...], the layout of exps.* there ("k-th block of T consecutive frames = k-th env", :125-128), written by
-// the head kernel's epilogue (MlpRecord); the observations are TIME-major [T][N][...]: the step kernel writes
-// obs_{t+1} / zone_obs_{t+1} straight into slot t+1 (zenv_collect points it there), so recording them costs no
-// copy -- the caller sees the transposed view.
+// collect_experiences (main/src/torch_ac/algos/base.py:131-216) on the device.  Every experience buffer is TIME-major
+// [T][N][...] in memory -- the head kernel's epilogue (MlpRecord) and the GAE scan then touch whole lines, and the
+// step kernel writes obs_{t+1} / zone_obs_{t+1} straight into slot t+1 (zenv_collect points it there), so recording
+// the observations costs no copy.  The caller sees the transposed [N][T][...] view, whose reshape(N*T, ...) is the
+// layout of exps.* in the reference ("k-th block of T consecutive frames = k-th env", :125-128).
 
 // after the LAST env step of a call: rewards[T-1] (shaped_reward when the env provides it, :153-159) and the new
 // self.mask (the earlier frames' rewards are recorded by the next frame's head kernel)
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void k_exp_reward(ExpBuffers x, int N, int t, 
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
-    x.reward[(size_t)env * x.T + t] = shaped ? (float)shaped[env] : reward[env];
+    x.reward[(size_t)t * N + env] = shaped ? (float)shaped[env] : reward[env];
     x.cur_mask[env] = done[env] ? 0.f : 1.f;            // self.mask = 1 - done (:150)
 }
 
@@ -795,16 +795,16 @@ __global__ __launch_bounds__(256) void k_exp_gae(ExpBuffers x, int N, const floa
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
-    const size_t base = (size_t)env * x.T;
     float nv = next_value[env], nm = x.cur_mask[env], na = 0.f;
     for (int i = x.T - 1; i >= 0; --i) {
-        const float v = x.value[base + i];
-        const float delta = x.reward[base + i] + discount * nv * nm - v;
+        const size_t at = (size_t)i * N + env;              // time-major: the threads of a wave read one line
+        const float v = x.value[at];
+        const float delta = x.reward[at] + discount * nv * nm - v;
         const float adv = delta + discount * gae_lambda * na * nm;
-        x.advantage[base + i] = adv;
-        x.returnn[base + i] = v + adv;
+        x.advantage[at] = adv;
+        x.returnn[at] = v + adv;
         nv = v;
-        nm = x.mask[base + i];
+        nm = x.mask[at];
         na = adv;
     }
 }

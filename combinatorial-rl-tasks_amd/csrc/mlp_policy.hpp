@@ -39,14 +39,14 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
 // reference's dist.sample() (utils/agent.py:41-44).
 // rec (zenv_collect only): the head kernel also writes frame t of the experience buffers -- action, per-dimension
 // log_prob, value, mask -- and the reward of frame t-1, which the step kernel left behind in the env's own
-// reward / done buffers (collect_experiences, base.py:146-160; env-major [N][T] arrays).
+// reward / done buffers (collect_experiences, base.py:146-160; time-major [T][N] arrays).
 struct MlpRecord {
     float *action, *log_prob, *value, *mask, *reward;   // null action: nothing is recorded
     const float *cur_mask;                               // mask of frame 0 (self.mask of the previous call)
     const float *prev_reward;                            // frame t-1 ...
     const double *prev_shaped;                           // ... or its shaped_reward (goal-conditioned envs), else null
     const uint8_t *prev_done;
-    int T, t;
+    int T, t, N;
 };
 struct MlpAction {
     int mode;
@@ -62,15 +62,15 @@ inline MlpAction no_mlp_action() { return MlpAction{ -1, 0u, 0ull, 0ull, nullptr
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
                               void *pooled, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s);
 
-// Experience buffers of one collect_experiences() call (base.py:131-216): scalars env-major [N][T][...],
-// observations time-major [T][N][...] (written in place by the step kernel)
+// Experience buffers of one collect_experiences() call (base.py:131-216), all time-major [T][N][...] (the
+// observations are written in place by the step kernel)
 struct ExpBuffers {
     int T;
     float *obs;        // [T][N][8]
     float *zone_obs;   // [T][N][Z*F]
-    float *action;     // [N][T][2]
-    float *log_prob;   // [N][T][2]
-    float *value, *reward, *mask, *advantage, *returnn;   // [N][T]
+    float *action;     // [T][N][2]
+    float *log_prob;   // [T][N][2]
+    float *value, *reward, *mask, *advantage, *returnn;   // [T][N]
     float *cur_mask;   // [N]  self.mask, carried from one call to the next
 };
 hipError_t launch_exp_reward(const ExpBuffers &x, int N, int t, const float *reward, const double *shaped,

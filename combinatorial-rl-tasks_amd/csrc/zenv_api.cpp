@@ -853,7 +853,7 @@ extern "C" int zenv_collect(zenv_t *h, int T, uint64_t policy_seed, uint64_t env
         // dist, value = acmodel(obs); action = dist.sample(); the head kernel also records frame t (and the reward
         // of frame t-1, still in the env's reward / done buffers)
         const MlpRecord rec{ h->exp.action, h->exp.log_prob, h->exp.value, h->exp.mask, h->exp.reward, h->exp.cur_mask,
-                             h->p.reward, h->goal_enabled ? h->p.shaped : nullptr, h->p.done_out, T, t };
+                             h->p.reward, h->goal_enabled ? h->p.shaped : nullptr, h->p.done_out, T, t, h->n_env };
         rc = run_policy(h, pol, &rec);
         if (rc) return rc;
         h->p.obs = t + 1 < T ? h->exp.obs + (size_t)(t + 1) * N * 8 : home.obs;

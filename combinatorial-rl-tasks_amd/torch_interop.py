@@ -71,8 +71,8 @@ class TorchZoneEnv:
 
     def collect(self, frames_per_proc, policy_seed=1, env_index0=0, discount=0.99, gae_lambda=0.95):
         """collect_experiences (torch_ac/algos/base.py:131-227) on the device; returns exps.* as float32 CUDA
-        tensors [N, T, ...] ALIASING the handle's experience buffers (overwritten by the next collect; obs and
-        zone_obs are transposed views of time-major memory, so ``reshape(N*T, ...)`` copies them once).  Enqueued
+        tensors [N, T, ...] ALIASING the handle's experience buffers (overwritten by the next collect;
+        transposed views of time-major memory, so ``reshape(N*T, ...)`` copies them once).  Enqueued
         on the shared stream like everything else: no synchronisation, no host copy."""
         self.env.collect_on_device(frames_per_proc, policy_seed, env_index0, discount, gae_lambda)
         out = {}

@@ -288,8 +288,8 @@ class ZoneVecEnv:
     def collect(self, frames_per_proc, policy_seed=1, env_index0=0, discount=0.99, gae_lambda=0.95):
         """BaseAlgo.collect_experiences (main/src/torch_ac/algos/base.py:131-227) on the device with the loaded
         actor-critic.  Returns a dict of env-major arrays [N, T, ...] -- reshape(N*T, ...) gives exps.* of the
-        reference (:211-227): obs, zone_obs, action, log_prob, value, reward, mask, advantage, returnn (obs and
-        zone_obs are transposed views of time-major buffers: reshape copies them once)."""
+        reference (:211-227): obs, zone_obs, action, log_prob, value, reward, mask, advantage, returnn (transposed
+        views of time-major buffers: reshape copies them once)."""
         T = int(frames_per_proc)
         self.collect_on_device(T, policy_seed, env_index0, discount, gae_lambda)
         out = {}
@@ -307,14 +307,14 @@ class ZoneVecEnv:
 
     def experience_layout(self, frames_per_proc):
         """name -> (field id, shape in memory, time_major) of the float32 buffers one collect of T frames per env
-        fills.  The observations are time-major [T, N, ...] in memory (the step kernel writes them in place);
-        ``collect`` hands out their [N, T, ...] view."""
+        fills.  Everything is time-major [T, N, ...] in memory (the step kernel writes the observations in place, the
+        head kernel and the GAE scan touch whole lines); ``collect`` hands out the [N, T, ...] views."""
         N, Z, F, T = self.num_envs, self.num_zones, self.zone_feat, int(frames_per_proc)
         return {"obs": (nat.F_EXP_OBS, (T, N, 8), True), "zone_obs": (nat.F_EXP_ZONE_OBS, (T, N, Z, F), True),
-                "action": (nat.F_EXP_ACTION, (N, T, 2), False), "log_prob": (nat.F_EXP_LOG_PROB, (N, T, 2), False),
-                "value": (nat.F_EXP_VALUE, (N, T), False), "reward": (nat.F_EXP_REWARD, (N, T), False),
-                "mask": (nat.F_EXP_MASK, (N, T), False), "advantage": (nat.F_EXP_ADVANTAGE, (N, T), False),
-                "returnn": (nat.F_EXP_RETURN, (N, T), False)}
+                "action": (nat.F_EXP_ACTION, (T, N, 2), True), "log_prob": (nat.F_EXP_LOG_PROB, (T, N, 2), True),
+                "value": (nat.F_EXP_VALUE, (T, N), True), "reward": (nat.F_EXP_REWARD, (T, N), True),
+                "mask": (nat.F_EXP_MASK, (T, N), True), "advantage": (nat.F_EXP_ADVANTAGE, (T, N), True),
+                "returnn": (nat.F_EXP_RETURN, (T, N), True)}
 
     def sync(self):
         check(lib().zenv_sync(self._h))

@@ -67,15 +67,16 @@ enum {
     ZENV_F_AVAILABLE_GOALS = 18, /* uint32  [N] get_available_goals() as a bit mask, bit z = zone z unvisited */
     ZENV_F_GOAL = 19,            /* int32   [N] goal zone, -1 = none */
     /* experience buffers of the last zenv_collect(), env-major: [N][T][...] (base.py:125-128, :211-227) */
-    ZENV_F_EXP_OBS = 20,         /* float32 [T,N,8]    time-major: written in place by the step kernel ... */
-    ZENV_F_EXP_ZONE_OBS = 21,    /* float32 [T,N,Z,F]  ... the other ZENV_F_EXP_* are env-major [N,T,...] */
-    ZENV_F_EXP_ACTION = 22,      /* float32 [N,T,2] */
-    ZENV_F_EXP_LOG_PROB = 23,    /* float32 [N,T,2]  Normal(mu, std).log_prob(action) */
-    ZENV_F_EXP_VALUE = 24,       /* float32 [N,T] */
-    ZENV_F_EXP_REWARD = 25,      /* float32 [N,T]    shaped_reward when the handle is goal-conditioned (:153-159) */
-    ZENV_F_EXP_MASK = 26,        /* float32 [N,T]    1 - done of the previous step (:149-150) */
-    ZENV_F_EXP_ADVANTAGE = 27,   /* float32 [N,T]    GAE (:190-196) */
-    ZENV_F_EXP_RETURN = 28,      /* float32 [N,T]    value + advantage (:226) */
+    ZENV_F_EXP_OBS = 20,         /* float32 [T,N,8]    every ZENV_F_EXP_* buffer is time-major (frame t of all envs is
+                                  *                    contiguous); the observations are written in place by the step kernel */
+    ZENV_F_EXP_ZONE_OBS = 21,    /* float32 [T,N,Z,F] */
+    ZENV_F_EXP_ACTION = 22,      /* float32 [T,N,2] */
+    ZENV_F_EXP_LOG_PROB = 23,    /* float32 [T,N,2]  Normal(mu, std).log_prob(action) */
+    ZENV_F_EXP_VALUE = 24,       /* float32 [T,N] */
+    ZENV_F_EXP_REWARD = 25,      /* float32 [T,N]    shaped_reward when the handle is goal-conditioned (:153-159) */
+    ZENV_F_EXP_MASK = 26,        /* float32 [T,N]    1 - done of the previous step (:149-150) */
+    ZENV_F_EXP_ADVANTAGE = 27,   /* float32 [T,N]    GAE (:190-196) */
+    ZENV_F_EXP_RETURN = 28,      /* float32 [T,N]    value + advantage (:226) */
     ZENV_F_ORDER_VAL = 29,       /* float32 [N,Z]    TSPOrderEnv's 7th row feature 0.5^(position in the route), 0 when visited */
     ZENV_F_COUNT = 13
 };
