@@ -66,7 +66,8 @@ enum {
     ZENV_F_NEED_GOAL = 17,       /* uint8   [N] info['need_next_goal'] / env.goal_zone is None (:69-75) */
     ZENV_F_AVAILABLE_GOALS = 18, /* uint32  [N] get_available_goals() as a bit mask, bit z = zone z unvisited */
     ZENV_F_GOAL = 19,            /* int32   [N] goal zone, -1 = none */
-    /* experience buffers of the last zenv_collect(), env-major: [N][T][...] (base.py:125-128, :211-227) */
+    /* experience buffers of the last zenv_collect(), time-major [T][N][...]; their [N][T] transposes, flattened, are
+     * exps.* of base.py:125-128, :211-227 */
     ZENV_F_EXP_OBS = 20,         /* float32 [T,N,8]    every ZENV_F_EXP_* buffer is time-major (frame t of all envs is
                                   *                    contiguous); the observations are written in place by the step kernel */
     ZENV_F_EXP_ZONE_OBS = 21,    /* float32 [T,N,Z,F] */
