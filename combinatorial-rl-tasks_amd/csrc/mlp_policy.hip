@@ -411,7 +411,7 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int nn = (n + 1) % NT;
-        // the next chain's fragments first: they have this whole region to arrive
+        // the next chain's fragments (placed in the region's late MFMA gaps by the group barriers below)
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
 #if defined(MLP_EXP) && (MLP_EXP & 4)      // diagnostic: one fragment read per chain instead of twelve
@@ -419,7 +419,7 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
 #else
             wf[(n + 1) & 1][kk] = as_frag(w2s[(nn * KS + kk) * kWave + lane]);
 #endif
-        __builtin_amdgcn_sched_barrier(0);
+
         const f32x16 prev = acc[(n + 1) & 1];                   // the chain before this one (n = 0: pend)
         acc[n & 1] = zero16();
 #pragma unroll
@@ -456,6 +456,13 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
 #pragma unroll
         for (int gsl = 0; gsl < MLP_GAPS; ++gsl) {
             __builtin_amdgcn_sched_group_barrier(0x002, MLP_PER_GAP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        // ... and the next chain's twelve fragment reads two per gap behind them (as a block at the head of the
+        // region they cost 48 issue cycles with no MFMA going out: -2.3 us per forward)
+#pragma unroll
+        for (int gsl = 0; gsl < 6; ++gsl) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
 #endif
