@@ -386,6 +386,10 @@ constexpr int kZone1Waves = 4;
 #define MLP_GAPS 6          // MFMA gaps that carry VALU work in a region ...
 #define MLP_PER_GAP 6       // ... and instructions per gap (32 per region: 16 + 16 conversions)
 #endif
+#ifndef MLP_RGAPS
+#define MLP_RGAPS 6         // MFMA gaps behind those that carry the next chain's fragment reads ...
+#define MLP_R_PER_GAP 2     // ... and reads per gap (12 per region)
+#endif
 
 // One 32-row tile: layer-2 chains on xa, pooling into pool[], and layer 1 of the NEXT tile (operand x0n) into
 // xb; x0nn is the operand of the tile after that.  pend = the previous tile's last chain, still to be converted and pooled; wf0 = fragments of output
@@ -461,8 +465,8 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
         // ... and the next chain's twelve fragment reads two per gap behind them (as a block at the head of the
         // region they cost 48 issue cycles with no MFMA going out: -2.3 us per forward)
 #pragma unroll
-        for (int gsl = 0; gsl < 6; ++gsl) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        for (int gsl = 0; gsl < MLP_RGAPS; ++gsl) {
+            __builtin_amdgcn_sched_group_barrier(0x100, MLP_R_PER_GAP, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
 #endif
