@@ -662,6 +662,28 @@ __device__ __forceinline__ void stage_fence()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// One hidden layer of the head: xout = [relu] (W xin [+ W_obs xo]), W's fragments staged in `buf` (NK k-steps per
+// output tile, the last one the obs part when NK > KS).  The conversion of output tile m-1 is issued between the
+// MFMAs of tile m (it used to be one block of 96 VALU instructions behind all six chains, with the matrix pipe idle
+// and all six accumulators live); xin and xout are different registers.
+template <int NK, bool RELU>
+__device__ __forceinline__ void head_layer(const uint4 *buf, int lane, const bf16x8 (&xin)[KS], const bf16x8 xo,
+                                           bf16x8 (&xout)[KS])
+{
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m <= NT; ++m) {
+        if (m < NT) {
+            acc[m & 1] = zero16();
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) acc[m & 1] = mfma(as_frag(buf[(m * NK + kk) * kWave + lane]), xin[kk], acc[m & 1]);
+            if (NK > KS) acc[m & 1] = mfma(as_frag(buf[(m * NK + KS) * kWave + lane]), xo, acc[m & 1]);
+        }
+        if (m > 0) acc_to_frags(acc[(m - 1) & 1], RELU, xout[2 * (m - 1)], xout[2 * (m - 1) + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 __global__ __launch_bounds__(kHeadWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf16 *__restrict__ pooled,
                 float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value, MlpAction act)
@@ -678,81 +700,46 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
     float value_out = 0.f;
 
     stage_issue(bufA, img.w3, NT * KS);
-    bf16x8 x[KS], xo;
+    bf16x8 xa[KS], xb[KS], xo;              // the activations ping-pong between xa and xb
     {
         // the mean is stored in bf16, 8 consecutive features = one fragment
         const uint4 *pr = reinterpret_cast<const uint4 *>(pooled + (size_t)env * HP + 8 * h);
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) x[kk] = as_frag(pr[2 * kk]);
+        for (int kk = 0; kk < KS; ++kk) xa[kk] = as_frag(pr[2 * kk]);
         const float4 *o = reinterpret_cast<const float4 *>(obs + (size_t)env * 8);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         xo = h == 0 ? frag_from_floats(o[0], o[1]) : frag_from_floats(z4, z4);
     }
-    f32x16 acc[NT];
-    // ---- e3 = W3 mean(H2)   (zone_net_.4 after the mean; no activation)
+    // ---- e3 = W3 mean(H2)   (zone_net_.4 after the mean; no activation)                       xa -> xb
     stage_fence();
     stage_issue(bufB, img.wc, NT * (KS + 1));
-#pragma unroll
-    for (int m = 0; m < NT; ++m) {
-        acc[m] = zero16();
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(bufA[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], false, x[2 * m], x[2 * m + 1]);
-    // ---- c = Wc [e3; obs]   (combine_net_; no activation)
+    head_layer<KS, false>(bufA, lane, xa, xo, xb);
+    // ---- c = Wc [e3; obs]   (combine_net_; no activation)                                      xb -> xa
     stage_fence();
     stage_issue(bufA, critic ? img.wv1 : img.wa, NT * KS);
-#pragma unroll
-    for (int m = 0; m < NT; ++m) {
-        acc[m] = zero16();
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(bufB[(m * (KS + 1) + kk) * kWave + lane]), x[kk], acc[m]);
-        acc[m] = mfma(as_frag(bufB[(m * (KS + 1) + KS) * kWave + lane]), xo, acc[m]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], false, x[2 * m], x[2 * m + 1]);
-    // ---- value = Wv2 relu(Wv1 c)   (critic, flat_model.py:43-47), from the same embedding c
+    head_layer<KS + 1, false>(bufB, lane, xb, xo, xa);
+    // ---- value = Wv2 relu(Wv1 c)   (critic, flat_model.py:43-47), from the same embedding c     xa -> xb
     if (critic) {
         stage_fence();
         stage_issue(bufB, img.wv2, KS);
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-            acc[m] = zero16();
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(bufA[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        bf16x8 xv[KS];
-#pragma unroll
-        for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], true, xv[2 * m], xv[2 * m + 1]);
+        head_layer<KS, true>(bufA, lane, xa, xo, xb);
         stage_fence();
         stage_issue(bufA, img.wa, NT * KS);
         f32x16 hv = zero16();
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) hv = mfma(as_frag(bufB[kk * kWave + lane]), xv[kk], hv);
+        for (int kk = 0; kk < KS; ++kk) hv = mfma(as_frag(bufB[kk * kWave + lane]), xb[kk], hv);
         value_out = hv[0];
         if (h == 0 && valid) value[env] = value_out;
     }
-    // ---- a = relu(Wa c)   (actor.enc_)
+    // ---- a = relu(Wa c)   (actor.enc_)                                                          xa -> xb
     stage_fence();
     stage_issue(bufB, img.wh, KS);
-#pragma unroll
-    for (int m = 0; m < NT; ++m) {
-        acc[m] = zero16();
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc[m] = mfma(as_frag(bufA[(m * KS + kk) * kWave + lane]), x[kk], acc[m]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int m = 0; m < NT; ++m) acc_to_frags(acc[m], true, x[2 * m], x[2 * m + 1]);
+    head_layer<KS, true>(bufA, lane, xa, xo, xb);
     // ---- heads: rows 0-1 = mu_, rows 2-3 = std_ (lane half 0, registers 0..3)
     stage_fence();
     f32x16 hd = zero16();
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) hd = mfma(as_frag(bufB[kk * kWave + lane]), x[kk], hd);
+    for (int kk = 0; kk < KS; ++kk) hd = mfma(as_frag(bufB[kk * kWave + lane]), xb[kk], hd);
     if (h == 0 && valid) {
         const float2 m = make_float2(2.0f * (sigmoidf_(hd[0]) - 0.5f), 2.0f * (sigmoidf_(hd[1]) - 0.5f));
         const float2 sd = make_float2(sigmoidf_(hd[2]) + 1e-3f, sigmoidf_(hd[3]) + 1e-3f);
