@@ -32,6 +32,10 @@ namespace {
 constexpr int kWave = 64;
 
 // Diagnostic build only (-DZENV_STAMPS, never shipped): lane 0 of each wave drops
+#ifndef ZENV_SUBSTEP_UNROLL
+#define ZENV_SUBSTEP_UNROLL 10      // = the reference's frameskip (Engine frameskip_binom_n, p = 1.0)
+#endif
+
 // s_memrealtime (100 MHz) stamps into p.dbg[block][16] at phase boundaries.
 #ifdef ZENV_STAMPS
 #define ZSTAMP(slot)                                                                                  \
@@ -1083,6 +1087,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             const double c0 = det_clamp((double)act.x, -1.0, 1.0);
             const double c1 = det_clamp((double)act.y, -1.0, 1.0);
             ZSTAMP(9);
+#pragma unroll ZENV_SUBSTEP_UNROLL
             for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
             emit_obs8(p, e, o);   // o[0] (remaining) is patched after the rendezvous
         }
@@ -1612,6 +1617,9 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 const double c0 = det_clamp((double)act.x, -1.0, 1.0);
                 const double c1 = det_clamp((double)act.y, -1.0, 1.0);
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 2)   // diagnostic: bit 1 drops the physics
+                // unrolled by the default frameskip (a remainder loop covers other values): the rolled loop carried
+                // its state through 8 v_mov_b64 per substep (-3...5 % of the step time)
+#pragma unroll ZENV_SUBSTEP_UNROLL
                 for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
 #endif
                 if (t == (n_steps >> 1)) ZSTAMP(2);
