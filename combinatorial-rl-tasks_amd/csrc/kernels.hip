@@ -1327,6 +1327,10 @@ __device__ __forceinline__ float2 greedy_action_regs(const float4 *zp, const int
         if (cg > best_cnt) { target_colour = 1; best_cnt = cg; }
         if (cr > best_cnt) { target_colour = 2; }
     }
+    // 3.0 from a register: as a literal it only fits v_fmac_f64, whose accumulator has to be loaded with -px by a
+    // v_mov_b64 first -- two instructions per coordinate instead of one v_fma_f64
+    double three = 3.0;
+    asm("" : "+v"(three));
     // two halves of the zone list, one after the other: halves the live distance array
     double mbest = 0.0;
     float bx = 0.f, by = 0.f;
@@ -1346,7 +1350,7 @@ __device__ __forceinline__ float2 greedy_action_regs(const float4 *zp, const int
             if (TASK == ZENV_TASK_COLOUR_MATCH)
                 eligible = auxr[z] == 0 && (int)((colpack >> (2 * z)) & 3ull) != target_colour;
             else eligible = ((vis >> z) & 1u) == 0u;
-            const double dx = __builtin_fma(3.0, (double)x3, -px), dy = __builtin_fma(3.0, (double)y3, -py);
+            const double dx = __builtin_fma(three, (double)x3, -px), dy = __builtin_fma(three, (double)y3, -py);
             const double d2 = __builtin_fma(dx, dx, dy * dy);
             d2s[i] = __hiloint2double(eligible ? __double2hiint(d2) : 0x7FE00000, __double2loint(d2));
         }
