@@ -67,17 +67,56 @@ def algorithmic_bytes(task, Z, steps_per_launch=1):
     return outputs + (reads + state_out) / steps_per_launch
 
 
-def load_traffic(workload, n_env, mode="per_step"):
-    """Measured HBM bytes per kernel launch from the committed rocprofv3 PMC passes."""
+def load_pmc(workload, n_env, mode):
+    """The committed rocprofv3 PMC record of this workload's dominant kernel (profiles/traffic.json, written by
+    scripts/summarize_profile.py from separate --pmc passes): HBM bytes as `fixed per launch + per step` (FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is) and the VALU-issue counters."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        key = f"{workload}@{n_env}" + ("" if mode != "persistent" else "@persistent")
-        ent = t.get(key)
-        return None if ent is None else ent["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
+        return t.get(f"{workload}@{n_env}", {}).get("persistent" if mode == "persistent" else "per_step")
+    except (OSError, ValueError):
         return None
+
+
+def traffic_for_launch(pmc, steps_per_launch):
+    """PMC HBM bytes of ONE launch of `steps_per_launch` steps (None when no PMC record is committed)."""
+    if not pmc or "hbm_bytes_per_step" not in pmc:
+        return None
+    return int(round(pmc.get("hbm_bytes_fixed_per_launch", 0.0) + pmc["hbm_bytes_per_step"] * steps_per_launch))
+
+
+def valu_issue(pmc, us_per_step):
+    """How busy the SIMDs' vector issue is (the bound of the small-row workloads, where HBM bytes are not):
+    VALU instructions per SIMD and step (committed PMC, a property of the binary and the workload) x 4 issue cycles
+    (a float64 or a lone wave's float32 instruction holds the SIMD-32's issue for 4 cycles, MI355X_MICROARCH.md
+    cycle-constants table) / the cycles a step takes.  Both the PMC pass's own cycle count and -- with the live
+    time per step at the committed clock -- the live figure are given."""
+    if not pmc or "valu_insts_per_simd_step" not in pmc:
+        return None
+    insts, cyc = pmc["valu_insts_per_simd_step"], pmc.get("gpu_cycles_per_step")
+    out = {"valu_insts_per_simd_step": round(insts, 1), "issue_cycles_per_inst": 4,
+           "pmc_gpu_cycles_per_step": None if cyc is None else round(cyc, 1),
+           "frac_pmc": None if not cyc else round(4.0 * insts / cyc, 4),
+           "salu_insts_per_simd_step": pmc.get("salu_insts_per_simd_step"),
+           "source": pmc.get("source")}
+    clk = pmc.get("gpu_clock_ghz")
+    if clk and us_per_step:
+        out["frac_live"] = round(4.0 * insts / (us_per_step * 1e3 * clk), 4)
+        out["clock_ghz_assumed"] = clk
+    return out
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -99,6 +138,8 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="run the stand-alone policy kernel before every step instead of the fused action source")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-steady", action="store_true",
+                    help="skip the 8192-step steady-state side measurement of the same kernel (aux.steady_state)")
     ap.add_argument("--no-mlp", action="store_true",
                     help="skip the side measurement with the reference's actor network as the on-device policy")
     ap.add_argument("--event-stride", type=int, default=16,
@@ -114,6 +155,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Build (or find up to date) the native library BEFORE this process touches the GPU or the process group: a
+    # compiler child must never be forked from a GPU-initialised process.  Every rank calls it; build_library()
+    # serialises concurrent callers with a file lock and is a no-op when lib/ is newer than csrc/.
+    import __graft_entry__ as entry
+    entry.build()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -124,11 +170,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    import __graft_entry__ as entry
-    if rank == 0:
-        entry.build()
-    if distributed:
-        dist.barrier()
     import combinatorial_rl_tasks_amd as Z
     from combinatorial_rl_tasks_amd import sharding
 
@@ -185,35 +226,43 @@ def main():
         value = total_env_steps / elapsed
         persistent = args.mode == "persistent" and zones in (5, 6, 10, 15, 20, 25)
         chunk = min(Z._native.ROLLOUT_CHUNK, max(args.steps, 1)) if persistent else 1
-        alg = algorithmic_bytes(task, zones, chunk)
+        n_launches = (args.steps + chunk - 1) // chunk if persistent else args.steps
+        pmc = load_pmc(args.workload, n_env, "persistent" if persistent else "per_step")
         roofline = None
         if args.steps > 0 and (ms_kernel is not None or not args.unfused):
-            # persistent / per_step: the timed region is back-to-back dispatches of ONE kernel, so the
-            # HIP events that bracket the loop on the kernel's stream give its duration per step (an
-            # upper bound of the dispatch duration: it includes the ~0.5 us gaps between launches).
-            # The begin/end events of the dispatches themselves are reported beside it: persistent --
-            # every launch (ROLLOUT_CHUNK steps each), summed / steps; per_step -- every
-            # event_stride-th launch.
-            k_avg_s = ms_total / 1e3 / args.steps if not args.unfused else ms_kernel / 1e3
-            achieved = alg * n_env / k_avg_s / 1e9
-            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": load_traffic(args.workload, n_env, args.mode),
-                        "kernel": "k_rollout_lane" if persistent else "k_step_lane",
-                        "kernel_avg_us": round(k_avg_s * 1e6 * (chunk if persistent else 1), 2),
-                        "steps_per_launch": chunk if persistent else 1,
-                        "kernel_us_per_step": round(k_avg_s * 1e6, 3),
-                        "kernel_launches_timed": (args.steps + chunk - 1) // chunk if persistent else
-                        args.steps if not args.unfused else
-                        (args.steps + args.event_stride - 1) // args.event_stride,
-                        "sampled_dispatch_avg_us": None if ms_kernel is None else round(ms_kernel * 1e3, 2),
-                        "algorithmic_bytes_per_env_step": round(alg, 1),
-                        "algorithmic_bytes_per_step_launch": algorithmic_bytes(task, zones, 1),
-                        "env_steps_per_launch": n_env * chunk}
+            # Duration of the dominant kernel per step, from HIP events on the kernel's stream over the timed
+            # region.  persistent: EVERY launch of the region carries begin/end events of the dispatch itself
+            # (hipExtLaunchKernel), summed / steps -- what rocprofv3's kernel trace reports for the same
+            # dispatches.  per_step: the events that bracket the back-to-back loop / steps (an upper bound: it
+            # includes the ~0.5 us gaps between launches; timing every dispatch would slow the loop), with the
+            # begin/end events of every event_stride-th dispatch beside it.
+            loop_s = ms_total / 1e3 / args.steps
+            if persistent and ms_kernel is not None:
+                k_step_s = ms_kernel / 1e3
+            elif args.unfused:
+                k_step_s = ms_kernel / 1e3
+            else:
+                k_step_s = loop_s
+            roofline = roofline_block(task, zones, n_env, k_step_s, chunk if persistent else 1, persistent, pmc)
+            roofline.update({
+                "kernel_launches_timed": n_launches if not args.unfused else
+                (args.steps + args.event_stride - 1) // args.event_stride,
+                "timing": ("begin/end HIP events of every dispatch of the timed region" if persistent and
+                           ms_kernel is not None else "HIP events around the back-to-back launch loop / steps"),
+                "loop_us_per_step": round(loop_s * 1e6, 3),
+                "sampled_dispatch_avg_us": None if ms_kernel is None else round(ms_kernel * 1e3, 3),
+            })
+        # side measurements, GPU ones first and back to back (each settles the clock itself); the CPU baseline last
+        ep = env.get(Z.F_EPISODES)
+        spot = parity_spot_check(env, cfg, shard, args, policy)
+        steady = None if (args.no_steady or args.override) else \
+            steady_state(env, task, zones, policy, shard, args.mode, pmc)
+        per_step = per_step_rate(env, task, zones, policy, shard, args.workload) \
+            if (args.mode == "persistent" and not distributed) else None
+        mlp = None if (args.no_mlp or distributed) else mlp_policy_rate(env, zones)
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is an N = 1 figure (rank 0 only)
             cpu = cpu_baseline(cfg, task, zones, keepout, policy)
-        ep = env.get(Z.F_EPISODES)
         out = {
             "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -228,14 +277,14 @@ def main():
                        "parallelism": f"env-shard x{world}, all-gather(ep_return) after rollout"},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "aux": {"settle_steps_untimed": args.settle, "hip_event_ms_total": round(ms_total, 3), "bank_build_s": round(t_bank, 2),
+            "aux": {"collective": ("nccl all_gather_into_tensor" if distributed and dist.get_backend() == "nccl"
+                                   else "none (single process)" if not distributed else dist.get_backend()),
+                    "settle_steps_untimed": args.settle, "hip_event_ms_total": round(ms_total, 3), "bank_build_s": round(t_bank, 2),
                     "episodes_finished_rank0": int(ep.sum()),
                     "mean_last_return_all_ranks": float(np.mean(returns[returns != 0]))
                     if (returns != 0).any() else 0.0,
-                    "parity_spot_check": parity_spot_check(env, cfg, shard, args, policy),
-                    "per_step_launch_mode": per_step_rate(env, task, zones, policy, shard)
-                    if (args.mode == "persistent" and not distributed) else None,
-                    "mlp_policy": None if (args.no_mlp or distributed) else mlp_policy_rate(env, zones)},
+                    "parity_spot_check": spot, "steady_state": steady, "per_step_launch_mode": per_step,
+                    "mlp_policy": mlp},
         }
         print(json.dumps(out), flush=True)
     env.close()
@@ -243,6 +292,68 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def roofline_block(task, zones, n_env, k_step_s, steps_per_launch, persistent, pmc):
+    """`roofline` of the bench line for a kernel that takes k_step_s per step in launches of steps_per_launch.
+
+    Two byte bases, both algorithmic: `outputs_only` -- what a launch of K steps must move when the
+    state stays in registers: K x the step's outputs + the state once (for K = 1 this IS the second base) --
+    and SURVEY.md 8(d)'s per-step figure, which charges the state round trip to every step.  `achieved`/`frac`
+    use the first, the one that describes the kernel measured; for the persistent kernel the second is given
+    for reference only (it exceeds 1: the kernel does not do that traffic, by design)."""
+    alg = algorithmic_bytes(task, zones, steps_per_launch)
+    alg1 = algorithmic_bytes(task, zones, 1)
+    achieved = alg * n_env / k_step_s / 1e9
+    achieved1 = alg1 * n_env / k_step_s / 1e9
+    traffic = traffic_for_launch(pmc, steps_per_launch)
+    return {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "traffic_note": (None if traffic is None else
+                         f"committed PMC bytes (FETCH_SIZE x2 + WRITE_SIZE) scaled to this launch of "
+                         f"{steps_per_launch} step(s); {pmc.get('source')}"),
+        "kernel": "k_rollout_lane" if persistent else "k_step_lane",
+        "kernel_avg_us": round(k_step_s * 1e6 * steps_per_launch, 2),
+        "steps_per_launch": steps_per_launch,
+        "kernel_us_per_step": round(k_step_s * 1e6, 3),
+        "env_steps_per_launch": n_env * steps_per_launch,
+        "algorithmic_bytes_per_env_step": round(alg, 1),
+        "algorithmic_bytes_per_launch": int(round(alg * n_env * steps_per_launch)),
+        "byte_bases": {
+            "outputs_only": {"bytes_per_env_step": round(alg, 1), "achieved": round(achieved, 1),
+                             "frac": round(achieved / HBM_PEAK_GBS, 4),
+                             "what": "outputs of every step + state in/out once per launch"},
+            "survey_8d": {"bytes_per_env_step": alg1, "achieved": round(achieved1, 1),
+                          "frac": round(achieved1 / HBM_PEAK_GBS, 4),
+                          "what": "state in + state out + outputs on EVERY step (one launch per step)",
+                          "applies": steps_per_launch == 1},
+        },
+        "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4),   # 6.29 TB/s float4 copy, MI355X_MICROARCH.md
+        "valu_issue": valu_issue(pmc, k_step_s * 1e6),
+    }
+
+
+def steady_state(env, task, zones, policy, shard, mode, pmc, steps=8192):
+    """Side measurement (never `value`): the SAME kernel, same envs, right after the timed region, over enough
+    steps that launch overheads and the clock transient are out of the picture -- every dispatch timed with its
+    own begin/end HIP events.  This is the figure to compare rounds by."""
+    try:
+        persistent = mode == "persistent" and zones in (5, 6, 10, 15, 20, 25)
+        env.rollout(SETTLE_STEPS, policy, policy_seed=0x5EED, env_index0=shard.env_index0, mode=mode)   # untimed
+        ms, ms_k = env.rollout(steps, policy, policy_seed=0x5EED, env_index0=shard.env_index0, mode=mode,
+                               time_step_kernel=persistent)
+        import combinatorial_rl_tasks_amd as Z
+        chunk = Z._native.ROLLOUT_CHUNK if persistent else 1
+        k_step_s = (ms_k if persistent else ms / steps) / 1e3
+        blk = roofline_block(task, zones, env.num_envs, k_step_s, chunk, persistent, pmc)
+        blk.update({"steps": steps, "launches": (steps + chunk - 1) // chunk,
+                    "env_steps_per_s": round(env.num_envs * steps / (ms * 1e-3), 1),
+                    "loop_us_per_step": round(ms / steps * 1e3, 3)})
+        return blk
+    except Exception as ex:  # the bench line must still print
+        return f"error: {ex}"
 
 
 def usable_cores():
@@ -276,6 +387,7 @@ def cpu_baseline(cfg, task, zones, keepout, policy):
     r1 = O.rollout(ocfg, seeds[:1024], 1000, policy, seed_stride=65536, policy_seed=0x5EED, n_threads=1)
     dt1 = time.perf_counter() - t1
     return {"value": round(r["total_steps"] / dt, 1), "unit": "env-steps/s", "cores": cores,
+            "cpu_model": cpu_model(), "nproc": os.cpu_count(),
             "kind": "port",
             "sample": f"first {n} envs x {T} steps of the same workload, OpenMP over envs, "
                       f"{dt:.2f}s wall",
@@ -283,17 +395,18 @@ def cpu_baseline(cfg, task, zones, keepout, policy):
             "one_core_sample": f"1024 envs x 1000 steps on 1 thread, {dt1:.2f}s wall"}
 
 
-def per_step_rate(env, task, zones, policy, shard, steps=2000):
+def per_step_rate(env, task, zones, policy, shard, workload, steps=2000):
     """Side measurement (never `value`): the same envs with ONE kernel launch per step (k_step_lane, the
     path an externally supplied action takes), right after the timed region, clocks still settled."""
     try:
-        env.rollout(200, policy, policy_seed=0x5EED, env_index0=shard.env_index0, mode="per_step")
+        env.rollout(2000, policy, policy_seed=0x5EED, env_index0=shard.env_index0, mode="per_step")
         ms, _ = env.rollout(steps, policy, policy_seed=0x5EED, env_index0=shard.env_index0, mode="per_step")
-        us = ms / steps * 1e3
-        alg = algorithmic_bytes(task, zones, 1)
-        return {"us_per_step": round(us, 2), "env_steps_per_s": round(env.num_envs * steps / (ms * 1e-3), 1),
-                "kernel": "k_step_lane", "algorithmic_bytes_per_env_step": alg,
-                "frac_of_hbm_peak": round(alg * env.num_envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        blk = roofline_block(task, zones, env.num_envs, ms / steps / 1e3, 1, False,
+                             load_pmc(workload, env.num_envs, "per_step"))
+        blk.update({"us_per_step": round(ms / steps * 1e3, 2), "steps": steps,
+                    "env_steps_per_s": round(env.num_envs * steps / (ms * 1e-3), 1),
+                    "frac_of_hbm_peak": blk["frac"]})
+        return blk
     except Exception as ex:  # the bench line must still print
         return f"error: {ex}"
 

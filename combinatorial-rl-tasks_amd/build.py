@@ -29,17 +29,50 @@ def _deps():
     return out
 
 
+def _up_to_date():
+    return os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in _deps())
+
+
+def under_profiler():
+    """True inside a rocprofv3 / rocprof run: the profiler's preloaded tool library initialises the GPU in every
+    process it is injected into, compiler children included, and hipcc's sh -> clang exec hops are then execs
+    from a GPU-initialised process -- not allowed on the GPU pool.  Build BEFORE starting the profiler."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    if "rocprof" in pre or "rocprofiler" in pre:
+        return True
+    return any(k.startswith(("ROCPROF", "ROCPROFILER_", "ROCP_TOOL", "ROCP_")) for k in os.environ)
+
+
 def build_library(force=False, verbose=False):
-    """Compile every HIP/C++ source into lib/libzenv_hip.so; returns its path."""
-    if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in _deps()):
-            return LIB_PATH
+    """Compile every HIP/C++ source into lib/libzenv_hip.so; returns its path.  A no-op when the library is newer
+    than every source.  Concurrent callers (the ranks of a torchrun job) are serialised by a file lock, and the
+    library appears atomically (compiled beside, then renamed)."""
+    if not force and _up_to_date():
+        return LIB_PATH
+    if under_profiler():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing or older than csrc/ and this process runs under a ROCm profiler: build first "
+            "(`python -c 'import __graft_entry__ as g; g.build()'`), then start rocprofv3")
+    import fcntl
     os.makedirs(LIB_DIR, exist_ok=True)
-    extra = os.environ.get("ZENV_EXTRA_FLAGS", "").split()      # experiments only (e.g. -DZENV_STORE_AUX=16)
-    cmd = [_hipcc()] + FLAGS + extra + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _up_to_date():          # another rank built it while we waited
+                return LIB_PATH
+            extra = os.environ.get("ZENV_EXTRA_FLAGS", "").split()   # experiments only (e.g. -DZENV_STORE_AUX=16)
+            tmp = LIB_PATH + f".tmp{os.getpid()}"
+            cmd = [_hipcc()] + FLAGS + extra + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, LIB_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

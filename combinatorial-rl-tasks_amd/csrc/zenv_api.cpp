@@ -65,6 +65,14 @@ struct zenv {
     bool sched_ready = false;
     bool was_reset = false;
     int64_t step_count = 0;
+    // What the internal action buffer holds when a fused rollout left a_{step_count} behind: the next rollout with
+    // the same action source continues from it instead of launching the policy kernel again.
+    struct {
+        bool valid = false;
+        int policy = -1;
+        uint64_t seed = 0, index0 = 0;
+        int64_t step = -1;
+    } act_tag;
     std::vector<hipEvent_t> events;
     // actor network (zenv_mlp_load)
     void *mlp_mem = nullptr;
@@ -618,6 +626,7 @@ extern "C" int zenv_reset(zenv_t *h, const uint8_t *mask)
         HIP_TRY(hipMemcpyAsync(h->d_mask, mask, h->n_env, hipMemcpyHostToDevice, h->stream));
         dmask = h->d_mask;
     }
+    h->act_tag.valid = false;
     HIP_TRY(launch_reset(h->p, dmask, h->stream));
     if (h->goal_enabled) HIP_TRY(launch_goal_clear(h->p, dmask, h->stream));
     if (h->order_enabled) HIP_TRY(launch_order_reset(h->p, dmask, h->stream));
@@ -631,6 +640,7 @@ extern "C" int zenv_step(zenv_t *h, const float *actions, int actions_on_device,
     if (!h->was_reset) return fail(ZENV_E_STATE, "Environment must be reset before stepping");
     int rc = use_device(h);
     if (rc) return rc;
+    h->act_tag.valid = false;
     const float *d_act = h->p.actions;
     if (actions) {
         if (actions_on_device) {
@@ -809,6 +819,7 @@ extern "C" int zenv_collect(zenv_t *h, int T, uint64_t policy_seed, uint64_t env
     int rc = use_device(h);
     if (rc) return rc;
     const size_t N = (size_t)h->n_env, ZF = (size_t)h->p.Z * h->p.F;
+    h->act_tag.valid = false;
     if (!h->exp_mem || h->exp.T != T) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         std::vector<float> keep_mask;
@@ -881,6 +892,7 @@ extern "C" int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t
     if (rc) return rc;
     const StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0,
                           dst_device ? dst_device : h->p.actions };
+    h->act_tag.valid = false;
     return run_policy(h, pol);
 }
 
@@ -915,10 +927,14 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
         HIP_TRY(hipEventCreate(&ev));
         h->events.push_back(ev);
     }
+    // a_0 is already in the action buffer when the previous fused rollout of the same action source ended here
+    const bool have_a0 = fused && h->act_tag.valid && h->act_tag.policy == policy && h->act_tag.seed == policy_seed &&
+                         h->act_tag.index0 == env_index0 && h->act_tag.step == h->step_count;
+    h->act_tag.valid = false;
     HIP_TRY(hipEventRecord(h->events[0], h->stream));
     if (persistent && steps > 0) {
         StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };
-        HIP_TRY(launch_policy(h->p, pol, h->stream));   // a_0; every launch leaves the next action behind
+        if (!have_a0) HIP_TRY(launch_policy(h->p, pol, h->stream));   // a_0; every launch leaves the next action behind
         for (int t = 0, c = 0; t < steps; t += kRolloutChunk, ++c) {
             const int k = std::min(kRolloutChunk, steps - t);
             pol.step_index = (uint32_t)(h->step_count + 1);
@@ -932,7 +948,7 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
         StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };
         // a_t = pi(obs_t, t): one stand-alone policy launch per step (unfused) or only before
         // the first step (fused: every step kernel then leaves a_{t+1} in the action buffer)
-        if (!fused || t == 0) {
+        if (!fused || (t == 0 && !have_a0)) {
             rc = run_policy(h, pol);
             if (rc) return rc;
         }
@@ -948,6 +964,13 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
         h->step_count += 1;
     }
     HIP_TRY(hipEventRecord(h->events[1], h->stream));
+    if (fused && (steps > 0 || have_a0)) {
+        h->act_tag.valid = true;
+        h->act_tag.policy = policy;
+        h->act_tag.seed = policy_seed;
+        h->act_tag.index0 = env_index0;
+        h->act_tag.step = h->step_count;
+    }
     HIP_TRY(hipEventSynchronize(h->events[1]));
     if (ms_total) HIP_TRY(hipEventElapsedTime(ms_total, h->events[0], h->events[1]));
     if (per_kernel) {
@@ -1092,6 +1115,7 @@ extern "C" int zenv_set_state(zenv_t *h, const void *src, int64_t bytes)
     }
     h->step_count = head[0];
     h->was_reset = ((head[1] >> 8) & 1) != 0;
+    h->act_tag.valid = false;
     return ZENV_OK;
 }
 

@@ -30,15 +30,21 @@ def build(force=False):
             and os.path.getmtime(_SO) >= max(os.path.getmtime(_SRC), os.path.getmtime(_HDR))):
         return _SO
     os.makedirs(_OUT_DIR, exist_ok=True)
+    tmp = _SO + f".tmp{os.getpid()}"       # concurrent builders (ranks of one job) each rename a complete file in
     cmd = ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC", "-shared",
-           "-Wall", "-Wextra", "-o", _SO, _SRC, "-lm"]
+           "-Wall", "-Wextra", "-o", tmp, _SRC, "-lm"]
     try:
         with open("/proc/cpuinfo") as f:
             if " fma " in f.read().replace("\n", " "):
                 cmd.insert(1, "-mfma")
     except OSError:
         pass
-    subprocess.run(cmd, check=True)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, _SO)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return _SO
 
 

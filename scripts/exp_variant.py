@@ -3,6 +3,9 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import combinatorial_rl_tasks_amd.build as B
+if B.under_profiler() and os.environ.get("EXP_SHIPPED") != "1":
+    raise SystemExit("this script compiles a variant library: run it without rocprofv3, or build the variant first "
+                     "(scripts/build_variant.py) and profile a script that loads it through ZENV_LIB_PATH")
 flags = [a for a in sys.argv[1:] if a.startswith("-D")]
 wl = [a for a in sys.argv[1:] if not a.startswith("-D")]
 so = os.path.join(ROOT, "gpurun_out", "libzenv_exp.so")

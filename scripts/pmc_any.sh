@@ -3,6 +3,7 @@
 # usage: scripts/pmc_any.sh "<COUNTER ...>" <kernel-name-substring> <script.py> [args]
 ctrs=$1; kern=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python -c 'import __graft_entry__ as g; g.build()' || exit 1   # never compile under the profiler's preload
 rm -rf gpurun_out/pmc_tmp
 rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/pmc_tmp -- python "$@" > /dev/null 2>&1
 python - "$kern" <<'PY'

@@ -1,6 +1,7 @@
 #!/bin/bash
 # clock of the GPU during each persistent launch: GRBM_GUI_ACTIVE cycles / dispatch duration
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python -c 'import __graft_entry__ as g; g.build()' || exit 1   # never compile under the profiler's preload
 rm -rf gpurun_out/pmc_clk
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_clk -- python scripts/chunk_times.py "$@" > gpurun_out/pmc_clk.log 2>&1
 python - <<'PY'

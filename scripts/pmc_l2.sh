@@ -1,6 +1,7 @@
 #!/bin/bash
 # L2 hit rate of the step kernel (rocprofv3 PMC pass).  usage: scripts/pmc_l2.sh [extra bench args]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python -c 'import __graft_entry__ as g; g.build()' || exit 1   # never compile under the profiler's preload
 rm -rf gpurun_out/pmc_l2
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_l2 -- python bench.py --steps 100 --no-cpu-baseline --no-kernel-events "$@" > /dev/null 2>&1
 python - <<'PY'

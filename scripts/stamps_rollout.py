@@ -5,6 +5,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import combinatorial_rl_tasks_amd.build as B
+if B.under_profiler():
+    raise SystemExit("this script compiles a variant library: run it without rocprofv3, or build the variant first "
+                     "(scripts/build_variant.py) and profile a script that loads it through ZENV_LIB_PATH")
 so = os.path.join(ROOT, "gpurun_out", "libzenv_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 flags = [a for a in sys.argv[1:] if a.startswith("-D")]
