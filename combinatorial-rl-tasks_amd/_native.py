@@ -28,7 +28,7 @@ E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE = -1, -2, -3, -4, -5
  F_LAST_LEN, F_EPISODES, F_VISIT_COUNT, F_SEED, F_ACTIONS, F_POLICY_MU, F_POLICY_STD, F_POLICY_VALUE,
  F_SHAPED_REWARD, F_NEED_GOAL, F_AVAILABLE_GOALS, F_GOAL,
  F_EXP_OBS, F_EXP_ZONE_OBS, F_EXP_ACTION, F_EXP_LOG_PROB, F_EXP_VALUE, F_EXP_REWARD, F_EXP_MASK,
- F_EXP_ADVANTAGE, F_EXP_RETURN, F_ORDER_VAL) = range(30)
+ F_EXP_ADVANTAGE, F_EXP_RETURN, F_ORDER_VAL, F_EXCEPTION) = range(31)
 
 
 MLP_TENSORS = ("zone_w1", "zone_b1", "zone_w2", "zone_b2", "zone_w3", "zone_b3", "comb_w", "comb_b",
@@ -57,7 +57,10 @@ class Config(C.Structure):
         ("time_saved_reward", C.c_double), ("beta_a", C.c_double), ("beta_b", C.c_double),
         ("timestep", C.c_double), ("mass", C.c_double), ("com_x", C.c_double),
         ("inertia_zz", C.c_double), ("damping", C.c_double * 3), ("gear", C.c_double),
-        ("forcerange", C.c_double), ("vel_kv", C.c_double),
+        ("forcerange", C.c_double), ("vel_kv", C.c_double), ("reward_exception", C.c_double),
+        ("n_zones_locations", C.c_int32), ("n_robot_locations", C.c_int32), ("robot_rot_fixed", C.c_int32),
+        ("visited0", C.c_uint32), ("robot_rot", C.c_double), ("robot_location", C.c_double * 2),
+        ("zones_locations", (C.c_double * 2) * MAX_ZONES),
     ]
 
     def copy(self):

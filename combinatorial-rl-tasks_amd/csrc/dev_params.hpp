@@ -23,7 +23,8 @@ struct DevParams {
     int32_t task, Z, F, N;
     int32_t num_steps, max_cd, frameskip, bank_size;
     int32_t sched_mode, sched_stride;
-    int32_t kernel, pad_kernel;   // ZENV_KERNEL_*
+    int32_t kernel;       // ZENV_KERNEL_*
+    uint32_t vis0;        // zones that start an episode visited (TSPHardEnv 'zones_colours'), bit z = zone z
     int64_t seed_min, seed_max;
     // model constants (derived on the host once; see zenv_api.cpp:derive_constants)
     double h, gear, fmax, kv, mc;
@@ -32,6 +33,7 @@ struct DevParams {
     double hit_d2;        // largest d2 with sqrt(d2) <= zones_size
     float d2_lo, d2_hi;   // float32 prefilter shell around zones_size^2 (see kernels.hip)
     double tsr;           // time_saved_reward
+    double reward_exc;    // Engine 'reward_exception'
     double inv3, inv1_5;  // RN(1/3), RN(1/1.5)
     double d_steps, inv_steps;   // (double)num_steps and RN(1/num_steps)
     double d_maxcd, inv_maxcd;   // (double)max_cd and RN(1/max_cd)
@@ -76,6 +78,7 @@ struct DevParams {
     // outputs
     float *obs, *zone_obs, *reward, *actions;
     uint8_t *done_out, *goal_met;
+    uint8_t *exception;   // info['exception'] of the last finished episode (written when an episode ends)
     unsigned long long *dbg;   // diagnostic stamps (ZENV_STAMPS builds), else null
 };
 

@@ -273,12 +273,22 @@ int sample_layout(const zenv_config &cfg, int64_t seed, Layout &out)
         bool failed = false;
         for (int obj = 0; obj <= Z && !failed; ++obj) {
             const double keepout = (obj == 0) ? cfg.robot_keepout : cfg.zones_keepout;
-            const double lo = -cfg.extent + keepout;
-            const double hi = cfg.extent - keepout;
+            // draw_placement: the extents shrunk by the keepout -- or, for an object with a fixed location
+            // ('robot_locations', 'zones_locations'), placements_dict_from_object's box (x-k, y-k, x+k, y+k) with
+            // k = keepout + 1e-9 shrunk the same way: a 2e-9-wide box that still takes two uniform draws
+            double xlo = -cfg.extent + keepout, xhi = cfg.extent - keepout, ylo = xlo, yhi = xhi;
+            const double *fixed = nullptr;
+            if (obj == 0 && cfg.n_robot_locations > 0) fixed = cfg.robot_location;
+            if (obj > 0 && obj - 1 < cfg.n_zones_locations) fixed = cfg.zones_locations[obj - 1];
+            if (fixed) {
+                const double k = keepout + 1e-9;
+                xlo = (fixed[0] - k) + keepout; xhi = (fixed[0] + k) - keepout;
+                ylo = (fixed[1] - k) + keepout; yhi = (fixed[1] + k) - keepout;
+            }
             bool found = false;
             for (int t = 0; t < 100 && !found; ++t) {
-                const double x = rs.uniform(lo, hi);
-                const double y = rs.uniform(lo, hi);
+                const double x = rs.uniform(xlo, xhi);
+                const double y = rs.uniform(ylo, yhi);
                 bool clear = true;
                 for (int j = 0; j < n_placed; ++j) {
                     const double ddx = x - placed[j].x, ddy = y - placed[j].y;
@@ -308,7 +318,8 @@ int sample_layout(const zenv_config &cfg, int64_t seed, Layout &out)
         out.zone_xy[z][0] = placed[z + 1].x;
         out.zone_xy[z][1] = placed[z + 1].y;
     }
-    out.robot_rot = rs.uniform(0.0, 2 * 3.141592653589793);
+    // build_world_config: robot_rot = random_rot() unless the config fixes it
+    out.robot_rot = cfg.robot_rot_fixed ? cfg.robot_rot : rs.uniform(0.0, 2 * 3.141592653589793);
     return 0;
 }
 

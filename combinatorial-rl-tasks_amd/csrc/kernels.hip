@@ -296,7 +296,7 @@ __device__ __forceinline__ void reset_env(const DevParams &p, int env, int slot,
     e.x0 = br[0]; e.y0 = br[1]; e.bq0 = br[2]; e.bq3 = br[3];
     e.q0 = e.q1 = e.q2 = 0.0;
     e.v0 = e.v1 = e.v2 = 0.0;
-    e.vis = 0u;
+    e.vis = (TASK == ZENV_TASK_COLOUR_MATCH) ? 0u : p.vis0;   // TSPHardEnv: some zones start visited
     e.colpack = 0ull;
     e.goal_dist = 0;
     e.steps = 0;
@@ -307,7 +307,7 @@ __device__ __forceinline__ void reset_env(const DevParams &p, int env, int slot,
         const double zx = bz[2 * z], zy = bz[2 * z + 1];
         const size_t zi = (size_t)z * N + env;
         p.zxy[zi] = make_double2(zx, zy);
-        int code = 0, aux = 0;
+        int code = (TASK == ZENV_TASK_COLOUR_MATCH) ? 0 : (int)((p.vis0 >> z) & 1u), aux = 0;
         if (TASK == ZENV_TASK_TIMED_TSP) {
             aux = ba[z];
             p.tmax[zi] = aux;
@@ -766,9 +766,11 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         float4 zp[ZH];      // float32 zone positions (x/3, y/3), two zones per 16-byte load
         int auxr[ZR];
         int epi_idx = 0, slot_first = 0;
+        float2 act = make_float2(0.f, 0.f);
         if (valid) {
             // ---- issue every load of this env first
             was_done = p.done_state[env];
+            act = reinterpret_cast<const float2 *>(actions)[env];   // only its NaN-ness matters here (exception path)
             {
                 const double2 qa = p.qa[env], fa = p.fa[env], fb = p.fb[env];
                 e.q0 = qa.x; e.q1 = qa.y;
@@ -910,9 +912,17 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         ZSTAMP(14);
         if (valid && !was_done) {
             // ---- reward / goal / termination (Engine.step order; none of it needs the physics)
+            // Engine.step's MujocoException path: MuJoCo cannot simulate a NaN control (np.clip keeps it; mj_checkAcc
+            // -> BADQACC -> mujoco-py raises): done, reward_exception, no reward() / goal test; the physics wave
+            // leaves the joint state mj_resetData would (zeros).  set_mocaps() above already ran, as in the reference.
+            const bool exc = !(act.x == act.x && act.y == act.y);
             double r = 0.0;
-            bool goal;
-            if (TASK == ZENV_TASK_COLOUR_MATCH) {
+            bool goal = false;
+            bool done = false;
+            if (exc) {
+                r = p.reward_exc;
+                done = true;
+            } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
                 if (first >= 0) {
                     const int nd = hamming_to_goal(e.colpack, Z);
                     r = (double)(e.goal_dist - nd);
@@ -923,7 +933,6 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 r = first >= 0 ? 1.0 : 0.0;
                 goal = (e.vis & full) == full;
             }
-            bool done = false;
             if (goal) {
                 r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
                 done = true;
@@ -943,6 +952,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 p.last_return[env] = ep_ret;
                 p.last_len[env] = k;
                 p.episodes[env] += 1;
+                p.exception[env] = exc ? 1 : 0;
                 if (auto_reset) need_reset = true;
                 else p.done_state[env] = 1;
             }
@@ -994,7 +1004,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 const int env_j = env0 + j;
                 const double *br = p.bank_robot + 4 * (size_t)slot;
                 const double b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];   // same address in every lane
-                int code = 0;
+                int code = (TASK == ZENV_TASK_COLOUR_MATCH) ? 0 : (int)((p.vis0 >> (lane & 31)) & 1u);   // pre-visited zones
                 float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (lane < Z) {
                     const size_t bi = (size_t)slot * Z + lane;
@@ -1033,7 +1043,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 fresh.x0 = b0; fresh.y0 = b1; fresh.bq0 = b2; fresh.bq3 = b3;
                 fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
                 fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
-                fresh.vis = 0u;
+                fresh.vis = (TASK == ZENV_TASK_COLOUR_MATCH) ? 0u : p.vis0;
                 fresh.colpack = colpack;
                 fresh.goal_dist = (TASK == ZENV_TASK_COLOUR_MATCH) ? hamming_to_goal(colpack, Z) : 0;
                 fresh.steps = 0;
@@ -1089,6 +1099,11 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             ZSTAMP(9);
 #pragma unroll ZENV_SUBSTEP_UNROLL
             for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
+            if (!(c0 == c0 && c1 == c1)) {
+                // exception path (see the zone wave): what mj_resetData leaves -- qpos = qpos0, qvel = 0
+                e.q0 = e.q1 = e.q2 = 0.0;
+                e.v0 = e.v1 = e.v2 = 0.0;
+            }
             emit_obs8(p, e, o);   // o[0] (remaining) is patched after the rendezvous
         }
         ZSTAMP(10);
@@ -1577,9 +1592,11 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 }
             }
             const bool timed_out = TASK == ZENV_TASK_TIMED_TSP && (expired & ~e.vis & full) != 0u;
-            // ---- reward / goal / termination (Engine.step order)
+            // ---- reward / goal / termination (Engine.step order).  No exception path here (see k_step_lane): this
+            // kernel's actions come from the scripted on-device policies only, which are finite by construction.
             double r = 0.0;
-            bool goal;
+            bool goal = false;
+            bool done = false;
             if (kColour) {
                 if (first >= 0) {
                     const int nd = hamming_to_goal(e.colpack, Z);
@@ -1591,7 +1608,6 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 r = first >= 0 ? 1.0 : 0.0;
                 goal = (e.vis & full) == full;
             }
-            bool done = false;
             if (goal) {
                 r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
                 done = true;
@@ -1610,6 +1626,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 p.last_return[env] = ep_ret;
                 p.last_len[env] = k;
                 p.episodes[env] += 1;
+                p.exception[env] = 0;
             }
             need_reset = done && auto_reset;
             dword = kColour ? e.colpack
@@ -1660,7 +1677,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 const int env_j = env0 + j;
                 const double *br = p.bank_robot + 4 * (size_t)slot;
                 const double b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];
-                int code = 0, aux = 0;
+                int code = kColour ? 0 : (int)((p.vis0 >> (lane & 31)) & 1u), aux = 0;   // pre-visited zones
                 float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (lane < Z) {
                     const size_t bi = (size_t)slot * Z + lane;
@@ -1692,7 +1709,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 fresh.x0 = b0; fresh.y0 = b1; fresh.bq0 = b2; fresh.bq3 = b3;
                 fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
                 fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
-                fresh.vis = 0u;
+                fresh.vis = kColour ? 0u : p.vis0;
                 fresh.colpack = colpack;
                 fresh.goal_dist = kColour ? hamming_to_goal(colpack, Z) : 0;
                 fresh.steps = 0;
@@ -1725,7 +1742,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                     e = fresh;
                     ep_ret = 0.0;
                     act = next_act;
-                    dword = kColour ? colpack : 0ull;          // nothing visited, step count 0
+                    dword = kColour ? colpack : (uint64_t)p.vis0;   // only the pre-visited zones, step count 0
                     p.seed[env] = p.bank_seed[slot];
                     store_obs8(p, env, of);
                 }
@@ -1818,7 +1835,8 @@ __global__ __launch_bounds__(256) void k_goal_clear(DevParams p, const uint8_t *
     p.need_goal[env] = 1;
     p.shaped[env] = 0.0;
     p.visit_zone[env] = -1;
-    p.available[env] = (p.Z >= 32) ? 0xFFFFFFFFu : ((1u << p.Z) - 1u);
+    const uint32_t full = (p.Z >= 32) ? 0xFFFFFFFFu : ((1u << p.Z) - 1u);
+    p.available[env] = p.task == ZENV_TASK_COLOUR_MATCH ? full : (~p.vis0 & full);
 }
 
 __global__ __launch_bounds__(256) void k_goal_step(DevParams p)
@@ -2056,10 +2074,15 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
     bool timed_out = false;
     if (TASK == ZENV_TASK_TIMED_TSP) timed_out = __ballot(zl && !visited && (aux - k) <= 0) != 0ull;   // TTSP_env.py:67
 
-    // ---- reward / goal / termination (Engine.step order)
+    // ---- reward / goal / termination (Engine.step order); a NaN action takes the exception path (see k_step_lane)
+    const bool exc = !(act.x == act.x && act.y == act.y);
     double r = 0.0;
-    bool goal;
-    if (TASK == ZENV_TASK_COLOUR_MATCH) {
+    bool goal = false;
+    bool done = false;
+    if (exc) {
+        r = p.reward_exc;
+        done = true;
+    } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
         if (first >= 0) {
             const int nd = hamming_to_goal(e.colpack, Z);
             r = (double)(e.goal_dist - nd);
@@ -2070,7 +2093,6 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
         r = first >= 0 ? 1.0 : 0.0;
         goal = (e.vis & full) == full;
     }
-    bool done = false;
     if (goal) {
         r += (double)(p.num_steps - e.steps) * p.tsr;
         done = true;
@@ -2084,6 +2106,10 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
     const double c0 = det_clamp((double)act.x, -1.0, 1.0);
     const double c1 = det_clamp((double)act.y, -1.0, 1.0);
     for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
+    if (exc) {
+        e.q0 = e.q1 = e.q2 = 0.0;
+        e.v0 = e.v1 = e.v2 = 0.0;
+    }
 
     if (lane == 0) {
         p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
@@ -2095,6 +2121,7 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
             p.last_return[env] = ep_ret;
             p.last_len[env] = k;
             p.episodes[env] += 1;
+            p.exception[env] = exc ? 1 : 0;
             if (!auto_reset) p.done_state[env] = 1;
         }
     }
@@ -2110,7 +2137,7 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
         if (lane == 0) slot = next_bank_slot(p, env);
         slot = __builtin_amdgcn_readfirstlane(slot);
         const double *br = p.bank_robot + 4 * (size_t)slot;
-        int code = 0;
+        int code = (TASK == ZENV_TASK_COLOUR_MATCH) ? 0 : (int)((p.vis0 >> (lane & 31)) & 1u);
         float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
         if (zl) {
             const size_t bi = (size_t)slot * Z + lane;
@@ -2135,7 +2162,7 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
         fresh.x0 = br[0]; fresh.y0 = br[1]; fresh.bq0 = br[2]; fresh.bq3 = br[3];
         fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
         fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
-        fresh.vis = 0u;
+        fresh.vis = (TASK == ZENV_TASK_COLOUR_MATCH) ? 0u : p.vis0;
         fresh.colpack = 0ull;
         fresh.goal_dist = 0;
         if (TASK == ZENV_TASK_COLOUR_MATCH) {
@@ -2183,7 +2210,8 @@ __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t
     store_counters(p, env, TASK, e);
     p.done_state[env] = 0;
     p.ep_return[env] = 0.0;
-    p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : 0;
+    p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
+    p.exception[env] = 0;
     float o[8];
     emit_obs8(p, e, o);
     store_obs8(p, env, o);

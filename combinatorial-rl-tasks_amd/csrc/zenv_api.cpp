@@ -102,6 +102,30 @@ int validate_config(const zenv_config &c)
     if (!(c.mass > 0) || !(c.inertia_zz > 0) || !(c.timestep > 0)) return fail(ZENV_E_ARG, "bad model constants");
     if (c.kernel != ZENV_KERNEL_LANE_PER_ENV && c.kernel != ZENV_KERNEL_WAVE_PER_ENV)
         return fail(ZENV_E_ARG, "unknown kernel layout %d", c.kernel);
+    // The step kernels treat "MuJoCo could not simulate this step" (Engine.step's MujocoException path) as
+    // "the action holds a NaN".  That is exact while a finite state and a finite control cannot produce a bad qacc
+    // (NaN, Inf, |.| > 1e10: mj_checkAcc): every model constant finite, the mass matrix's Schur complement on the
+    // hinge positive (I0 > m c^2, the parallel-axis bound of any physical body), forces far below 1e10 * mass.
+    for (double v : { c.mass, c.com_x, c.inertia_zz, c.timestep, c.damping[0], c.damping[1], c.damping[2], c.gear,
+                      c.forcerange, c.vel_kv, c.reward_exception, c.time_saved_reward, c.zones_size })
+        if (!std::isfinite(v)) return fail(ZENV_E_ARG, "non-finite model constant");
+    if (c.damping[0] < 0 || c.damping[1] < 0 || c.damping[2] < 0 || c.forcerange < 0)
+        return fail(ZENV_E_ARG, "damping and forcerange must be non-negative");
+    {
+        const double mc = c.mass * c.com_x, bmin = std::min(c.damping[0], c.damping[1]);
+        const double schur = c.inertia_zz + c.timestep * c.damping[2] - mc * mc / (c.mass + c.timestep * bmin);
+        if (!(schur > 1e-12 * c.inertia_zz)) return fail(ZENV_E_ARG, "inertia_zz must exceed mass * com_x^2");
+        if (!(std::fabs(c.gear) * c.forcerange < 1e6 * std::min(c.mass, schur)))
+            return fail(ZENV_E_ARG, "actuator force out of proportion to the body's mass / inertia");
+    }
+    if (c.n_zones_locations < 0 || c.n_zones_locations > c.num_zones)
+        return fail(ZENV_E_ARG, "n_zones_locations %d outside [0, num_zones]", c.n_zones_locations);
+    if (c.n_robot_locations < 0 || c.n_robot_locations > 1)
+        return fail(ZENV_E_ARG, "n_robot_locations must be 0 or 1");
+    if (c.num_zones < 32 && (c.visited0 >> c.num_zones) != 0u) return fail(ZENV_E_ARG, "visited0 names a zone >= num_zones");
+    if (c.visited0 && c.task == ZENV_TASK_COLOUR_MATCH) return fail(ZENV_E_ARG, "visited0 is a TSP / TimedTSP setting");
+    if (c.visited0 && (c.num_zones >= 32 ? c.visited0 == 0xFFFFFFFFu : c.visited0 == (1u << c.num_zones) - 1u))
+        return fail(ZENV_E_ARG, "visited0 leaves no zone to visit");
     return ZENV_OK;
 }
 
@@ -109,7 +133,7 @@ void derive_constants(const zenv_config &c, DevParams &p)
 {
     p.task = c.task;
     p.kernel = c.kernel;
-    p.pad_kernel = 0;
+    p.vis0 = c.visited0;
     p.Z = c.num_zones;
     p.F = zenv_zone_feat(&c);
     p.num_steps = c.num_steps;
@@ -136,6 +160,7 @@ void derive_constants(const zenv_config &c, DevParams &p)
         p.d2_hi = std::nextafterf((float)hi, INFINITY);
     }
     p.tsr = c.time_saved_reward;
+    p.reward_exc = c.reward_exception;
     p.inv3 = 1.0 / 3.0;
     p.inv1_5 = 1.0 / 1.5;
     p.d_steps = (double)c.num_steps;
@@ -196,6 +221,7 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_EXP_ADVANTAGE: return { h->exp.advantage, h->exp.obs ? N * h->exp.T * 4 : 0 };
     case ZENV_F_EXP_RETURN: return { h->exp.returnn, h->exp.obs ? N * h->exp.T * 4 : 0 };
     case ZENV_F_ORDER_VAL: return { p.order_val, p.order_val ? N * p.Z * 4 : 0 };
+    case ZENV_F_EXCEPTION: return { p.exception, N };
     default: return { nullptr, 0 };
     }
 }
@@ -247,6 +273,7 @@ extern "C" int zenv_default_config(int task, int num_zones, zenv_config *c)
     c->gear = 0.3;
     c->forcerange = 0.05;
     c->vel_kv = 1.0;
+    c->reward_exception = -10.0;   // [not vendored] Engine.DEFAULT
     return validate_config(*c);
 }
 
@@ -262,13 +289,34 @@ extern "C" int zenv_config_for_id(const char *env_id, zenv_config *out)
         { "PointTSP-v0", ZENV_TASK_TSP, 15, 2000 },        { "PointTSP-v1", ZENV_TASK_TSP, 5, 1000 },
         { "PointTTSP-v0", ZENV_TASK_TIMED_TSP, 15, 2000 }, { "PointTTSP-v1", ZENV_TASK_TIMED_TSP, 5, 1000 },
         { "ColourMatch-v0", ZENV_TASK_COLOUR_MATCH, 6, 2000 },
+        { "PointTSP-v4", ZENV_TASK_TSP, 15, 1000 },        { "PointTSP-v5", ZENV_TASK_TSP, 15, 250 },
     };
     for (const Entry &e : table) {
         if (std::strcmp(e.id, env_id) == 0) {
             int rc = zenv_default_config(e.task, e.zones, out);
             if (rc) return rc;
             out->num_steps = e.steps;
-            return ZENV_OK;
+            // TSPHardEnv: config_zone_fixed_1 / _2 (envs/__init__.py:52-81)
+            if (std::strcmp(env_id, "PointTSP-v4") == 0) {
+                static const double loc[5][2] = { { -2.6, -1.6 }, { -0., -0.5 }, { 1., 0.5 }, { 1.8, 1.5 }, { 2.6, 2.6 } };
+                out->n_zones_locations = 5;
+                std::memcpy(out->zones_locations, loc, sizeof(loc));
+                out->visited0 = 0x7FE0u;                 // 'zones_colours': [6] * 5 + [5] * 10 (Cyan, then Yellow)
+                out->n_robot_locations = 1;
+                out->robot_location[0] = -0.9;
+                out->robot_location[1] = -0.9;
+                out->robot_rot_fixed = 1;
+                out->robot_rot = -1.0;
+            } else if (std::strcmp(env_id, "PointTSP-v5") == 0) {
+                static const double loc[3][2] = { { -2.6, -2.6 }, { -2, -1.6 }, { 2, 1 } };
+                out->n_zones_locations = 3;
+                std::memcpy(out->zones_locations, loc, sizeof(loc));
+                out->visited0 = 0x7FF8u;                 // [6] * 3 + [5] * 12
+                out->n_robot_locations = 1;
+                out->robot_location[0] = 0.8;
+                out->robot_location[1] = 0.8;
+            }
+            return validate_config(*out);
         }
     }
     return fail(ZENV_E_ARG, "Unknown environment: %s", env_id);
@@ -360,6 +408,7 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
     want(h, p.obs, 8 * N, true); want(h, p.zone_obs, Z * F * N, true);
     want(h, p.reward, N, true); want(h, p.actions, 2 * N, true);
     want(h, p.done_out, N, true); want(h, p.goal_met, N, true);
+    want(h, p.exception, N, true);
     want(h, p.dbg, 16 * ((N + 63) / 64), false);
 
     hipError_t err = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);

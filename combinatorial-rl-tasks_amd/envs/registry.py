@@ -1,6 +1,6 @@
 """The gym registry of main/envs/__init__.py:7-141 for the ids on the MI355X hot path."""
 from .zone_envs import (ColourMatchEnv, ColourMatchNextCityEnv, TimedTSPEnv, TimedTSPNextCityEnv, TSPEnv,
-                        TSPNextCityEnv, TSPOrderEnv)
+                        TSPHardEnv, TSPNextCityEnv, TSPOrderEnv)
 
 config_point = {                      # __init__.py:7-14
     "robot_base": "xmls/point.xml", "num_cities": 15, "walled": False,
@@ -15,20 +15,37 @@ config_point_colour = {               # __init__.py:43-50
     "observe_remaining": True, "observation_flatten": False, "num_steps": 2000,
 }
 
+zone_locations_1 = [(-2.6, -1.6), (-0., -0.5), (1., 0.5), (1.8, 1.5), (2.6, 2.6)]          # __init__.py:52
+config_zone_fixed_1 = {               # __init__.py:54-66
+    "robot_base": "xmls/point.xml", "num_cities": 15, "walled": False,
+    "observe_remaining": True, "observation_flatten": False, "num_steps": 1000, "zones_num": 15,
+    "zones_locations": zone_locations_1, "zones_colours": [6] * 5 + [5] * 10,
+    "robot_locations": [(-0.9, -0.9)], "robot_rot": -1,
+}
+zone_locations_2 = [(-2.6, -2.6), (-2, -1.6), (2, 1)]                                       # __init__.py:68-69
+config_zone_fixed_2 = {               # __init__.py:70-81
+    "robot_base": "xmls/point.xml", "num_cities": 15, "walled": False,
+    "observe_remaining": True, "observation_flatten": False, "num_steps": 250, "zones_num": 15,
+    "zones_locations": zone_locations_2, "zones_colours": [6] * 3 + [5] * 12,
+    "robot_locations": [(0.8, 0.8)],
+}
+
 REGISTRY = {
     "PointTSP-v0": (TSPEnv, config_point),                 # __init__.py:88-90
     "PointTSP-v1": (TSPEnv, config_point_easy),            # :94-96
     "PointTTSP-v0": (TimedTSPEnv, config_point),           # :127-129
     "PointTTSP-v1": (TimedTSPEnv, config_point_easy),      # :131-133
     "ColourMatch-v0": (ColourMatchEnv, config_point_colour),   # :136-138
+    "PointTSP-v4": (TSPHardEnv, config_zone_fixed_1),      # :109-111 hard instance 1
+    "PointTSP-v5": (TSPHardEnv, config_zone_fixed_2),      # :114-116 hard instance 2
     "PointTSP-v2": (TSPOrderEnv, config_point),            # :98-100 solver-ordered (own tour instead of OR-tools)
     "PointTSP-v3": (TSPNextCityEnv, config_point),         # :104-106 goal-conditioned
     "PointTTSP-v3": (TimedTSPNextCityEnv, config_point),   # zone-goals/envs/__init__.py:140-142
     "ColourMatch-v3": (ColourMatchNextCityEnv, config_point_colour),   # zone-goals/envs/__init__.py:151-153
 }
 
-# registered by the reference but outside this build (other robots, solver/goal variants)
-OUT_OF_SCOPE = ("PointTSP-v4", "PointTSP-v5", "CarTSP-v0", "DoggoTSP-v0")
+# registered by the reference but outside this build (other robots)
+OUT_OF_SCOPE = ("CarTSP-v0", "DoggoTSP-v0")
 
 
 def make(env_id, **kwargs):

@@ -112,6 +112,8 @@ class ZoneEnvBase:
         info = {"cost": 0}
         if self._vec.get(nat.F_GOAL_MET)[0]:
             info["goal_met"] = True
+        if self.done and self._vec.get(nat.F_EXCEPTION)[0]:
+            info = {"exception": True}       # Engine.step's MujocoException branch: no cost(), no goal test
         return self.obs(), reward, self.done, info
 
     def close(self):
@@ -163,6 +165,31 @@ class TSPEnv(ZoneEnvBase):
     def zones(self):
         st = self._vec.debug_state()["zone_state"][0]
         return [visited if v else unvisited for v in st]
+
+
+class TSPHardEnv(TSPEnv):
+    """PointTSP-v4 / -v5 (main/envs/TSP_hard_env.py:11-29 with config_zone_fixed_1/_2, envs/__init__.py:52-81): the
+    first cities and the robot sit at fixed locations (Engine 'zones_locations', 'robot_locations', 'robot_rot'), the
+    other cities are sampled as usual but start the episode already visited ('zones_colours': zone.Yellow)."""
+
+    def __init__(self, config, **kw):
+        config = copy.deepcopy(config)
+        self.zone_colours = config.pop("zones_colours", None)              # :14
+        if self.zone_colours is None or len(self.zone_colours) != config["num_cities"]:
+            raise ValueError("TSPHardEnv needs one zones_colours entry per city")
+        bad = [c for c in self.zone_colours if zone(c) not in (visited, unvisited)]
+        if bad:
+            raise ValueError(f"zones_colours must be {unvisited.value} (Cyan) or {visited.value} (Yellow), got {bad}")
+        self._hard = {"visited0": sum(1 << i for i, c in enumerate(self.zone_colours) if zone(c) == visited),
+                      "zones_locations": config.get("zones_locations", []),
+                      "robot_locations": config.get("robot_locations", []),
+                      "robot_rot": config.get("robot_rot", None)}
+        if config.get("zones_num", config["num_cities"]) != config["num_cities"]:
+            raise ValueError("zones_num must equal num_cities")
+        super().__init__(config, **kw)
+
+    def _native_overrides(self):
+        return dict(self._hard)
 
 
 class TimedTSPEnv(TSPEnv):

@@ -134,11 +134,14 @@ class ParallelEnv:
         zo = zo.astype(np.float64)
         was_finished = getattr(self, "_finished", np.zeros(self.num_envs, bool))
         goal_info = self._vec.goal_info() if getattr(self, "_goals", False) else None
+        exc = self._vec.get(nat.F_EXCEPTION) if d.any() else None
         results = []
         for i in range(self.num_envs):
             info = {} if was_finished[i] else {"cost": 0}   # WaitWrapper no-op: info = {}
             if g[i]:
                 info["goal_met"] = True
+            if d[i] and not was_finished[i] and exc[i]:
+                info = {"exception": True}                   # Engine.step's MujocoException branch
             if goal_info is not None:
                 info["shaped_reward"] = float(goal_info[0][i])
                 info["need_next_goal"] = bool(goal_info[1][i])

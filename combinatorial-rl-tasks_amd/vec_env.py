@@ -22,6 +22,7 @@ _FIELD_DTYPES = {
     nat.F_ACTIONS: np.float32, nat.F_POLICY_MU: np.float32, nat.F_POLICY_STD: np.float32,
     nat.F_POLICY_VALUE: np.float32, nat.F_SHAPED_REWARD: np.float64, nat.F_NEED_GOAL: np.uint8,
     nat.F_AVAILABLE_GOALS: np.uint32, nat.F_GOAL: np.int32, nat.F_ORDER_VAL: np.float32,
+    nat.F_EXCEPTION: np.uint8,
 }
 
 
@@ -45,6 +46,21 @@ def apply_overrides(cfg, overrides):
         if k == "damping":
             for i in range(3):
                 cfg.damping[i] = float(v[i])
+        elif k == "robot_locations":              # Engine 'robot_locations': [] or [(x, y)]
+            cfg.n_robot_locations = len(v)
+            for i, c in enumerate(v[:1]):
+                cfg.robot_location[0], cfg.robot_location[1] = float(c[0]), float(c[1])
+            if len(v) > 1:
+                raise ValueError("at most one robot location")
+        elif k == "zones_locations":              # Engine 'zones_locations': the first len(v) zones are fixed
+            if len(v) > nat.MAX_ZONES:
+                raise ValueError("too many zones_locations")
+            cfg.n_zones_locations = len(v)
+            for i, c in enumerate(v):
+                cfg.zones_locations[i][0], cfg.zones_locations[i][1] = float(c[0]), float(c[1])
+        elif k == "robot_rot":                    # Engine 'robot_rot': None = random
+            cfg.robot_rot_fixed = 0 if v is None else 1
+            cfg.robot_rot = 0.0 if v is None else float(v)
         elif not hasattr(cfg, k):
             raise KeyError(f"unknown config key {k!r}")
         else:

@@ -79,7 +79,9 @@ enum {
     ZENV_F_EXP_ADVANTAGE = 27,   /* float32 [T,N]    GAE (:190-196) */
     ZENV_F_EXP_RETURN = 28,      /* float32 [T,N]    value + advantage (:226) */
     ZENV_F_ORDER_VAL = 29,       /* float32 [N,Z]    TSPOrderEnv's 7th row feature 0.5^(position in the route), 0 when visited */
-    ZENV_F_COUNT = 13
+    ZENV_F_EXCEPTION = 30,       /* uint8   [N]      info['exception'] of the env's LAST FINISHED episode: 1 = it was ended by
+                                  *                    Engine.step's MujocoException path (valid once done; see zenv_step) */
+    ZENV_F_COUNT = 31
 };
 
 /* scripted on-device action sources (the build's own; used by bench/tests) */
@@ -117,6 +119,18 @@ typedef struct zenv_config {
     double mass, com_x, inertia_zz;
     double damping[3];
     double gear, forcerange, vel_kv;
+    double reward_exception;   /* Engine.DEFAULT 'reward_exception' (-10.0): the reward of a step MuJoCo could not simulate */
+    /* Fixed placements and a pre-coloured start: config_zone_fixed_1/_2 of envs/__init__.py:52-81 for TSPHardEnv
+     * (TSP_hard_env.py:11-29, ids PointTSP-v4 / -v5).  [not vendored] Engine.placements_dict_from_object gives object i
+     * with a fixed location (x, y) the placement box (x-k, y-k, x+k, y+k), k = keepout + 1e-9, which draw_placement
+     * shrinks by the keepout again: the object lands within 1e-9 of (x, y) and still consumes two uniform draws. */
+    int32_t n_zones_locations; /* 'zones_locations': the first n zones are fixed, the rest sampled as usual */
+    int32_t n_robot_locations; /* 'robot_locations': 0 or 1 entry */
+    int32_t robot_rot_fixed;   /* != 0: 'robot_rot' is given (no random_rot() draw for the robot) */
+    uint32_t visited0;         /* 'zones_colours': bit z set = zone z starts visited (Yellow); TSP / TimedTSP only */
+    double robot_rot;
+    double robot_location[2];
+    double zones_locations[ZENV_MAX_ZONES][2];
 } zenv_config;
 
 typedef struct zenv zenv_t;
@@ -124,8 +138,8 @@ typedef struct zenv zenv_t;
 /* ---- configuration / introspection (host only; usable without a GPU) ---- */
 const char *zenv_last_error(void);
 const char *zenv_version(void);
-/* env_id: "PointTSP-v0", "PointTSP-v1", "PointTTSP-v0", "PointTTSP-v1", "ColourMatch-v0"
- * (envs/__init__.py:88-141); unknown id -> ZENV_E_ARG (make_env.py:18 RuntimeError). */
+/* env_id: "PointTSP-v0", "PointTSP-v1", "PointTSP-v4", "PointTSP-v5" (TSPHardEnv), "PointTTSP-v0", "PointTTSP-v1",
+ * "ColourMatch-v0" (envs/__init__.py:88-141); unknown id -> ZENV_E_ARG (make_env.py:18 RuntimeError). */
 int zenv_config_for_id(const char *env_id, zenv_config *out);
 int zenv_default_config(int task, int num_zones, zenv_config *out);
 int zenv_zone_feat(const zenv_config *cfg);   /* F: 6 (TSP) or 7 */
@@ -175,7 +189,13 @@ int zenv_reset(zenv_t *h, const uint8_t *mask);
  * (NULL = internal action buffer written by zenv_policy); auto_reset != 0 resets finished
  * envs in the same launch and returns the new episode's first observation with the terminal
  * reward/done/goal_met (penv.py:8-11).  With auto_reset == 0 a finished env is a masked
- * no-op: zero obs, reward 0, done 1 (WaitWrapper, wrappers.py:34-45). */
+ * no-op: zero obs, reward 0, done 1 (WaitWrapper, wrappers.py:34-45).
+ * Exception path ([not vendored] Engine.step: `except MujocoException: done = True; reward = reward_exception;
+ * info['exception'] = True`): mujoco-py raises it when MuJoCo warns that qacc / qpos / qvel hold a NaN, an Inf or a
+ * value beyond 1e10 (mj_checkAcc -> mjWARN_BADQACC, after which MuJoCo has reset the data to qpos0, qvel = 0).  With
+ * the actuator forces clamped and a validated config the state stays finite, so the one trigger is a NaN action
+ * (np.clip keeps a NaN): that step ends the episode with reward_exception, no goal test, joint state zeroed,
+ * ZENV_F_EXCEPTION = 1.  The zone visit of that step's first set_mocaps() still counts (it ran before sim.step()). */
 int zenv_step(zenv_t *h, const float *actions, int actions_on_device, int auto_reset);
 /* Scripted action source -> internal action buffer (or dst_device if non-NULL). */
 int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0,

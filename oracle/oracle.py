@@ -57,7 +57,10 @@ class Config(C.Structure):
         ("time_saved_reward", C.c_double), ("beta_a", C.c_double), ("beta_b", C.c_double),
         ("timestep", C.c_double), ("mass", C.c_double), ("com_x", C.c_double),
         ("inertia_zz", C.c_double), ("damping", C.c_double * 3), ("gear", C.c_double),
-        ("forcerange", C.c_double), ("vel_kv", C.c_double),
+        ("forcerange", C.c_double), ("vel_kv", C.c_double), ("reward_exception", C.c_double),
+        ("n_zones_locations", C.c_int32), ("n_robot_locations", C.c_int32), ("robot_rot_fixed", C.c_int32),
+        ("visited0", C.c_uint32), ("robot_rot", C.c_double), ("robot_location", C.c_double * 2),
+        ("zones_locations", (C.c_double * 2) * MAX_Z),
     ]
 
 
@@ -75,7 +78,7 @@ class Env(C.Structure):
         ("goal_dist", C.c_int32), ("steps", C.c_int32), ("done", C.c_int32),
         ("layout_restarts", C.c_int32),
         ("goal_zone", C.c_int32), ("last_visit", C.c_int32), ("last_dist", C.c_double),
-        ("route", C.c_int32 * MAX_Z), ("route_len", C.c_int32),
+        ("route", C.c_int32 * MAX_Z), ("route_len", C.c_int32), ("exception", C.c_int32),
     ]
 
 

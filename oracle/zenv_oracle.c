@@ -224,6 +224,7 @@ void orc_default_config(int task, int num_zones, orc_config *c)
     c->gear = 0.3;
     c->forcerange = 0.05;
     c->vel_kv = 1.0;
+    c->reward_exception = -10.0;    /* [UPSTREAM] Engine.DEFAULT */
 }
 
 int orc_zone_feat(const orc_config *cfg)
@@ -279,13 +280,24 @@ static int sample_layout(orc_env *e, orc_rs *rs)
     double px[ORC_MAX_Z + 1] = { 0 }, py[ORC_MAX_Z + 1] = { 0 }, pk[ORC_MAX_Z + 1] = { 0 };
     for (int obj = 0; obj <= Z; obj++) {
         double keepout = obj == 0 ? c->robot_keepout : c->zones_keepout;
-        /* constrain_placement: (xmin + k, ymin + k, xmax - k, ymax - k) */
-        double lo = -c->extent + keepout, hi = c->extent - keepout;
+        /* draw_placement -> constrain_placement: (xmin + k, ymin + k, xmax - k, ymax - k) of the extents ... */
+        double xlo = -c->extent + keepout, xhi = c->extent - keepout, ylo = xlo, yhi = xhi;
+        /* ... or, [UPSTREAM] placements_dict_from_object for object i < len(<name>s_locations): the placement
+         * (x - k, y - k, x + k, y + k) with k = keepout + 1e-9, constrained the same way (config_zone_fixed_1/_2,
+         * envs/__init__.py:52-81); one placement -> no rs.choice draw, two uniform draws as usual */
+        const double *fixed = 0;
+        if (obj == 0 && c->n_robot_locations > 0) fixed = c->robot_location;
+        if (obj > 0 && obj - 1 < c->n_zones_locations) fixed = c->zones_locations[obj - 1];
+        if (fixed) {
+            double k = keepout + 1e-9;
+            xlo = (fixed[0] - k) + keepout; xhi = (fixed[0] + k) - keepout;
+            ylo = (fixed[1] - k) + keepout; yhi = (fixed[1] + k) - keepout;
+        }
         int conflicted = 1;
         double x = 0, y = 0;
         for (int t = 0; t < 100; t++) {
-            x = orc_rs_uniform(rs, lo, hi);
-            y = orc_rs_uniform(rs, lo, hi);
+            x = orc_rs_uniform(rs, xlo, xhi);
+            y = orc_rs_uniform(rs, ylo, yhi);
             int ok = 1;
             for (int j = 0; j < obj; j++) {
                 double dx = x - px[j], dy = y - py[j];
@@ -329,7 +341,9 @@ int orc_reset(orc_env *e, const orc_config *cfg, int64_t seed)
             if (e->goal_dist > 0) break;
         }
     }
-    /* TSP_env.py:75: zones = [unvisited]*Z (memset above) */
+    /* TSP_env.py:75: zones = [unvisited]*Z (memset above); TSP_hard_env.py:27-29: zones = zones_colours */
+    if (cfg->task != ORC_TASK_COLOUR)
+        for (int z = 0; z < Z; z++) e->visited[z] = (int32_t)((cfg->visited0 >> z) & 1u);
 
     /* [UPSTREAM] Engine.reset: _seed += 1; rs = RandomState(_seed) */
     orc_rs_seed(&rs, (uint32_t)(seed + 1));
@@ -339,8 +353,8 @@ int orc_reset(orc_env *e, const orc_config *cfg, int64_t seed)
         e->layout_restarts++;
     }
     if (!ok) return -3; /* ResamplingError */
-    /* build_world_config: robot_rot = random_rot() = rs.uniform(0, 2*pi) */
-    e->rot = orc_rs_uniform(&rs, 0.0, 2 * 3.141592653589793);
+    /* build_world_config: robot_rot = random_rot() = rs.uniform(0, 2*pi) unless the config gives 'robot_rot' */
+    e->rot = cfg->robot_rot_fixed ? cfg->robot_rot : orc_rs_uniform(&rs, 0.0, 2 * 3.141592653589793);
     /* (one cosmetic random_rot per zone follows, ZoneEnvBase.py:132: unobservable) */
     /* [UPSTREAM] world.py rot2quat: [cos(rot/2), 0, 0, sin(rot/2)] */
     orc_sincos(e->rot / 2, &e->bq3, &e->bq0);
@@ -357,7 +371,13 @@ int orc_reset(orc_env *e, const orc_config *cfg, int64_t seed)
 
 static double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-static void mj_substep(orc_env *e, const double ctrl[2])
+/* [UPSTREAM] mju_isBad (engine_util_misc.c): NaN or beyond mjMAXVAL = 1e10 */
+static int is_bad(double x) { return x != x || x > 1e10 || x < -1e10; }
+
+/* One mj_step.  Returns 1 when mj_checkAcc would have raised mjWARN_BADQACC (some qacc is bad): MuJoCo then
+ * resets the data (qpos = qpos0, qvel = 0) and runs mj_forward, and mujoco-py turns the warning into a
+ * MujocoException once the call returns. */
+static int mj_substep(orc_env *e, const double ctrl[2])
 {
     const orc_config *c = &e->cfg;
     const double h = c->timestep, g = c->gear, F = c->forcerange;
@@ -387,12 +407,18 @@ static void mj_substep(orc_env *e, const double ctrl[2])
     double a2 = num / den;
     double a0 = FMA(mcs, a2, rhs0) * inv00;
     double a1 = FMA(-mck, a2, rhs1) * inv11;
+    if (is_bad(a0) || is_bad(a1) || is_bad(a2)) {
+        q[0] = q[1] = q[2] = 0.0;       /* mj_resetData */
+        v[0] = v[1] = v[2] = 0.0;
+        return 1;
+    }
     v[0] = FMA(h, a0, v[0]);
     v[1] = FMA(h, a1, v[1]);
     v[2] = FMA(h, a2, v[2]);
     q[0] = FMA(h, v[0], q[0]);
     q[1] = FMA(h, v[1], q[1]);
     q[2] = FMA(h, v[2], q[2]);
+    return 0;
 }
 
 int orc_step(orc_env *e, const float action[2], double *reward, int *done, int *goal_met)
@@ -402,6 +428,7 @@ int orc_step(orc_env *e, const float action[2], double *reward, int *done, int *
     if (e->done) return -1; /* 'Environment must be reset before stepping' */
     int event = 0;
     e->last_visit = -1;
+    e->exception = 0;
     *goal_met = 0;
 
     /* colour_match_env.py:98-100: cooldowns tick before anything else */
@@ -433,8 +460,20 @@ int orc_step(orc_env *e, const float action[2], double *reward, int *done, int *
     double ctrl[2];
     ctrl[0] = clampd((double)action[0], -1.0, 1.0);
     ctrl[1] = clampd((double)action[1], -1.0, 1.0);
-    for (int i = 0; i < c->frameskip; i++) mj_substep(e, ctrl);
-    forward(e);
+    /* np.clip keeps a NaN action; `try: set_mocaps(); sim.step() except MujocoException: exception = True; break` */
+    for (int i = 0; i < c->frameskip; i++)
+        if (mj_substep(e, ctrl)) { e->exception = 1; break; }
+    forward(e);   /* exception: obs() still runs sim.forward() on the reset data */
+
+    if (e->exception) {
+        /* `if exception: self.done = True; reward = self.reward_exception; info['exception'] = True`
+         * -- no reward(), no goal_met(); then steps += 1 and the time limit as always */
+        e->done = 1;
+        e->steps += 1;
+        *reward = c->reward_exception;
+        *done = 1;
+        return 0;
+    }
 
     /* reward(): TSP_env.py:41-42 / colour_match_env.py:86-93 */
     double r = 0.0;

@@ -53,6 +53,15 @@ typedef struct orc_config {
     double gear;               /* both actuators */
     double forcerange;         /* |force| clamp of both actuators */
     double vel_kv;             /* velocity actuator gain */
+    double reward_exception;   /* [UPSTREAM] Engine.DEFAULT 'reward_exception': -10.0 */
+    /* TSPHardEnv (TSP_hard_env.py:11-29) configs config_zone_fixed_1/_2, envs/__init__.py:52-81 */
+    int32_t n_zones_locations; /* 'zones_locations': the first n zones have fixed locations */
+    int32_t n_robot_locations; /* 'robot_locations': 0 or 1 */
+    int32_t robot_rot_fixed;   /* 'robot_rot' given */
+    uint32_t visited0;         /* 'zones_colours': bit z = zone z starts as zone.Yellow (visited) */
+    double robot_rot;
+    double robot_location[2];
+    double zones_locations[ORC_MAX_Z][2];
 } orc_config;
 
 typedef struct orc_env {
@@ -82,6 +91,7 @@ typedef struct orc_env {
     /* solver-ordered variant (TSP_order_env.py): route_len zones still to visit, in order */
     int32_t route[ORC_MAX_Z];
     int32_t route_len;
+    int32_t exception;         /* info['exception'] of the last step ([UPSTREAM] Engine.step) */
 } orc_env;
 
 /* ---- numpy-legacy RandomState restatement (exposed for pinning tests) ---- */

@@ -19,17 +19,36 @@ EVAL_SEEDS = np.arange(1000000, 1000100)      # main/scripts/evaluate.py:47
 EXTENT, ROBOT_KEEPOUT, MARGIN = 3.0, 0.4, 0.0
 
 
-def sample_layout(seed, num_zones, zones_keepout):
+def placements_dict(num_zones, zones_keepout, robot_locations=(), zones_locations=()):
+    """[not vendored] Engine.build_placements_dict / placements_dict_from_object: object -> (placements, keepout);
+    an object with a fixed location gets the box (x - k, y - k, x + k, y + k), k = keepout + 1e-9."""
+    out = {}
+    for name, locs, keepout in ([("robot", robot_locations, ROBOT_KEEPOUT)] +
+                                [(f"zone{i}", zones_locations[i:i + 1], zones_keepout) for i in range(num_zones)]):
+        if len(locs):
+            x, y = locs[0]
+            k = keepout + 1e-9
+            out[name] = ([(x - k, y - k, x + k, y + k)], keepout)
+        else:
+            out[name] = (None, keepout)
+    return out
+
+
+def sample_layout(seed, num_zones, zones_keepout, robot_locations=(), zones_locations=(), robot_rot=None):
     rs = np.random.RandomState(seed + 1)       # Engine.reset: _seed += 1
     names = ["robot"] + [f"zone{i}" for i in range(num_zones)]
-    keepouts = {n: (ROBOT_KEEPOUT if n == "robot" else zones_keepout) for n in names}
+    placements = placements_dict(num_zones, zones_keepout, robot_locations, zones_locations)
+    keepouts = {n: placements[n][1] for n in names}
     restarts = 0
     for _ in range(10000):
         layout = {}
         ok = True
         for name in names:
             k = keepouts[name]
-            xmin, ymin, xmax, ymax = -EXTENT + k, -EXTENT + k, EXTENT - k, EXTENT - k
+            # draw_placement: constrain_placement(extents or the single fixed box, keepout)
+            box = placements[name][0]
+            bx0, by0, bx1, by1 = (-EXTENT, -EXTENT, EXTENT, EXTENT) if box is None else box[0]
+            xmin, ymin, xmax, ymax = bx0 + k, by0 + k, bx1 - k, by1 - k
             conflicted = True
             for _t in range(100):
                 xy = np.array([rs.uniform(xmin, xmax), rs.uniform(ymin, ymax)])
@@ -51,7 +70,8 @@ def sample_layout(seed, num_zones, zones_keepout):
         restarts += 1
     else:
         raise RuntimeError("Failed to sample layout of objects")
-    rot = rs.uniform(0, 2 * np.pi)             # build_world_config: robot_rot = random_rot()
+    # build_world_config: robot_rot = random_rot() unless 'robot_rot' is configured
+    rot = rs.uniform(0, 2 * np.pi) if robot_rot is None else float(robot_rot)
     zones = np.stack([layout[f"zone{i}"] for i in range(num_zones)])
     return np.r_[layout["robot"], rot], zones, restarts
 
@@ -62,6 +82,18 @@ def main():
         robots, zones, restarts = [], [], []
         for s in EVAL_SEEDS:
             r, z, n = sample_layout(int(s), Z, keepout)
+            robots.append(r); zones.append(z); restarts.append(n)
+        out[f"robot_{tag}"] = np.array(robots)
+        out[f"zones_{tag}"] = np.array(zones)
+        out[f"restarts_{tag}"] = np.array(restarts, np.int32)
+    # TSPHardEnv: config_zone_fixed_1 / _2 (main/envs/__init__.py:52-81)
+    hard = {"hard1": dict(robot_locations=[(-0.9, -0.9)], robot_rot=-1,
+                          zones_locations=[(-2.6, -1.6), (-0., -0.5), (1., 0.5), (1.8, 1.5), (2.6, 2.6)]),
+            "hard2": dict(robot_locations=[(0.8, 0.8)], zones_locations=[(-2.6, -2.6), (-2, -1.6), (2, 1)])}
+    for tag, kw in hard.items():
+        robots, zones, restarts = [], [], []
+        for s in EVAL_SEEDS:
+            r, z, n = sample_layout(int(s), 15, 0.55, **kw)
             robots.append(r); zones.append(z); restarts.append(n)
         out[f"robot_{tag}"] = np.array(robots)
         out[f"zones_{tag}"] = np.array(zones)

@@ -5,7 +5,8 @@ TASK_IDS = {0: "PointTSP-v0", 1: "PointTTSP-v0", 2: "ColourMatch-v0"}
 _SHARED_FIELDS = ["task", "num_zones", "num_steps", "max_cd", "frameskip", "zones_size",
                   "zones_keepout", "robot_keepout", "extent", "placements_margin",
                   "time_saved_reward", "beta_a", "beta_b", "timestep", "mass", "com_x",
-                  "inertia_zz", "gear", "forcerange", "vel_kv"]
+                  "inertia_zz", "gear", "forcerange", "vel_kv", "reward_exception", "n_zones_locations",
+                  "n_robot_locations", "robot_rot_fixed", "visited0", "robot_rot"]
 
 
 def oracle_config_from(O, zcfg):
@@ -15,6 +16,11 @@ def oracle_config_from(O, zcfg):
         setattr(ocfg, f, getattr(zcfg, f))
     for i in range(3):
         ocfg.damping[i] = zcfg.damping[i]
+    for i in range(2):
+        ocfg.robot_location[i] = zcfg.robot_location[i]
+    for z in range(32):
+        for i in range(2):
+            ocfg.zones_locations[z][i] = zcfg.zones_locations[z][i]
     return ocfg
 
 

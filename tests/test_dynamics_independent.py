@@ -1,0 +1,221 @@
+"""An INDEPENDENT derivation of one MuJoCo step of the Point robot, asserted against the oracle's closed form.
+
+The oracle (oracle/zenv_oracle.c: mj_substep) and the HIP kernels solve the 3-dof system in a hand-reduced closed
+form (Schur complement on the hinge row), co-designed so that both produce the same bits.  GPU == oracle therefore
+proves the port, not the physics.  This file restates the physics the generic way MuJoCo's documentation describes
+its pipeline -- without looking at mj_substep's algebra -- in plain numpy float64:
+
+  * kinematics of a planar rigid body on three joints (slide x, slide y, hinge z at the body origin);
+  * joint-space inertia M(q) = sum over geoms of  Jv^T m Jv + Jw^T I_com Jw  (what the composite-rigid-body
+    algorithm computes), from the two geoms of xmls/point.xml (sphere + box, uniform density) -- mass, centre of
+    mass and inertia are re-derived here from the geom sizes, not taken from the config;
+  * bias forces c(q, v) from the Christoffel symbols of M(q) (what recursive Newton-Euler computes);
+  * actuation: a `motor` on the body site along the body x axis and a `velocity` servo on the hinge
+    (force = kv * ctrl - kv * gear * qvel), both with ctrlrange [-1, 1], forcerange +-0.05, gear 0.3;
+  * passive joint damping; MuJoCo's Euler integrator with implicit damping:
+        (M + h diag(b)) qacc = qfrc_passive - c + qfrc_actuator;  v += h qacc;  q += h v   (numpy.linalg.solve).
+
+Parity is still UNPINNED against MuJoCo itself (absent); what this pins is that the closed form IS the documented
+algorithm for the model constants of SURVEY.md Appendix A.3, to 1e-12.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+H, GEAR, FMAX, KV = 0.002, 0.3, 0.05, 1.0
+DAMPING = np.array([0.01, 0.01, 0.005])
+
+
+def geoms(density=1.0):
+    """(mass, position of the centre in the body frame, inertia about the own centre around z) per geom."""
+    r = 0.1
+    m_s = density * 4.0 / 3.0 * math.pi * r ** 3
+    hx = 0.05
+    m_b = density * (2 * hx) ** 3
+    return [(m_s, np.array([0.0, 0.0]), 0.4 * m_s * r * r),                       # solid sphere: 2/5 m r^2
+            (m_b, np.array([0.1, 0.0]), m_b * ((2 * hx) ** 2 + (2 * hx) ** 2) / 12.0)]   # cube: m (a^2 + b^2) / 12
+
+
+def jacobians(theta, pos_body):
+    """Translational / rotational Jacobian (planar) of a point fixed in the body at pos_body."""
+    c, s = math.cos(theta), math.sin(theta)
+    px, py = pos_body
+    # world offset of the point = R(theta) pos_body ; d/dtheta = R'(theta) pos_body
+    jv = np.array([[1.0, 0.0, -s * px - c * py],
+                   [0.0, 1.0, c * px - s * py]])
+    jw = np.array([0.0, 0.0, 1.0])
+    return jv, jw
+
+
+def mass_matrix(theta, density=1.0):
+    M = np.zeros((3, 3))
+    for m, pos, i_own in geoms(density):
+        jv, jw = jacobians(theta, pos)
+        M += m * jv.T @ jv + i_own * np.outer(jw, jw)
+    return M
+
+
+def dM_dtheta(theta, density=1.0):
+    """Analytic derivative of M with respect to the hinge angle (the only coordinate M depends on)."""
+    c, s = math.cos(theta), math.sin(theta)
+    dM = np.zeros((3, 3))
+    for m, pos, _ in geoms(density):
+        px, py = pos
+        jv, _ = jacobians(theta, pos)
+        djv = np.array([[0.0, 0.0, -c * px + s * py],
+                        [0.0, 0.0, -s * px - c * py]])
+        dM += m * (djv.T @ jv + jv.T @ djv)
+    return dM
+
+
+def bias(theta, v, density=1.0):
+    """c_i = sum_jk Gamma_ijk v_j v_k,  Gamma_ijk = (dM_ij/dq_k + dM_ik/dq_j - dM_jk/dq_i) / 2."""
+    dM = np.zeros((3, 3, 3))          # dM[i, j, k] = d M_ij / d q_k
+    dM[:, :, 2] = dM_dtheta(theta, density)
+    cvec = np.zeros(3)
+    for i in range(3):
+        for j in range(3):
+            for k in range(3):
+                cvec[i] += 0.5 * (dM[i, j, k] + dM[i, k, j] - dM[j, k, i]) * v[j] * v[k]
+    return cvec
+
+
+def generic_substep(q, v, ctrl, density=1.0):
+    theta = q[2]
+    c, s = math.cos(theta), math.sin(theta)
+    ctrl = np.clip(ctrl, -1.0, 1.0)
+    f0 = float(np.clip(ctrl[0], -FMAX, FMAX))                       # motor: gain 1, no bias
+    f1 = float(np.clip(KV * ctrl[1] - KV * (GEAR * v[2]), -FMAX, FMAX))   # velocity servo on the hinge
+    jv_site, _ = jacobians(theta, np.array([0.0, 0.0]))              # the site sits at the body origin
+    act = jv_site.T @ (GEAR * f0 * np.array([c, s]))                 # force along the body x axis
+    act[2] += GEAR * f1
+    qfrc = -DAMPING * v - bias(theta, v, density) + act
+    qacc = np.linalg.solve(mass_matrix(theta, density) + H * np.diag(DAMPING), qfrc)
+    v2 = v + H * qacc
+    return q + H * v2, v2
+
+
+def oracle_substeps(O, q, v, ctrl, n=1, density=1.0):
+    cfg = O.default_config(0, 1, frameskip=n)
+    if density != 1.0:
+        g = geoms(density)
+        mass = g[0][0] + g[1][0]
+        cfg.mass = mass
+        cfg.com_x = 0.1 * g[1][0] / mass
+        cfg.inertia_zz = g[0][2] + g[1][2] + g[1][0] * 0.1 ** 2
+    env = O.OracleEnv(cfg)
+    env.reset(3)
+    for i in range(3):
+        env.e.qpos[i] = float(q[i])
+        env.e.qvel[i] = float(v[i])
+    env.step(np.asarray(ctrl, np.float32))
+    return np.array(env.e.qpos[:]), np.array(env.e.qvel[:])
+
+
+def test_model_constants_follow_from_the_geoms(oracle_mod):
+    """mass, centre of mass and hinge inertia of the config = what the two geoms of point.xml give at density 1."""
+    cfg = oracle_mod.default_config(0, 15)
+    g = geoms(1.0)
+    mass = sum(m for m, _, _ in g)
+    com = sum(m * p for m, p, _ in g) / mass
+    inertia = sum(i + m * float(p @ p) for m, p, i in g)              # parallel axes, about the hinge
+    assert cfg.mass == pytest.approx(mass, rel=1e-15)
+    assert cfg.com_x == pytest.approx(com[0], rel=1e-15) and com[1] == 0.0
+    assert cfg.inertia_zz == pytest.approx(inertia, rel=1e-15)
+    # and the generic mass matrix has the structure the closed form assumes
+    th = 0.7
+    M = mass_matrix(th)
+    mc = mass * com[0]
+    expect = np.array([[mass, 0, -mc * math.sin(th)], [0, mass, mc * math.cos(th)],
+                       [-mc * math.sin(th), mc * math.cos(th), inertia]])
+    assert np.allclose(M, expect, rtol=1e-14, atol=1e-20)
+
+
+def test_closed_form_substep_equals_the_generic_pipeline(oracle_mod):
+    rs = np.random.RandomState(12345)
+    worst = 0.0
+    for _ in range(400):
+        q = np.array([rs.uniform(-3, 3), rs.uniform(-3, 3), rs.uniform(-20, 20)])
+        v = np.array([rs.uniform(-2, 2), rs.uniform(-2, 2), rs.uniform(-4, 4)])
+        ctrl = np.array([rs.uniform(-1.5, 1.5), rs.uniform(-1.5, 1.5)]).astype(np.float32).astype(np.float64)
+        q_ref, v_ref = generic_substep(q, v, ctrl)
+        q_o, v_o = oracle_substeps(oracle_mod, q, v, ctrl)
+        worst = max(worst, np.abs(q_o - q_ref).max(), np.abs(v_o - v_ref).max())
+    assert worst <= 1e-12, worst
+
+
+@pytest.mark.parametrize("density", [1.0, 5.0])
+def test_closed_form_tracks_the_generic_pipeline_along_a_trajectory(oracle_mod, density):
+    """2 000 substeps of a changing control, compared substep by substep from the oracle's own state: <= 1e-12 each.
+
+    (Whole trajectories of two DIFFERENT float64 evaluation orders cannot be compared: at density 1 the hinge's
+    velocity servo is unstable in its unsaturated band -- one explicit-force Euler step multiplies a velocity error by
+    1 - h g^2 kv / (I_eff + h b2) = -4.2, I_eff = I0 - (m c)^2 / m -- so the clamped servo chatters and a 1e-16 rounding difference reaches O(1)
+    in the hinge velocity within ~30 substeps.  test_servo_gain_factor pins that number; DESIGN.md section 0 discusses it.)"""
+    rs = np.random.RandomState(7)
+    qo, vo = np.zeros(3), np.zeros(3)
+    worst = 0.0
+    for step in range(200):
+        ctrl = np.array([rs.uniform(-1, 1), rs.uniform(-1, 1)]).astype(np.float32).astype(np.float64)
+        for _ in range(10):
+            q_ref, v_ref = generic_substep(qo, vo, ctrl, density)
+            qo, vo = oracle_substeps(oracle_mod, qo, vo, ctrl, n=1, density=density)
+            worst = max(worst, np.abs(qo - q_ref).max(), np.abs(vo - v_ref).max())
+    assert worst <= 1e-12, worst
+    assert np.abs(qo[:2]).max() > 0.05 and abs(qo[2]) > 0.1            # the robot did move and turn
+
+
+def test_one_env_step_of_ten_substeps_agrees(oracle_mod):
+    """Engine.step's 10 substeps in one oracle call vs ten generic substeps from the same state: the error growth of
+    the chattering servo (4.2x per substep at worst) keeps this within 1e-9."""
+    rs = np.random.RandomState(99)
+    worst = 0.0
+    for _ in range(200):
+        q = np.array([rs.uniform(-3, 3), rs.uniform(-3, 3), rs.uniform(-6, 6)])
+        v = np.array([rs.uniform(-1.5, 1.5), rs.uniform(-1.5, 1.5), rs.uniform(-3, 3)])
+        ctrl = np.array([rs.uniform(-1, 1), rs.uniform(-1, 1)]).astype(np.float32).astype(np.float64)
+        q_o, v_o = oracle_substeps(oracle_mod, q, v, ctrl, n=10)
+        for _ in range(10):
+            q, v = generic_substep(q, v, ctrl)
+        worst = max(worst, np.abs(q_o - q).max(), np.abs(v_o - v).max())
+    assert worst <= 1e-9, worst
+
+
+def test_servo_gain_factor():
+    """The per-substep multiplier of a hinge-velocity perturbation while the servo is unsaturated, from the generic
+    pipeline: about -4.2 at density 1 (chatter, bounded by the force clamp), about -0.33 at density 5 (stable)."""
+    for density, lo, hi in ((1.0, -4.5, -3.9), (5.0, -0.45, -0.2)):
+        q, v, ctrl = np.zeros(3), np.array([0.0, 0.0, 1.0]), np.array([0.0, 0.3])      # servo error 0: unsaturated
+        eps = 1e-6
+        _, v_a = generic_substep(q, v, ctrl, density)
+        _, v_b = generic_substep(q, v + np.array([0, 0, eps]), ctrl, density)
+        factor = (v_b[2] - v_a[2]) / eps
+        assert lo < factor < hi, (density, factor)
+
+
+def test_world_quantities_follow_the_kinematic_chain(oracle_mod):
+    """xpos / xvelp / xvelr / xquat of body `robot` as mj_kinematics + the body Jacobian give them: the slides act in
+    the frame the body was placed in (rotated by the layout's robot_rot), the hinge turns about the body origin."""
+    O = oracle_mod
+    env = O.OracleEnv(O.default_config(0, 3))
+    env.reset(11)
+    robot, _ = env.layout
+    x0, y0, rot = robot
+    q = np.array([0.3, -0.2, 1.1])
+    v = np.array([0.5, 0.25, -2.0])
+    for i in range(3):
+        env.e.qpos[i], env.e.qvel[i] = q[i], v[i]
+    cfg1 = O.default_config(0, 3, frameskip=1)
+    env.cfg = cfg1
+    env.e.cfg = cfg1
+    qn, vn = generic_substep(q, v, np.zeros(2))
+    env.step(np.zeros(2, np.float32))
+    R = np.array([[math.cos(rot), -math.sin(rot)], [math.sin(rot), math.cos(rot)]])
+    assert np.allclose(np.array(env.e.xpos[:]), np.array([x0, y0]) + R @ qn[:2], rtol=0, atol=1e-13)
+    assert np.allclose(np.array(env.e.xvelp[:]), R @ vn[:2], rtol=0, atol=1e-13)
+    assert env.e.xvelr == pytest.approx(vn[2], abs=1e-13)
+    half = 0.5 * (rot + qn[2])
+    assert env.e.xquat0 == pytest.approx(math.cos(half), abs=1e-14)
+    assert env.e.xquat3 == pytest.approx(math.sin(half), abs=1e-14)

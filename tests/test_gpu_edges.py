@@ -55,7 +55,8 @@ def test_fused_rollout_runtime_zone_count(zenv_mod, oracle_mod):
 
 
 def test_out_of_range_and_nonfinite_actions(zenv_mod, oracle_mod):
-    """Engine.step clips to the actuator ctrlrange; NaN propagates identically on both sides."""
+    """Engine.step clips to the actuator ctrlrange (+-inf included); a NaN survives np.clip and takes Engine.step's
+    MujocoException branch: done, reward_exception, state reset -- identically on both sides, observations finite."""
     Z, O = zenv_mod, oracle_mod
     cfg = Z.config_for_id("PointTSP-v1")
     n = 8
@@ -71,8 +72,11 @@ def test_out_of_range_and_nonfinite_actions(zenv_mod, oracle_mod):
         ob.step(a)
         o, zo = env.observations()
         o_ref, zo_ref = ob.obs()
-        assert np.array_equal(o, o_ref, equal_nan=True) and np.array_equal(zo, zo_ref)
-    assert np.isnan(o[5]).any() and not np.isnan(o[:5]).any()
+        assert np.array_equal(o, o_ref) and np.array_equal(zo, zo_ref)
+        assert np.isfinite(o).all()
+        r, d = env.get(Z.F_REWARD), env.get(Z.F_DONE).astype(bool)
+        assert (r[5:7] == -10.0).all() and d[5:7].all() and env.get(Z.F_EXCEPTION)[5:7].all()
+        assert not d[:5].any() and not d[7]
     env.close()
 
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(zenv_mod):
 
 def test_config_struct_layout(zenv_mod):
     Z = zenv_mod
-    assert C.sizeof(Z.Config) == Z._native.lib().zenv_config_size() == 6 * 4 + 18 * 8
+    assert C.sizeof(Z.Config) == Z._native.lib().zenv_config_size() == 6 * 4 + 19 * 8 + 4 * 4 + (1 + 2 + 64) * 8
     cfg = Z.config_for_id("PointTSP-v0")
     assert (cfg.task, cfg.num_zones, cfg.num_steps, cfg.frameskip) == (0, 15, 2000, 10)
     assert (cfg.zones_size, cfg.zones_keepout, cfg.robot_keepout, cfg.extent) == (0.2, 0.55, 0.4, 3.0)
@@ -39,7 +39,8 @@ def test_config_struct_layout(zenv_mod):
 
 @pytest.mark.parametrize("env_id,task,zones,steps,feat", [
     ("PointTSP-v0", 0, 15, 2000, 6), ("PointTSP-v1", 0, 5, 1000, 6), ("PointTTSP-v0", 1, 15, 2000, 7),
-    ("PointTTSP-v1", 1, 5, 1000, 7), ("ColourMatch-v0", 2, 6, 2000, 7)])
+    ("PointTTSP-v1", 1, 5, 1000, 7), ("ColourMatch-v0", 2, 6, 2000, 7), ("PointTSP-v4", 0, 15, 1000, 6),
+    ("PointTSP-v5", 0, 15, 250, 6)])
 def test_registry_ids(zenv_mod, env_id, task, zones, steps, feat):
     """main/envs/__init__.py:88-141."""
     Z = zenv_mod
