@@ -30,6 +30,9 @@ struct DevParams {
     double h, gear, fmax, kv, mc;
     double b0, b1, b2;
     double A22, inv00, inv11;
+    double inv_den;       // 1 / (A22 - mc^2 inv00): the hinge row's Schur complement when b0 == b1 (iso)
+    double kvg;           // vel_kv * gear
+    int32_t iso, pad_iso;
     double hit_d2;        // largest d2 with sqrt(d2) <= zones_size
     float d2_lo, d2_hi;   // float32 prefilter shell around zones_size^2 (see kernels.hip)
     double tsr;           // time_saved_reward
@@ -80,6 +83,7 @@ struct DevParams {
     uint8_t *done_out, *goal_met;
     uint8_t *exception;   // info['exception'] of the last finished episode (written when an episode ends)
     unsigned long long *dbg;   // diagnostic stamps (ZENV_STAMPS builds), else null
+    const DevParams *self;     // device copy of this block (kept current by the host): cold fields are read through it
 };
 
 enum { SCHED_SEQUENTIAL = 0, SCHED_FIXED_SEEDS = 1 };

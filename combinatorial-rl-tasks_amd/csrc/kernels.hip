@@ -186,7 +186,8 @@ __device__ __forceinline__ void world_pos(const EnvRegs &e, double &px, double &
     py = __builtin_fma(sr, e.q0, __builtin_fma(cr, e.q1, e.y0));
 }
 
-__device__ __forceinline__ Pose forward_pose(const EnvRegs &e)
+// hs, hc: sin / cos of half the hinge angle -- what the next step's physics starts from (physics_step)
+__device__ __forceinline__ Pose forward_pose(const EnvRegs &e, double &hs, double &hc)
 {
     Pose o;
     const double cr = __builtin_fma(e.bq0, e.bq0, -(e.bq3 * e.bq3));
@@ -196,7 +197,6 @@ __device__ __forceinline__ Pose forward_pose(const EnvRegs &e)
     o.vx = __builtin_fma(cr, e.v0, -(sr * e.v1));
     o.vy = __builtin_fma(sr, e.v0, cr * e.v1);
     o.w = e.v2;
-    double hs, hc;
     det_sincos_inl(0.5 * e.q2, hs, hc);
     o.xq0 = __builtin_fma(e.bq0, hc, -(e.bq3 * hs));
     o.xq3 = __builtin_fma(e.bq0, hs, e.bq3 * hc);
@@ -204,9 +204,9 @@ __device__ __forceinline__ Pose forward_pose(const EnvRegs &e)
 }
 
 // ZoneEnvBase.py:190-192,217-224 -> the 8-float 'obs' of wrappers.py:136-142
-__device__ __forceinline__ void emit_obs8(const DevParams &p, const EnvRegs &e, float *o)
+__device__ __forceinline__ void emit_obs8(const DevParams &p, const EnvRegs &e, float *o, double &hs, double &hc)
 {
-    const Pose f = forward_pose(e);
+    const Pose f = forward_pose(e, hs, hc);
     o[0] = (float)(1.0 - div_const((double)e.steps, p.d_steps, p.inv_steps));
     o[1] = (float)div_const_z(f.px, 3.0, p.inv3);
     o[2] = (float)div_const_z(f.py, 3.0, p.inv3);
@@ -216,6 +216,11 @@ __device__ __forceinline__ void emit_obs8(const DevParams &p, const EnvRegs &e, 
     o[5] = (float)div_const_z(f.vx, 1.5, p.inv1_5);
     o[6] = (float)div_const_z(f.vy, 1.5, p.inv1_5);
     o[7] = (float)div_const_z(f.w, 3.0, p.inv3);
+}
+__device__ __forceinline__ void emit_obs8(const DevParams &p, const EnvRegs &e, float *o)
+{
+    double hs, hc;
+    emit_obs8(p, e, o, hs, hc);
 }
 
 __device__ __forceinline__ void store_obs8(const DevParams &p, int env, const float *o)
@@ -349,25 +354,40 @@ __device__ __forceinline__ void store_counters(const DevParams &p, int env, int 
     }
 }
 
-// MuJoCo mj_step for point.xml: 3 dof (slide x, slide y, hinge z), offset COM, implicit
-// joint damping, no active constraints.  Operation order is the
-// oracle's, token for token.
-__device__ __forceinline__ void mj_substep(const DevParams &p, EnvRegs &e, double c0, double c1)
+// The frameskip mj_step calls of one Engine.step for point.xml: 3 dof (slide x, slide y, hinge z), offset COM,
+// implicit joint damping, no active constraints.  Operation order is the oracle's
+// (oracle/zenv_oracle.c: mj_env_step), token for token:
+//   * sin/cos of the hinge angle come from the half-angle pair (hs, hc) the observation's quaternion needs anyway
+//     (one det_sincos per env step instead of eleven) and are then TURNED by d = h*omega after every substep with
+//     short Taylor kernels of sin d / cos d (|d| < 0.05 by config validation; 0.01 for point.xml);
+//   * (M + h diag(b)) qacc = qfrc is solved by the Schur complement on the hinge row, which for equal slide damping
+//     (p.iso) does not depend on the angle: a multiplication by p.inv_den replaces the division;
+//   * the controls are finite here (a NaN action takes the exception path before the physics), so the force clamps
+//     are v_min_f64 / v_max_f64 -- same values as the oracle's compare-and-select for every finite input.
+__device__ __forceinline__ double clamp_sym(double x, double lim)
 {
-    double s, k;
-    det_sincos_inl(e.q2, s, k);
+    return __builtin_fmax(__builtin_fmin(x, lim), -lim);
+}
+
+template <bool ISO>
+__device__ __forceinline__ void physics_substep(const DevParams &p, EnvRegs &e, double gf0, double kvc1, double &s,
+                                                double &k)
+{
     const double mcs = p.mc * s, mck = p.mc * k;
     const double w2 = e.v2 * e.v2;
-    const double f0 = det_clamp(c0, -p.fmax, p.fmax);
-    const double f1 = det_clamp(__builtin_fma(-p.kv, p.gear * e.v2, p.kv * c1), -p.fmax, p.fmax);
-    const double gf0 = p.gear * f0;
+    const double f1 = clamp_sym(__builtin_fma(-p.kvg, e.v2, kvc1), p.fmax);
     const double rhs0 = __builtin_fma(-p.b0, e.v0, __builtin_fma(mck, w2, gf0 * k));
     const double rhs1 = __builtin_fma(-p.b1, e.v1, __builtin_fma(mcs, w2, gf0 * s));
     const double rhs2 = __builtin_fma(-p.b2, e.v2, p.gear * f1);
     const double t0 = rhs0 * p.inv00, t1 = rhs1 * p.inv11;
-    const double den = __builtin_fma(-(mck * mck), p.inv11, __builtin_fma(-(mcs * mcs), p.inv00, p.A22));
     const double num = __builtin_fma(-mck, t1, __builtin_fma(mcs, t0, rhs2));
-    const double a2 = num / den;
+    double a2;
+    if (ISO) {
+        a2 = num * p.inv_den;
+    } else {
+        const double den = __builtin_fma(-(mck * mck), p.inv11, __builtin_fma(-(mcs * mcs), p.inv00, p.A22));
+        a2 = num / den;
+    }
     const double a0 = __builtin_fma(mcs, a2, rhs0) * p.inv00;
     const double a1 = __builtin_fma(-mck, a2, rhs1) * p.inv11;
     e.v0 = __builtin_fma(p.h, a0, e.v0);
@@ -376,6 +396,39 @@ __device__ __forceinline__ void mj_substep(const DevParams &p, EnvRegs &e, doubl
     e.q0 = __builtin_fma(p.h, e.v0, e.q0);
     e.q1 = __builtin_fma(p.h, e.v1, e.q1);
     e.q2 = __builtin_fma(p.h, e.v2, e.q2);
+    // (s, k) <- sin / cos(theta + d), d = h * omega
+    const double d = p.h * e.v2;
+    const double z = d * d;
+    double ps = __builtin_fma(z, 1.0 / 362880.0, -1.0 / 5040.0);
+    ps = __builtin_fma(z, ps, 1.0 / 120.0);
+    ps = __builtin_fma(z, ps, -1.0 / 6.0);
+    const double sd = __builtin_fma(d, z * ps, d);
+    double pc = __builtin_fma(z, -1.0 / 3628800.0, 1.0 / 40320.0);
+    pc = __builtin_fma(z, pc, -1.0 / 720.0);
+    pc = __builtin_fma(z, pc, 1.0 / 24.0);
+    pc = __builtin_fma(z, pc, -0.5);
+    const double cd = __builtin_fma(z, pc, 1.0);
+    const double s2 = __builtin_fma(k, sd, s * cd);
+    const double k2 = __builtin_fma(-s, sd, k * cd);
+    s = s2;
+    k = k2;
+}
+
+// c0, c1: the clipped controls; hs, hc: sin / cos of half the hinge angle on entry
+__device__ __forceinline__ void physics_step(const DevParams &p, EnvRegs &e, double c0, double c1, double hs, double hc)
+{
+    double s = 2.0 * (hs * hc);
+    double k = __builtin_fma(hc, hc, -(hs * hs));
+    const double gf0 = p.gear * clamp_sym(c0, p.fmax);
+    const double kvc1 = p.kv * c1;
+    // one wave-uniform branch per env step, not per substep
+    if (p.iso) {
+#pragma unroll ZENV_SUBSTEP_UNROLL
+        for (int i = 0; i < p.frameskip; ++i) physics_substep<true>(p, e, gf0, kvc1, s, k);
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < p.frameskip; ++i) physics_substep<false>(p, e, gf0, kvc1, s, k);
+    }
 }
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -1097,8 +1150,11 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             const double c0 = det_clamp((double)act.x, -1.0, 1.0);
             const double c1 = det_clamp((double)act.y, -1.0, 1.0);
             ZSTAMP(9);
-#pragma unroll ZENV_SUBSTEP_UNROLL
-            for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
+            {
+                double hs, hc;
+                det_sincos_inl(0.5 * e.q2, hs, hc);
+                physics_step(p, e, c0, c1, hs, hc);
+            }
             if (!(c0 == c0 && c1 == c1)) {
                 // exception path (see the zone wave): what mj_resetData leaves -- qpos = qpos0, qvel = 0
                 e.q0 = e.q1 = e.q2 = 0.0;
@@ -1472,9 +1528,16 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
 
     // ======================================================================= env wave
     if (!kStreamFirst) __builtin_amdgcn_s_setprio(3);
+    // Everything the steady state of the loop does not touch -- the bank, the schedule, the state arrays, the episode
+    // counters -- is read through the device copy of the parameter block, at the point of use inside the rare
+    // branches (episode end, reset, rim test) and in the epilogue.  As by-value kernel arguments those ~25 pointers
+    // are loaded at kernel entry and live across the whole loop: beyond the 102 SGPRs, i.e. v_readlane / v_writelane
+    // spill traffic on the env wave's critical path in every step.
+    const DevParams &pc = *p.self;
     EnvRegs e;
     bool frozen = false;
     double ep_ret = 0.0;
+    double hs = 0.0, hc = 1.0;     // sin / cos of half the hinge angle, carried from obs to the next step's physics
     int epi_idx = 0, slot_first = 0;
     float2 act = make_float2(0.f, 0.f);
     float4 zp[ZH];
@@ -1493,6 +1556,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
         e.v0 = qb.y; e.v1 = qc.x; e.v2 = qc.y;
         e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
         act = reinterpret_cast<const float2 *>(p.actions)[env];
+        det_sincos_inl(0.5 * e.q2, hs, hc);
         frozen = p.done_state[env] != 0;
         e.steps = p.steps[env];
         if (kColour) {
@@ -1572,9 +1636,9 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 // the rim: exact float64 test on the float64 zone centres (rare, divergent)
                 const int z = __ffs((int)(amb_mask & full)) - 1;
                 amb_mask &= ~(1u << z);
-                const double2 zz = p.zxy[(size_t)z * N + env];
+                const double2 zz = pc.zxy[(size_t)z * N + env];
                 const double dx = zz.x - rx, dy = zz.y - ry;
-                if (dx * dx + dy * dy <= p.hit_d2) in_mask |= 1u << z;
+                if (dx * dx + dy * dy <= pc.hit_d2) in_mask |= 1u << z;
             }
             if (!kColour) elig_mask = ~e.vis;
             const uint32_t hits = in_mask & elig_mask & full;
@@ -1586,7 +1650,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                     e.colpack = (e.colpack & ~(3ull << (2 * first))) | ((uint64_t)col << (2 * first));
 #pragma unroll
                     for (int z = 0; z < ZT; ++z)
-                        if (z == first) auxr[z] = p.max_cd;
+                        if (z == first) auxr[z] = pc.max_cd;
                 } else {
                     e.vis |= 1u << first;
                 }
@@ -1623,10 +1687,10 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
             p.visit_count[env] = kColour ? e.goal_dist : __popc(e.vis);
 #endif
             if (done) {
-                p.last_return[env] = ep_ret;
-                p.last_len[env] = k;
-                p.episodes[env] += 1;
-                p.exception[env] = 0;
+                pc.last_return[env] = ep_ret;
+                pc.last_len[env] = k;
+                pc.episodes[env] += 1;
+                pc.exception[env] = 0;
             }
             need_reset = done && auto_reset;
             dword = kColour ? e.colpack
@@ -1640,11 +1704,10 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 2)   // diagnostic: bit 1 drops the physics
                 // unrolled by the default frameskip (a remainder loop covers other values): the rolled loop carried
                 // its state through 8 v_mov_b64 per substep (-3...5 % of the step time)
-#pragma unroll ZENV_SUBSTEP_UNROLL
-                for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
+                physics_step(p, e, c0, c1, hs, hc);
 #endif
                 if (t == (n_steps >> 1)) ZSTAMP(2);
-                emit_obs8(p, e, o);
+                emit_obs8(p, e, o, hs, hc);
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 8)   // diagnostic: bit 3 drops the env wave's per-step global stores
                 store_obs8(p, env, o);
 #endif
@@ -1655,7 +1718,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                     act = greedy_action_regs<TASK, ZT>(zp, auxr, e.vis, e.colpack, o[1], o[2], o[3], o[4]);
 #endif
                 if (done) {          // finished, no auto-reset: frozen from the next step on
-                    p.done_state[env] = 1;
+                    pc.done_state[env] = 1;
                     frozen = true;
                 }
             }
@@ -1667,7 +1730,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
             lds_ctr_wait(ctr + 1, t);     // flush(t-1) has read the static entries about to change
             int my_slot = 0;
             if (need_reset) {
-                my_slot = next_bank_slot(p, env, epi_idx, slot_first);
+                my_slot = next_bank_slot(pc, env, epi_idx, slot_first);
                 epi_idx += 1;
             }
             while (pending) {
@@ -1675,20 +1738,20 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 pending &= pending - 1;
                 const int slot = __shfl(my_slot, j);
                 const int env_j = env0 + j;
-                const double *br = p.bank_robot + 4 * (size_t)slot;
+                const double *br = pc.bank_robot + 4 * (size_t)slot;
                 const double b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];
-                int code = kColour ? 0 : (int)((p.vis0 >> (lane & 31)) & 1u), aux = 0;   // pre-visited zones
+                int code = kColour ? 0 : (int)((pc.vis0 >> (lane & 31)) & 1u), aux = 0;   // pre-visited zones
                 float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (lane < Z) {
                     const size_t bi = (size_t)slot * Z + lane;
-                    const double2 zz = reinterpret_cast<const double2 *>(p.bank_zone)[bi];
+                    const double2 zz = reinterpret_cast<const double2 *>(pc.bank_zone)[bi];
                     const size_t zi = (size_t)lane * N + env_j;
-                    p.zxy[zi] = zz;
+                    pc.zxy[zi] = zz;
                     if (TASK == ZENV_TASK_TIMED_TSP) {
-                        aux = p.bank_aux[bi];
-                        p.tmax[zi] = aux;
+                        aux = pc.bank_aux[bi];
+                        pc.tmax[zi] = aux;
                     } else if (kColour) {
-                        code = p.bank_aux[bi];
+                        code = pc.bank_aux[bi];
                     }
                     en = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
                     sent[j * Z + lane] = make_static<TASK>(en.x, en.y, aux);
@@ -1696,7 +1759,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 {
                     const float nx = __shfl_down(en.x, 1), ny = __shfl_down(en.y, 1);
                     if (lane < Z && !(lane & 1))
-                        p.zpf[(size_t)(lane >> 1) * N + env_j] =
+                        pc.zpf[(size_t)(lane >> 1) * N + env_j] =
                             make_float4(en.x, en.y, lane + 1 < Z ? nx : 0.f, lane + 1 < Z ? ny : 0.f);
                 }
                 uint64_t colpack = 0ull;
@@ -1709,7 +1772,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 fresh.x0 = b0; fresh.y0 = b1; fresh.bq0 = b2; fresh.bq3 = b3;
                 fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
                 fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
-                fresh.vis = kColour ? 0u : p.vis0;
+                fresh.vis = kColour ? 0u : pc.vis0;
                 fresh.colpack = colpack;
                 fresh.goal_dist = kColour ? hamming_to_goal(colpack, Z) : 0;
                 fresh.steps = 0;
@@ -1741,9 +1804,11 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                     }
                     e = fresh;
                     ep_ret = 0.0;
+                    hs = 0.0;
+                    hc = 1.0;
                     act = next_act;
-                    dword = kColour ? colpack : (uint64_t)p.vis0;   // only the pre-visited zones, step count 0
-                    p.seed[env] = p.bank_seed[slot];
+                    dword = kColour ? colpack : (uint64_t)pc.vis0;   // only the pre-visited zones, step count 0
+                    pc.seed[env] = pc.bank_seed[slot];
                     store_obs8(p, env, of);
                 }
             }
@@ -1784,13 +1849,13 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
 
     // ---- the registers go back to the state arrays
     if (valid) {
-        store_dyn(p, env, e);
-        store_frame(p, env, e);
-        store_counters(p, env, TASK, e);
-        p.ep_return[env] = ep_ret;
+        store_dyn(pc, env, e);
+        store_frame(pc, env, e);
+        store_counters(pc, env, TASK, e);
+        pc.ep_return[env] = ep_ret;
         if (kColour) {
 #pragma unroll
-            for (int z = 0; z < ZT; ++z) p.cooldown[(size_t)z * N + env] = (uint8_t)auxr[z];
+            for (int z = 0; z < ZT; ++z) pc.cooldown[(size_t)z * N + env] = (uint8_t)auxr[z];
         }
         if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = act;
     }
@@ -2105,7 +2170,11 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
     // ---- Engine.step: ctrl = clip(action, ctrlrange); frameskip x mj_step (wave-uniform)
     const double c0 = det_clamp((double)act.x, -1.0, 1.0);
     const double c1 = det_clamp((double)act.y, -1.0, 1.0);
-    for (int i = 0; i < p.frameskip; ++i) mj_substep(p, e, c0, c1);
+    {
+        double hs, hc;
+        det_sincos_inl(0.5 * e.q2, hs, hc);
+        physics_step(p, e, c0, c1, hs, hc);
+    }
     if (exc) {
         e.q0 = e.q1 = e.q2 = 0.0;
         e.v0 = e.v1 = e.v2 = 0.0;

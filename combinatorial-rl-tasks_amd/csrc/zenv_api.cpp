@@ -58,6 +58,9 @@ struct zenv {
     hipStream_t stream = nullptr;       // the stream work is enqueued on
     hipStream_t own_stream = nullptr;   // created with the handle; `stream` unless zenv_set_stream
     DevParams p{};
+    DevParams *d_self = nullptr;     // device copy of p (DevParams::self): the persistent kernel reads cold fields from it
+    DevParams self_shadow{};         // what d_self holds
+    bool self_valid = false;
     std::vector<Alloc> allocs;
     void *bank_mem[4] = { nullptr, nullptr, nullptr, nullptr };
     uint8_t *d_mask = nullptr;
@@ -117,6 +120,17 @@ int validate_config(const zenv_config &c)
         if (!(schur > 1e-12 * c.inertia_zz)) return fail(ZENV_E_ARG, "inertia_zz must exceed mass * com_x^2");
         if (!(std::fabs(c.gear) * c.forcerange < 1e6 * std::min(c.mass, schur)))
             return fail(ZENV_E_ARG, "actuator force out of proportion to the body's mass / inertia");
+        // The kernels turn sin/cos of the hinge angle by d = h * omega per substep with Taylor kernels good to
+        // |d| = 0.1.  |omega| stays below the servo's terminal speed plus the overshoot of its chatter (two
+        // force-clamped substeps): keep that bound under 0.05 rad per substep (point.xml: 0.0093).
+        const double torque = std::fabs(c.gear) * c.forcerange;
+        const double w_term = c.damping[2] > 0 ? torque / c.damping[2]
+                                               : (c.vel_kv * std::fabs(c.gear) > 0 ? 1.0 / std::fabs(c.gear) : 1e30);
+        const double w_servo = c.vel_kv * std::fabs(c.gear) > 0 ? 1.0 / std::fabs(c.gear) : w_term;   // |ctrl| <= 1
+        const double w_max = std::min(w_term, w_servo) + 2.0 * c.timestep * torque / schur;
+        if (!(c.timestep * w_max < 0.05))
+            return fail(ZENV_E_ARG, "the hinge can turn %.3g rad per substep: beyond the small-angle update (0.05)",
+                        c.timestep * w_max);
     }
     if (c.n_zones_locations < 0 || c.n_zones_locations > c.num_zones)
         return fail(ZENV_E_ARG, "n_zones_locations %d outside [0, num_zones]", c.n_zones_locations);
@@ -152,6 +166,10 @@ void derive_constants(const zenv_config &c, DevParams &p)
     p.A22 = c.inertia_zz + c.timestep * c.damping[2];
     p.inv00 = 1.0 / A00;
     p.inv11 = 1.0 / A11;
+    p.iso = c.damping[0] == c.damping[1];
+    p.pad_iso = 0;
+    p.inv_den = 1.0 / std::fma(-(p.mc * p.mc), p.inv00, p.A22);
+    p.kvg = c.vel_kv * c.gear;
     p.hit_d2 = sqrt_threshold(c.zones_size);
     {
         // prefilter shell: +-2e-6 on the radius, i.e. +-8e-7 on r^2 at r = 0.2 (4x the float error bound)
@@ -426,6 +444,8 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
         }
     }
     err = hipMalloc(reinterpret_cast<void **>(&h->d_mask), N);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&h->d_self), sizeof(DevParams));
+    if (err == hipSuccess) p.self = h->d_self;
     if (err == hipSuccess) err = hipStreamSynchronize(h->stream);
     if (err != hipSuccess) {
         zenv_destroy(h);
@@ -445,6 +465,7 @@ extern "C" int zenv_destroy(zenv_t *h)
     for (void *m : h->bank_mem)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
+    if (h->d_self) (void)hipFree(h->d_self);
     for (void *m : { h->mlp_mem, h->mlp_pooled, (void *)h->mlp_mu, (void *)h->mlp_std, (void *)h->mlp_value,
                      (void *)h->p.visit_zone, (void *)h->p.term_xy, (void *)h->p.goal, (void *)h->p.goal_last,
                      (void *)h->p.goal_xy, (void *)h->p.shaped, (void *)h->p.need_goal, (void *)h->p.available,
@@ -947,6 +968,18 @@ extern "C" int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t
 
 static constexpr int kRolloutChunk = ZENV_ROLLOUT_CHUNK;   // steps per launch of the persistent kernel
 
+// Bring the device copy of the parameter block up to date (it changes with the bank, the schedule, a redirected
+// output buffer ...: rarely, so one comparison per rollout call and a copy only when something did change).
+static int ensure_self(zenv_t *h)
+{
+    if (h->self_valid && std::memcmp(&h->p, &h->self_shadow, sizeof(DevParams)) == 0) return ZENV_OK;
+    h->self_shadow = h->p;
+    HIP_TRY(hipMemcpyAsync(h->d_self, &h->self_shadow, sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the source is host memory that the next change overwrites
+    h->self_valid = true;
+    return ZENV_OK;
+}
+
 extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
                             int auto_reset, int flags, int event_stride, float *ms_total, float *ms_step_kernel_avg)
 {
@@ -980,6 +1013,10 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     const bool have_a0 = fused && h->act_tag.valid && h->act_tag.policy == policy && h->act_tag.seed == policy_seed &&
                          h->act_tag.index0 == env_index0 && h->act_tag.step == h->step_count;
     h->act_tag.valid = false;
+    if (persistent && steps > 0) {
+        rc = ensure_self(h);
+        if (rc) return rc;
+    }
     HIP_TRY(hipEventRecord(h->events[0], h->stream));
     if (persistent && steps > 0) {
         StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };

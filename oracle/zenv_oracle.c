@@ -374,10 +374,39 @@ static double clampd(double x, double lo, double hi) { return x < lo ? lo : (x >
 /* [UPSTREAM] mju_isBad (engine_util_misc.c): NaN or beyond mjMAXVAL = 1e10 */
 static int is_bad(double x) { return x != x || x > 1e10 || x < -1e10; }
 
-/* One mj_step.  Returns 1 when mj_checkAcc would have raised mjWARN_BADQACC (some qacc is bad): MuJoCo then
- * resets the data (qpos = qpos0, qvel = 0) and runs mj_forward, and mujoco-py turns the warning into a
- * MujocoException once the call returns. */
-static int mj_substep(orc_env *e, const double ctrl[2])
+/* (s, k) = sin/cos(theta) -> sin/cos(theta + d) for the small angle d = h * omega that one substep turns the hinge by:
+ * Taylor kernels of sin d through d^9 and of cos d through d^10 (truncation < 3e-19 for |d| <= 0.1; the product's
+ * config validation keeps |d| below 0.05, point.xml reaches 0.01) and the angle-sum formulas.  MuJoCo evaluates
+ * sin/cos of the joint angle afresh in every mj_kinematics; re-anchoring on the exact sincos once per env step
+ * (mj_env_step) keeps this within a few 1e-16 of that -- tests/test_dynamics_independent.py measures it. */
+static void rotate_small(double d, double *s, double *k)
+{
+    double z = d * d;
+    double ps = FMA(z, 1.0 / 362880.0, -1.0 / 5040.0);
+    ps = FMA(z, ps, 1.0 / 120.0);
+    ps = FMA(z, ps, -1.0 / 6.0);
+    double sd = FMA(d, z * ps, d);
+    double pc = FMA(z, -1.0 / 3628800.0, 1.0 / 40320.0);
+    pc = FMA(z, pc, -1.0 / 720.0);
+    pc = FMA(z, pc, 1.0 / 24.0);
+    pc = FMA(z, pc, -0.5);
+    double cd = FMA(z, pc, 1.0);
+    double s2 = FMA(*k, sd, *s * cd);
+    double k2 = FMA(-*s, sd, *k * cd);
+    *s = s2;
+    *k = k2;
+}
+
+/* The frameskip mj_step calls of one Engine.step for point.xml: 3 dof (slide x, slide y, hinge z), offset COM,
+ * implicit joint damping, no active constraints.  Returns 1 when mj_checkAcc would have
+ * raised mjWARN_BADQACC in some substep (a qacc is bad): MuJoCo then resets the data (qpos = qpos0, qvel = 0), and
+ * mujoco-py turns the warning into a MujocoException once the call returns.
+ *
+ * (M + h diag(b)) qacc = qfrc with M = [[m,0,-mc s],[0,m,mc k],[-mc s,mc k,I0]] is solved by the Schur complement
+ * on the hinge row.  With equal damping on the two slides (point.xml: 0.01 and 0.01) that complement,
+ * I0 + h b2 - (mc)^2 (s^2 + k^2) / (m + h b), does not depend on the angle: one host-side reciprocal replaces the
+ * division of every substep.  Operation order is what the HIP kernels execute, token for token. */
+static int mj_env_step(orc_env *e, const double ctrl[2])
 {
     const orc_config *c = &e->cfg;
     const double h = c->timestep, g = c->gear, F = c->forcerange;
@@ -386,38 +415,52 @@ static int mj_substep(orc_env *e, const double ctrl[2])
     const double A11 = c->mass + h * c->damping[1];
     const double A22 = c->inertia_zz + h * c->damping[2];
     const double inv00 = 1.0 / A00, inv11 = 1.0 / A11;
+    const int iso = c->damping[0] == c->damping[1];
+    const double inv_den = 1.0 / FMA(-(mc * mc), inv00, A22);
+    const double kvg = c->vel_kv * g;
     double *q = e->qpos, *v = e->qvel;
 
-    double s, k;
-    orc_sincos(q[2], &s, &k);
-    double mcs = mc * s, mck = mc * k;
-    double w2 = v[2] * v[2];
-    /* actuators: motor on site (gear .3 0 0 0 0 0); velocity servo on hinge (kv, gear .3) */
-    double f0 = clampd(ctrl[0], -F, F);
-    double f1 = clampd(FMA(-c->vel_kv, g * v[2], c->vel_kv * ctrl[1]), -F, F);
-    double gf0 = g * f0;
-    /* qfrc = passive(-b v) - bias(centrifugal of the offset COM) + actuator */
-    double rhs0 = FMA(-c->damping[0], v[0], FMA(mck, w2, gf0 * k));
-    double rhs1 = FMA(-c->damping[1], v[1], FMA(mcs, w2, gf0 * s));
-    double rhs2 = FMA(-c->damping[2], v[2], g * f1);
-    /* (M + h diag(b)) a = qfrc, M = [[m,0,-mcs],[0,m,mck],[-mcs,mck,I0]]  (implicit-damping Euler) */
-    double t0 = rhs0 * inv00, t1 = rhs1 * inv11;
-    double den = FMA(-(mck * mck), inv11, FMA(-(mcs * mcs), inv00, A22));
-    double num = FMA(-mck, t1, FMA(mcs, t0, rhs2));
-    double a2 = num / den;
-    double a0 = FMA(mcs, a2, rhs0) * inv00;
-    double a1 = FMA(-mck, a2, rhs1) * inv11;
-    if (is_bad(a0) || is_bad(a1) || is_bad(a2)) {
-        q[0] = q[1] = q[2] = 0.0;       /* mj_resetData */
-        v[0] = v[1] = v[2] = 0.0;
-        return 1;
+    /* sin/cos of the hinge angle from the half angle mj_kinematics' quaternion needs anyway */
+    double hs, hc;
+    orc_sincos(0.5 * q[2], &hs, &hc);
+    double s = 2.0 * (hs * hc);
+    double k = FMA(hc, hc, -(hs * hs));
+    /* actuators: motor on site (gear .3 0 0 0 0 0); velocity servo on hinge (kv, gear .3); both force-limited */
+    const double gf0 = g * clampd(ctrl[0], -F, F);
+    const double kvc1 = c->vel_kv * ctrl[1];
+    for (int i = 0; i < c->frameskip; i++) {
+        double mcs = mc * s, mck = mc * k;
+        double w2 = v[2] * v[2];
+        double f1 = clampd(FMA(-kvg, v[2], kvc1), -F, F);
+        /* qfrc = passive(-b v) - bias(centrifugal of the offset COM) + actuator */
+        double rhs0 = FMA(-c->damping[0], v[0], FMA(mck, w2, gf0 * k));
+        double rhs1 = FMA(-c->damping[1], v[1], FMA(mcs, w2, gf0 * s));
+        double rhs2 = FMA(-c->damping[2], v[2], g * f1);
+        double t0 = rhs0 * inv00, t1 = rhs1 * inv11;
+        double num = FMA(-mck, t1, FMA(mcs, t0, rhs2));
+        double a2;
+        if (iso) {
+            a2 = num * inv_den;
+        } else {
+            double den = FMA(-(mck * mck), inv11, FMA(-(mcs * mcs), inv00, A22));
+            a2 = num / den;
+        }
+        double a0 = FMA(mcs, a2, rhs0) * inv00;
+        double a1 = FMA(-mck, a2, rhs1) * inv11;
+        if (is_bad(a0) || is_bad(a1) || is_bad(a2)) {
+            q[0] = q[1] = q[2] = 0.0;       /* mj_resetData */
+            v[0] = v[1] = v[2] = 0.0;
+            return 1;
+        }
+        v[0] = FMA(h, a0, v[0]);
+        v[1] = FMA(h, a1, v[1]);
+        v[2] = FMA(h, a2, v[2]);
+        q[0] = FMA(h, v[0], q[0]);
+        q[1] = FMA(h, v[1], q[1]);
+        q[2] = FMA(h, v[2], q[2]);
+        /* the next substep's sin/cos: turn by d = h omega */
+        rotate_small(h * v[2], &s, &k);
     }
-    v[0] = FMA(h, a0, v[0]);
-    v[1] = FMA(h, a1, v[1]);
-    v[2] = FMA(h, a2, v[2]);
-    q[0] = FMA(h, v[0], q[0]);
-    q[1] = FMA(h, v[1], q[1]);
-    q[2] = FMA(h, v[2], q[2]);
     return 0;
 }
 
@@ -461,8 +504,7 @@ int orc_step(orc_env *e, const float action[2], double *reward, int *done, int *
     ctrl[0] = clampd((double)action[0], -1.0, 1.0);
     ctrl[1] = clampd((double)action[1], -1.0, 1.0);
     /* np.clip keeps a NaN action; `try: set_mocaps(); sim.step() except MujocoException: exception = True; break` */
-    for (int i = 0; i < c->frameskip; i++)
-        if (mj_substep(e, ctrl)) { e->exception = 1; break; }
+    e->exception = mj_env_step(e, ctrl);
     forward(e);   /* exception: obs() still runs sim.forward() on the reset data */
 
     if (e->exception) {
