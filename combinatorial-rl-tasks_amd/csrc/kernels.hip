@@ -50,10 +50,17 @@ constexpr int kWave = 64;
 #define ZSTAMP(slot) do { } while (0)
 #endif
 
+// Rows per flush chunk of the 6-float rows (RPC * 6 floats must be whole float4: 2 or 4).  4 halves the number of
+// expand -> slab -> store iterations of a 25-zone tile (13 -> 7), which is what made PointTSP-25 flush slower per byte
+// than TimedTSP-25's 7-float rows.
+#ifndef ZENV_RPC6
+#define ZENV_RPC6 4
+#endif
+
 template <int TASK>
 struct TaskTraits {
     static constexpr int F = (TASK == ZENV_TASK_TSP) ? 6 : 7;        // floats per zone row
-    static constexpr int RPC = (F == 6) ? 2 : 4;                     // rows per flush chunk
+    static constexpr int RPC = (F == 6) ? ZENV_RPC6 : 4;             // rows per flush chunk (RPC * F floats = G float4)
     static constexpr int G = RPC * F / 4;                            // float4 per flush chunk
 };
 
@@ -82,7 +89,9 @@ __device__ __forceinline__ void pcg_step_dev(uint64_t &hi, uint64_t &lo, uint64_
     lo = nlo;
 }
 
-__device__ __forceinline__ uint32_t pcg_next32_dev(const DevParams &p, int env)
+// (P = DevParams, or the same block seen through the constant address space: see k_rollout_lane)
+template <typename P>
+__device__ __forceinline__ uint32_t pcg_next32_dev(const P &p, int env)
 {
     uint32_t *buf = p.pcg_buf + 2 * (size_t)env;
     if (buf[0]) {
@@ -104,7 +113,8 @@ __device__ __forceinline__ uint32_t pcg_next32_dev(const DevParams &p, int env)
 
 // Bank slot of env's next episode (and advance the schedule).  episode index / first slot are
 // passed in when the caller has already loaded them.
-__device__ __forceinline__ int next_bank_slot(const DevParams &p, int env, int k, int first)
+template <typename P>
+__device__ __forceinline__ int next_bank_slot(const P &p, int env, int k, int first)
 {
     p.episode_idx[env] = k + 1;
     if (p.sched_mode == SCHED_SEQUENTIAL) {
@@ -126,7 +136,8 @@ __device__ __forceinline__ int next_bank_slot(const DevParams &p, int env, int k
     }
     return (int)(m >> 32);
 }
-__device__ __forceinline__ int next_bank_slot(const DevParams &p, int env)
+template <typename P>
+__device__ __forceinline__ int next_bank_slot(const P &p, int env)
 {
     return next_bank_slot(p, env, p.episode_idx[env], p.slot_first[env]);
 }
@@ -330,20 +341,23 @@ __device__ __forceinline__ void reset_env(const DevParams &p, int env, int slot,
     p.seed[env] = p.bank_seed[slot];
 }
 
-__device__ __forceinline__ void store_dyn(const DevParams &p, int env, const EnvRegs &e)
+template <typename P>
+__device__ __forceinline__ void store_dyn(const P &p, int env, const EnvRegs &e)
 {
     p.qa[env] = make_double2(e.q0, e.q1);
     p.qb[env] = make_double2(e.q2, e.v0);
     p.qc[env] = make_double2(e.v1, e.v2);
 }
 
-__device__ __forceinline__ void store_frame(const DevParams &p, int env, const EnvRegs &e)
+template <typename P>
+__device__ __forceinline__ void store_frame(const P &p, int env, const EnvRegs &e)
 {
     p.fa[env] = make_double2(e.x0, e.y0);
     p.fb[env] = make_double2(e.bq0, e.bq3);
 }
 
-__device__ __forceinline__ void store_counters(const DevParams &p, int env, int task, const EnvRegs &e)
+template <typename P>
+__device__ __forceinline__ void store_counters(const P &p, int env, int task, const EnvRegs &e)
 {
     p.steps[env] = e.steps;
     if (task == ZENV_TASK_COLOUR_MATCH) {
@@ -415,15 +429,21 @@ __device__ __forceinline__ void physics_substep(const DevParams &p, EnvRegs &e, 
 }
 
 // c0, c1: the clipped controls; hs, hc: sin / cos of half the hinge angle on entry
-__device__ __forceinline__ void physics_step(const DevParams &p, EnvRegs &e, double c0, double c1, double hs, double hc)
+// straight10: frameskip == 10, the reference's value -- ten substeps as straight-line code (a runtime trip count costs
+// the unrolled loop its remainder loop and a set of register copies between the two)
+__device__ __forceinline__ void physics_step(const DevParams &p, EnvRegs &e, double c0, double c1, double hs, double hc,
+                                             bool straight10)
 {
     double s = 2.0 * (hs * hc);
     double k = __builtin_fma(hc, hc, -(hs * hs));
     const double gf0 = p.gear * clamp_sym(c0, p.fmax);
     const double kvc1 = p.kv * c1;
     // one wave-uniform branch per env step, not per substep
-    if (p.iso) {
-#pragma unroll ZENV_SUBSTEP_UNROLL
+    if (p.iso && straight10) {
+#pragma unroll
+        for (int i = 0; i < ZENV_SUBSTEP_UNROLL; ++i) physics_substep<true>(p, e, gf0, kvc1, s, k);
+    } else if (p.iso) {
+#pragma unroll 1
         for (int i = 0; i < p.frameskip; ++i) physics_substep<true>(p, e, gf0, kvc1, s, k);
     } else {
 #pragma unroll 1
@@ -1153,7 +1173,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             {
                 double hs, hc;
                 det_sincos_inl(0.5 * e.q2, hs, hc);
-                physics_step(p, e, c0, c1, hs, hc);
+                physics_step(p, e, c0, c1, hs, hc, p.frameskip == ZENV_SUBSTEP_UNROLL);
             }
             if (!(c0 == c0 && c1 == c1)) {
                 // exception path (see the zone wave): what mj_resetData leaves -- qpos = qpos0, qvel = 0
@@ -1532,13 +1552,16 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
     // counters -- is read through the device copy of the parameter block, at the point of use inside the rare
     // branches (episode end, reset, rim test) and in the epilogue.  As by-value kernel arguments those ~25 pointers
     // are loaded at kernel entry and live across the whole loop: beyond the 102 SGPRs, i.e. v_readlane / v_writelane
-    // spill traffic on the env wave's critical path in every step.
-    const DevParams &pc = *p.self;
+    // spill traffic on the env wave's critical path in every step.  The copy is read through the CONSTANT address
+    // space: uniform loads from it are scalar loads (s_load, lgkmcnt) -- as plain global loads they would be vector
+    // loads whose s_waitcnt vmcnt(0) also drains the wave's outstanding observation stores.
+    typedef const __attribute__((address_space(4))) DevParams ConstDevParams;
+    const ConstDevParams &pc = *reinterpret_cast<ConstDevParams *>(reinterpret_cast<uintptr_t>(p.self));
     EnvRegs e;
     bool frozen = false;
     double ep_ret = 0.0;
     double hs = 0.0, hc = 1.0;     // sin / cos of half the hinge angle, carried from obs to the next step's physics
-    int epi_idx = 0, slot_first = 0;
+    int epi_idx = 0, slot_first = 0, vcount = 0;
     float2 act = make_float2(0.f, 0.f);
     float4 zp[ZH];
     int auxr[ZT];
@@ -1566,6 +1589,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
             e.vis = p.vis[env];
         }
         ep_ret = p.ep_return[env];
+        vcount = p.visit_count[env];
         epi_idx = p.episode_idx[env];
         slot_first = p.slot_first[env];
 #pragma unroll
@@ -1585,144 +1609,147 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
     if (lane < 4) ctr[lane] = 0;
     __syncthreads();   // the only barrier of the launch
 
+    auto write_back = [&](const EnvRegs &er, double ret) {
+        store_dyn(pc, env, er);
+        store_frame(pc, env, er);
+        store_counters(pc, env, TASK, er);
+        pc.ep_return[env] = ret;
+        if (kColour) {
+#pragma unroll
+            for (int z = 0; z < ZT; ++z) pc.cooldown[(size_t)z * N + env] = (uint8_t)auxr[z];
+        }
+    };
+    // A step is written so that its common case has no divergent branch: every lane of the wave runs the zone pass,
+    // the reward logic, the physics and the policy on its registers -- lanes without a live env (frozen, or beyond N in
+    // the last tile) on harmless zero state -- and only the global stores and the rare events (rim test, episode end,
+    // reset, frozen env) sit behind exec masks.
+    const bool fs10 = p.frameskip == ZENV_SUBSTEP_UNROLL;
     for (int t = 0; t < n_steps; ++t) {
         StepPolicy polt = pol;
         polt.step_index = pol.step_index + (uint32_t)t;
-        float rew_out = 0.f;
-        uint8_t done_out = 1, goal_out = 0;
-        bool need_reset = false;
-        int first = -1;
-        uint64_t dword = kDynZero;
-        float o[8];
+        const bool live = valid && !frozen;
         if (t == (n_steps >> 1)) ZSTAMP(0);
-        if (valid && frozen) {
-            // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
-            for (int i = 0; i < 8; ++i) o[i] = 0.f;
-            store_obs8(p, env, o);
-            if (pol.policy >= 0) act = make_float2(0.f, 0.f);   // what either policy kernel makes of a zero obs
-        } else if (valid) {
-            const int k = e.steps + 1;
-            double rx, ry;
-            world_pos(e, rx, ry);          // set_mocaps() sees the PRE-physics pose
-            // ---- zone pass (see k_step_lane), entirely on registers
-            const float rxf = (float)rx, ryf = (float)ry;
-            // d2f >= +0, so its bit pattern orders like its value: "d2f < d2_lo" is the borrow of an
-            // integer subtraction, shifted into the mask with one v_alignbit (zones visited from the
-            // top so that zone z ends up in bit z).  A NaN pose sorts above d2_hi: outside, as before.
-            uint32_t in_mask = 0u, out_mask = 0u, elig_mask = 0u, expired = 0u;
-            const uint32_t lo_bits = __float_as_uint(p.d2_lo), hi_bits = __float_as_uint(p.d2_hi);
+        const int k = e.steps + 1;
+        double rx, ry;
+        world_pos(e, rx, ry);          // set_mocaps() sees the PRE-physics pose
+        // ---- zone pass (see k_step_lane), entirely on registers
+        const float rxf = (float)rx, ryf = (float)ry;
+        // d2f >= +0, so its bit pattern orders like its value: "d2f < d2_lo" is the borrow of an
+        // integer subtraction, shifted into the mask with one v_alignbit (zones visited from the
+        // top so that zone z ends up in bit z).
+        uint32_t in_mask = 0u, out_mask = 0u, elig_mask = 0u, expired = 0u;
+        const uint32_t lo_bits = __float_as_uint(p.d2_lo), hi_bits = __float_as_uint(p.d2_hi);
 #pragma unroll
-            for (int z = ZT - 1; z >= 0; --z) {
-                const float4 pr = zp[z >> 1];
-                const float x3 = (z & 1) ? pr.z : pr.x, y3 = (z & 1) ? pr.w : pr.y;
-                const float dxf = __builtin_fmaf(3.f, x3, -rxf), dyf = __builtin_fmaf(3.f, y3, -ryf);
-                const uint32_t d2b = __float_as_uint(__builtin_fmaf(dxf, dxf, dyf * dyf));
-                in_mask = __builtin_amdgcn_alignbit(in_mask, d2b - lo_bits, 31);       // d2f <  d2_lo
-                out_mask = __builtin_amdgcn_alignbit(out_mask, hi_bits - d2b, 31);     // d2f >  d2_hi
-                if (kColour) {
-                    const int cd = max(auxr[z] - 1, 0);         // colour_match_env.py:98-100
-                    auxr[z] = cd;
-                    elig_mask = __builtin_amdgcn_alignbit(elig_mask, (uint32_t)(cd - 1), 31);          // cd == 0
-                } else if (TASK == ZENV_TASK_TIMED_TSP) {
-                    expired = __builtin_amdgcn_alignbit(expired, (uint32_t)(auxr[z] - (k + 1)), 31);   // tmax - k <= 0, TTSP_env.py:67
-                }
-            }
-            if (!(rxf == rxf && ryf == ryf)) {   // NaN pose (its sign bit is arbitrary): every zone is outside
-                in_mask = 0u;
-                out_mask = ~0u;
-            }
-            uint32_t amb_mask = ~(in_mask | out_mask);
-            while (amb_mask & full) {
-                // the rim: exact float64 test on the float64 zone centres (rare, divergent)
-                const int z = __ffs((int)(amb_mask & full)) - 1;
-                amb_mask &= ~(1u << z);
-                const double2 zz = pc.zxy[(size_t)z * N + env];
-                const double dx = zz.x - rx, dy = zz.y - ry;
-                if (dx * dx + dy * dy <= pc.hit_d2) in_mask |= 1u << z;
-            }
-            if (!kColour) elig_mask = ~e.vis;
-            const uint32_t hits = in_mask & elig_mask & full;
-            first = hits ? __ffs((int)hits) - 1 : -1;                // lowest index wins, one per step
-            if (first >= 0) {
-                if (kColour) {
-                    int col = (int)((e.colpack >> (2 * first)) & 3ull);
-                    col = (col == 2) ? 0 : col + 1;                  // Blue->Green->Red->Blue
-                    e.colpack = (e.colpack & ~(3ull << (2 * first))) | ((uint64_t)col << (2 * first));
-#pragma unroll
-                    for (int z = 0; z < ZT; ++z)
-                        if (z == first) auxr[z] = pc.max_cd;
-                } else {
-                    e.vis |= 1u << first;
-                }
-            }
-            const bool timed_out = TASK == ZENV_TASK_TIMED_TSP && (expired & ~e.vis & full) != 0u;
-            // ---- reward / goal / termination (Engine.step order).  No exception path here (see k_step_lane): this
-            // kernel's actions come from the scripted on-device policies only, which are finite by construction.
-            double r = 0.0;
-            bool goal = false;
-            bool done = false;
+        for (int z = ZT - 1; z >= 0; --z) {
+            const float4 pr = zp[z >> 1];
+            const float x3 = (z & 1) ? pr.z : pr.x, y3 = (z & 1) ? pr.w : pr.y;
+            const float dxf = __builtin_fmaf(3.f, x3, -rxf), dyf = __builtin_fmaf(3.f, y3, -ryf);
+            const uint32_t d2b = __float_as_uint(__builtin_fmaf(dxf, dxf, dyf * dyf));
+            in_mask = __builtin_amdgcn_alignbit(in_mask, d2b - lo_bits, 31);       // d2f <  d2_lo
+            out_mask = __builtin_amdgcn_alignbit(out_mask, hi_bits - d2b, 31);     // d2f >  d2_hi
             if (kColour) {
-                if (first >= 0) {
-                    const int nd = hamming_to_goal(e.colpack, Z);
-                    r = (double)(e.goal_dist - nd);
-                    e.goal_dist = nd;
-                }
-                goal = e.goal_dist == 0;
-            } else {
-                r = first >= 0 ? 1.0 : 0.0;
-                goal = (e.vis & full) == full;
-            }
-            if (goal) {
-                r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
-                done = true;
-                goal_out = 1;
-            }
-            e.steps = k;
-            if (k >= p.num_steps) done = true;
-            if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
-            ep_ret = ep_ret + r;
-            rew_out = (float)r;
-            done_out = done ? 1 : 0;
-#if !defined(ZENV_EXP) || !(ZENV_EXP & 8)
-            p.visit_count[env] = kColour ? e.goal_dist : __popc(e.vis);
-#endif
-            if (done) {
-                pc.last_return[env] = ep_ret;
-                pc.last_len[env] = k;
-                pc.episodes[env] += 1;
-                pc.exception[env] = 0;
-            }
-            need_reset = done && auto_reset;
-            dword = kColour ? e.colpack
-                            : ((uint64_t)e.vis | (TASK == ZENV_TASK_TIMED_TSP ? (uint64_t)(uint32_t)k << 32 : 0ull));
-
-            if (t == (n_steps >> 1)) ZSTAMP(1);
-            if (!need_reset) {
-                // ---- Engine.step: ctrl = clip(action, ctrlrange); frameskip x mj_step; obs; next action
-                const double c0 = det_clamp((double)act.x, -1.0, 1.0);
-                const double c1 = det_clamp((double)act.y, -1.0, 1.0);
-#if !defined(ZENV_EXP) || !(ZENV_EXP & 2)   // diagnostic: bit 1 drops the physics
-                // unrolled by the default frameskip (a remainder loop covers other values): the rolled loop carried
-                // its state through 8 v_mov_b64 per substep (-3...5 % of the step time)
-                physics_step(p, e, c0, c1, hs, hc);
-#endif
-                if (t == (n_steps >> 1)) ZSTAMP(2);
-                emit_obs8(p, e, o, hs, hc);
-#if !defined(ZENV_EXP) || !(ZENV_EXP & 8)   // diagnostic: bit 3 drops the env wave's per-step global stores
-                store_obs8(p, env, o);
-#endif
-#if !defined(ZENV_EXP) || !(ZENV_EXP & 4)   // diagnostic: bit 2 drops the action source
-                if (pol.policy == ZENV_POLICY_UNIFORM)
-                    act = uniform_action(polt.env_index0 + (uint64_t)env, polt.step_index, polt.seed);
-                else if (pol.policy == ZENV_POLICY_GREEDY)
-                    act = greedy_action_regs<TASK, ZT>(zp, auxr, e.vis, e.colpack, o[1], o[2], o[3], o[4]);
-#endif
-                if (done) {          // finished, no auto-reset: frozen from the next step on
-                    pc.done_state[env] = 1;
-                    frozen = true;
-                }
+                const int cd = max(auxr[z] - 1, 0);         // colour_match_env.py:98-100
+                auxr[z] = cd;
+                elig_mask = __builtin_amdgcn_alignbit(elig_mask, (uint32_t)(cd - 1), 31);          // cd == 0
+            } else if (TASK == ZENV_TASK_TIMED_TSP) {
+                expired = __builtin_amdgcn_alignbit(expired, (uint32_t)(auxr[z] - (k + 1)), 31);   // tmax - k <= 0, TTSP_env.py:67
             }
         }
+        // the rim: exact float64 test on the float64 zone centres (rare, divergent; live envs only -- the state of
+        // this kernel's envs is finite, so the pose is never a NaN)
+        uint32_t amb_mask = live ? ~(in_mask | out_mask) & full : 0u;
+        while (amb_mask) {
+            const int z = __ffs((int)amb_mask) - 1;
+            amb_mask &= ~(1u << z);
+            const double2 zz = pc.zxy[(size_t)z * N + env];
+            const double dx = zz.x - rx, dy = zz.y - ry;
+            if (dx * dx + dy * dy <= pc.hit_d2) in_mask |= 1u << z;
+        }
+        if (!kColour) elig_mask = ~e.vis;
+        const uint32_t hits = in_mask & elig_mask & full;
+        const int first = hits ? __ffs((int)hits) - 1 : -1;                // lowest index wins, one per step
+        if (first >= 0) {
+            if (kColour) {
+                int col = (int)((e.colpack >> (2 * first)) & 3ull);
+                col = (col == 2) ? 0 : col + 1;                  // Blue->Green->Red->Blue
+                e.colpack = (e.colpack & ~(3ull << (2 * first))) | ((uint64_t)col << (2 * first));
+#pragma unroll
+                for (int z = 0; z < ZT; ++z)
+                    if (z == first) auxr[z] = p.max_cd;
+            } else {
+                e.vis |= 1u << first;
+            }
+        }
+        const bool timed_out = TASK == ZENV_TASK_TIMED_TSP && (expired & ~e.vis & full) != 0u;
+        // ---- reward / goal / termination (Engine.step order).  No exception path here (see k_step_lane): this
+        // kernel's actions come from the scripted on-device policies only, which are finite by construction.
+        double r = 0.0;
+        bool goal = false;
+        if (kColour) {
+            if (first >= 0) {
+                const int nd = hamming_to_goal(e.colpack, Z);
+                r = (double)(e.goal_dist - nd);
+                e.goal_dist = nd;
+            }
+            goal = e.goal_dist == 0;
+        } else {
+            r = first >= 0 ? 1.0 : 0.0;
+            goal = (e.vis & full) == full;
+        }
+        if (goal) r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
+        e.steps = k;
+        const bool done = goal || k >= p.num_steps || (TASK == ZENV_TASK_TIMED_TSP && timed_out);
+        ep_ret = ep_ret + r;
+        const float rew_out = live ? (float)r : 0.f;                   // a frozen env reports reward 0, done 1
+        const uint8_t done_out = (!live || done) ? 1 : 0, goal_out = (live && goal) ? 1 : 0;
+        const bool need_reset = live && done && auto_reset;
+        // (an env auto-reset in this step reports the finished episode's count; a frozen one keeps its last)
+        vcount = live ? (kColour ? e.goal_dist : (int)__popc(e.vis)) : vcount;
+        if (live && done) {
+            pc.last_return[env] = ep_ret;
+            pc.last_len[env] = k;
+            pc.episodes[env] += 1;
+            pc.exception[env] = 0;
+        }
+        uint64_t dword = !live ? kDynZero
+                         : kColour ? e.colpack
+                                   : ((uint64_t)e.vis | (TASK == ZENV_TASK_TIMED_TSP ? (uint64_t)(uint32_t)k << 32 : 0ull));
+        if (t == (n_steps >> 1)) ZSTAMP(1);
+
+        // ---- Engine.step: ctrl = clip(action, ctrlrange); frameskip x mj_step; obs; next action.  (An env about to be
+        // reset runs it too: its result is replaced below.)
+        float o[8];
+        {
+            const double c0 = clamp_sym((double)act.x, 1.0), c1 = clamp_sym((double)act.y, 1.0);
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 2)   // diagnostic: bit 1 drops the physics
+            physics_step(p, e, c0, c1, hs, hc, fs10);
+#endif
+            if (t == (n_steps >> 1)) ZSTAMP(2);
+            emit_obs8(p, e, o, hs, hc);
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 4)   // diagnostic: bit 2 drops the action source
+            if (pol.policy == ZENV_POLICY_UNIFORM)
+                act = uniform_action(polt.env_index0 + (uint64_t)env, polt.step_index, polt.seed);
+            else if (pol.policy == ZENV_POLICY_GREEDY)
+                act = greedy_action_regs<TASK, ZT>(zp, auxr, e.vis, e.colpack, o[1], o[2], o[3], o[4]);
+#endif
+        }
+        if (!live) {
+            // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45) -- zero obs, zero action
+            // (what either policy kernel makes of a zero obs)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = 0.f;
+            if (pol.policy >= 0) act = make_float2(0.f, 0.f);
+        }
+        if (live && done && !auto_reset) {
+            // finished, no auto-reset: frozen from the next step on.  Its registers go back to the state arrays NOW --
+            // from here on the lane only idles through the steps on them (nothing of a frozen lane is written back).
+            pc.done_state[env] = 1;
+            write_back(e, ep_ret);
+            frozen = true;
+        }
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 8)   // diagnostic: bit 3 drops the env wave's per-step global stores
+        if (valid && !need_reset) store_obs8(p, env, o);
+#endif
 
         // ---- auto-reset (penv.py:8-11), wave-cooperative: lane z <-> zone z of the finished env
         unsigned long long pending = __ballot(need_reset);
@@ -1740,7 +1767,8 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 const int env_j = env0 + j;
                 const double *br = pc.bank_robot + 4 * (size_t)slot;
                 const double b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];
-                int code = kColour ? 0 : (int)((pc.vis0 >> (lane & 31)) & 1u), aux = 0;   // pre-visited zones
+                const uint32_t vis0 = pc.vis0;
+                int code = kColour ? 0 : (int)((vis0 >> (lane & 31)) & 1u), aux = 0;   // pre-visited zones
                 float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (lane < Z) {
                     const size_t bi = (size_t)slot * Z + lane;
@@ -1772,7 +1800,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 fresh.x0 = b0; fresh.y0 = b1; fresh.bq0 = b2; fresh.bq3 = b3;
                 fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
                 fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
-                fresh.vis = kColour ? 0u : pc.vis0;
+                fresh.vis = kColour ? 0u : vis0;
                 fresh.colpack = colpack;
                 fresh.goal_dist = kColour ? hamming_to_goal(colpack, Z) : 0;
                 fresh.steps = 0;
@@ -1807,7 +1835,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                     hs = 0.0;
                     hc = 1.0;
                     act = next_act;
-                    dword = kColour ? colpack : (uint64_t)pc.vis0;   // only the pre-visited zones, step count 0
+                    dword = kColour ? colpack : (uint64_t)vis0;   // only the pre-visited zones, step count 0
                     pc.seed[env] = pc.bank_seed[slot];
                     store_obs8(p, env, of);
                 }
@@ -1839,6 +1867,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
         lds_ctr_set(ctr + 0, t + 1);                      // published(t)
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 8)
         if (valid) {
+            p.visit_count[env] = vcount;
             p.reward[env] = rew_out;
             p.done_out[env] = done_out;
             p.goal_met[env] = goal_out;
@@ -1847,16 +1876,9 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
         if (t == (n_steps >> 1)) ZSTAMP(5);
     }
 
-    // ---- the registers go back to the state arrays
+    // ---- the registers go back to the state arrays (a frozen env's did when it froze, or never left them)
     if (valid) {
-        store_dyn(pc, env, e);
-        store_frame(pc, env, e);
-        store_counters(pc, env, TASK, e);
-        pc.ep_return[env] = ep_ret;
-        if (kColour) {
-#pragma unroll
-            for (int z = 0; z < ZT; ++z) pc.cooldown[(size_t)z * N + env] = (uint8_t)auxr[z];
-        }
+        if (!frozen) write_back(e, ep_ret);
         if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = act;
     }
 }
@@ -2173,7 +2195,7 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
     {
         double hs, hc;
         det_sincos_inl(0.5 * e.q2, hs, hc);
-        physics_step(p, e, c0, c1, hs, hc);
+        physics_step(p, e, c0, c1, hs, hc, p.frameskip == ZENV_SUBSTEP_UNROLL);
     }
     if (exc) {
         e.q0 = e.q1 = e.q2 = 0.0;
@@ -2296,7 +2318,7 @@ static inline int n_blocks(int n) { return (n + kWave - 1) / kWave; }
 static inline size_t full_tile_bytes(const DevParams &p) { return (size_t)kWave * p.Z * p.F * sizeof(float); }
 static inline size_t step_lds_bytes(const DevParams &p)
 {
-    const int G = p.F == 6 ? 3 : 7;
+    const int G = p.F == 6 ? (ZENV_RPC6 * 6) / 4 : 7;
     return (size_t)kWave * p.Z * sizeof(float4) + (size_t)kWave * G * sizeof(float4) + 2 * kWave * sizeof(int);
 }
 
@@ -2351,7 +2373,7 @@ hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset,
 
 static inline size_t rollout_lds_bytes(const DevParams &p)
 {
-    const int G = p.F == 6 ? 3 : 7;
+    const int G = p.F == 6 ? (ZENV_RPC6 * 6) / 4 : 7;
     const int ZB = (p.Z + 3) & ~3;
     const size_t ent = p.task == ZENV_TASK_TIMED_TSP ? sizeof(float4) : sizeof(float2);
     return (size_t)kWave * p.Z * ent + (size_t)kWave * G * sizeof(float4)         // static entries, flush slab
