@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -966,7 +967,13 @@ extern "C" int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t
     return run_policy(h, pol);
 }
 
-static constexpr int kRolloutChunk = ZENV_ROLLOUT_CHUNK;   // steps per launch of the persistent kernel
+// steps per launch of the persistent kernel (diagnostic: ZENV_ROLLOUT_CHUNK_EXP=<n> shortens it, e.g. to time the
+// persistent kernel at one step per launch against the per-step kernel)
+static const int kRolloutChunk = [] {
+    const char *e = std::getenv("ZENV_ROLLOUT_CHUNK_EXP");
+    const int v = e ? std::atoi(e) : 0;
+    return v >= 1 && v <= ZENV_ROLLOUT_CHUNK ? v : ZENV_ROLLOUT_CHUNK;
+}();
 
 // Bring the device copy of the parameter block up to date (it changes with the bank, the schedule, a redirected
 // output buffer ...: rarely, so one comparison per rollout call and a copy only when something did change).
