@@ -436,7 +436,11 @@ def mlp_policy_rate(env, zones, steps=300):
         n = env.num_envs
         flop = n * (zones * 2 * ((8 + F) * h + h * h) + 2 * (h * h + (8 + h) * h + h * h + 4 * h))
         us = ms / steps * 1e3
-        return {"us_per_step": round(us, 1), "env_steps_per_s": round(n * steps / (ms * 1e-3), 1),
+        # the float32 mode of the same network (ZENV_MLP_F32: the reference's arithmetic, for evaluation)
+        env.load_mlp(t, precision="f32")
+        env.rollout(5, Z.POLICY_MLP_SAMPLE, policy_seed=1)
+        ms32, _ = env.rollout(20, Z.POLICY_MLP_SAMPLE, policy_seed=1)
+        return {"us_per_step": round(us, 1), "f32_mode_us_per_step": round(ms32 / 20 * 1e3, 1), "env_steps_per_s": round(n * steps / (ms * 1e-3), 1),
                 "network_gflop_per_step": round(flop / 1e9, 1), "dtype": "bf16 MFMA, f32 accumulate",
                 "network_tflops_incl_env_step": round(flop / (us * 1e-6) / 1e12, 1), "mfma_peak_tflops": 2500.0,
                 # a bare v_mfma_f32_32x32x16_bf16 chain on every SIMD with random operands: the power controller

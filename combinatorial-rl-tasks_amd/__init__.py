@@ -13,7 +13,7 @@ from ._native import (Config, ZenvError, TASK_TSP, TASK_TIMED_TSP, TASK_COLOUR_M
                       POLICY_UNIFORM, POLICY_GREEDY, POLICY_MLP_MEAN, POLICY_MLP_SAMPLE, F_OBS, F_ZONE_OBS, F_REWARD, F_DONE,
                       F_GOAL_MET, F_EP_RETURN, F_EP_LEN, F_LAST_RETURN, F_LAST_LEN, F_EPISODES,
                       F_VISIT_COUNT, F_SEED, F_ACTIONS, F_POLICY_MU, F_POLICY_STD, F_POLICY_VALUE,
-                      F_SHAPED_REWARD, F_NEED_GOAL, F_AVAILABLE_GOALS, F_GOAL, F_ORDER_VAL, F_EXCEPTION)
+                      F_SHAPED_REWARD, F_NEED_GOAL, F_AVAILABLE_GOALS, F_GOAL, F_ORDER_VAL, F_EXCEPTION, F_POLICY_VALUE_SIGMA)
 from .vec_env import (ZoneVecEnv, config_for_id, default_config, sample_layout,
                       fixed_seed_sequence, route_ranks, zone_feat)
 

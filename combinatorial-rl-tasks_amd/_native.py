@@ -28,17 +28,20 @@ E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE = -1, -2, -3, -4, -5
  F_LAST_LEN, F_EPISODES, F_VISIT_COUNT, F_SEED, F_ACTIONS, F_POLICY_MU, F_POLICY_STD, F_POLICY_VALUE,
  F_SHAPED_REWARD, F_NEED_GOAL, F_AVAILABLE_GOALS, F_GOAL,
  F_EXP_OBS, F_EXP_ZONE_OBS, F_EXP_ACTION, F_EXP_LOG_PROB, F_EXP_VALUE, F_EXP_REWARD, F_EXP_MASK,
- F_EXP_ADVANTAGE, F_EXP_RETURN, F_ORDER_VAL, F_EXCEPTION) = range(31)
+ F_EXP_ADVANTAGE, F_EXP_RETURN, F_ORDER_VAL, F_EXCEPTION, F_POLICY_VALUE_SIGMA) = range(32)
 
 
 MLP_TENSORS = ("zone_w1", "zone_b1", "zone_w2", "zone_b2", "zone_w3", "zone_b3", "comb_w", "comb_b",
                "enc_w", "enc_b", "mu_w", "mu_b", "std_w", "std_b")
 MLP_CRITIC_TENSORS = ("critic_w1", "critic_b1", "critic_w2", "critic_b2")   # optional, all or none
+MLP_SIGMA_TENSORS = ("critic_sigma_w", "critic_sigma_b")   # optional: the distributional critic (critic_w2 = critic_mu)
+MLP_BF16, MLP_F32 = 0, 1
 
 
 class MlpWeights(C.Structure):
     """struct zenv_mlp_weights (include/zenv.h): host float32 tensors in state_dict layout."""
-    _fields_ = [("h_dim", C.c_int32), ("reserved", C.c_int32)] + [(n, C.c_void_p) for n in MLP_TENSORS + MLP_CRITIC_TENSORS]
+    _fields_ = [("h_dim", C.c_int32), ("precision", C.c_int32)] + [
+        (n, C.c_void_p) for n in MLP_TENSORS + MLP_CRITIC_TENSORS + MLP_SIGMA_TENSORS]
 
 
 class ZenvError(RuntimeError):

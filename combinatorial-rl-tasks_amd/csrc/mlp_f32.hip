@@ -1,0 +1,222 @@
+// mlp_f32.hip -- the reference's actor-critic network in float32 (ZENV_MLP_F32), gfx950.
+//
+// Same network as mlp_policy.hip (ZoneEnvModel main/src/env_model.py:48-79, ACModel flat_model.py:21-68,
+// PolicyNetwork policy_network.py:9-52), evaluated in the reference's own arithmetic type: float32 operands, float32
+// FMA accumulation, precise expf / log1pf.  It exists so that evaluate() with a trained checkpoint -- and any test that
+// asks for it -- sees actions within 1e-5 of what the reference's torch modules produce; the bf16 MFMA kernels are the
+// fast mode (their operands carry 8 significant bits).  Only the summation order differs from torch's GEMM, and the
+// mean over an env's zone rows is taken BEFORE zone_net_'s third (activation-free) layer, with which it commutes.
+//
+// Shape: a workgroup of kMlpHP = 192 threads owns EB consecutive envs; thread j owns hidden feature j.  An input
+// row's activations sit in LDS ([k][row], row-contiguous: one ds_read_b128 = 4 rows of a feature, the same address in
+// every lane = a broadcast), the weights are read from memory transposed ([k][j]: 192 consecutive floats per k, served
+// by L2 -- every workgroup streams the same 0.6 MB), each thread keeps RP = 32 row accumulators in registers.
+// ~1 FMA per LDS-or-global access byte is not what bounds this kernel: its float32 vector FMAs are (61 GFMA per step
+// at N = 65 536, Z = 25 = 0.8 ms at the 157 TFLOP/s vector peak; measured: DESIGN.md section 4).
+#include <hip/hip_runtime.h>
+
+#include "mlp_head_out.hpp"
+#include "mlp_policy.hpp"
+
+namespace zenvk {
+namespace {
+
+constexpr int HP = kMlpHP;     // 192 threads = hidden features (padded)
+constexpr int RP = 32;         // rows (zone rows of consecutive envs) per pass
+constexpr int EB = 4;          // envs per workgroup
+constexpr int KIN = 16;        // padded input width of zone_net_.0 (8 obs + F <= 7 zone features)
+
+// acc[r] += w * x[k][r] for the RP rows of one pass
+__device__ __forceinline__ void fma_rows(float (&acc)[RP], float w, const float *__restrict__ xk)
+{
+    const float4 *x4 = reinterpret_cast<const float4 *>(xk);
+#pragma unroll
+    for (int q = 0; q < RP / 4; ++q) {
+        const float4 v = x4[q];
+        acc[4 * q + 0] = __builtin_fmaf(w, v.x, acc[4 * q + 0]);
+        acc[4 * q + 1] = __builtin_fmaf(w, v.y, acc[4 * q + 1]);
+        acc[4 * q + 2] = __builtin_fmaf(w, v.z, acc[4 * q + 2]);
+        acc[4 * q + 3] = __builtin_fmaf(w, v.w, acc[4 * q + 3]);
+    }
+}
+
+// out[e] = b[j] + sum_k wt[k][j] * x[e][k]   for the EB env vectors in LDS (x: [EB][stride])
+__device__ __forceinline__ void matvec(float (&out)[EB], const float *__restrict__ wt, const float *__restrict__ b,
+                                       const float *__restrict__ x, int stride, int n_in, int j)
+{
+#pragma unroll
+    for (int e = 0; e < EB; ++e) out[e] = b[j];
+    for (int k = 0; k < n_in; ++k) {
+        const float w = wt[(size_t)k * HP + j];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) out[e] = __builtin_fmaf(w, x[e * stride + k], out[e]);
+    }
+}
+
+__global__ __launch_bounds__(HP) void k_mlp_f32(MlpF32 w, int N, int Z, int F, const float *__restrict__ obs,
+                                                const float *__restrict__ zone_obs, float *__restrict__ mu,
+                                                float *__restrict__ stdv, float *__restrict__ value,
+                                                float *__restrict__ value_sigma, MlpAction act)
+{
+    __shared__ __align__(16) float x0[KIN * RP];        // zone_net_.0 input of the pass      [k][row]
+    __shared__ __align__(16) float y1[HP * RP];         // relu(zone_net_.0) of the pass      [k][row]
+    __shared__ float va[EB * (8 + HP)];                 // head vectors: [obs (8); features]  per env
+    __shared__ float vb[EB * HP];
+    const int j = threadIdx.x;
+    const int h = w.h;
+    const bool live = j < h;                             // padded features stay exactly 0
+    const int env0 = blockIdx.x * EB;
+    const int n_env = min(EB, N - env0);
+    const int n_rows = n_env * Z;
+    const float b1 = w.b1[j], b2 = w.b2[j];
+
+    // ---- zone_net_.0, ReLU, zone_net_.2, ReLU on every [obs, zone row]; rows summed per env
+    float psum[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) psum[e] = 0.f;
+    for (int r0 = 0; r0 < n_rows; r0 += RP) {
+        __syncthreads();                                  // the previous pass is done with x0 / y1
+        for (int i = j; i < KIN * RP; i += HP) {
+            const int k = i / RP, r = i % RP, row = r0 + r;
+            float v = 0.f;
+            if (row < n_rows) {
+                const int e = row / Z, z = row - e * Z;
+                if (k < 8) v = obs[(size_t)(env0 + e) * 8 + k];
+                else if (k < 8 + F) v = zone_obs[((size_t)(env0 + e) * Z + z) * F + (k - 8)];
+            }
+            x0[k * RP + r] = v;
+        }
+        __syncthreads();
+        float acc[RP];
+#pragma unroll
+        for (int r = 0; r < RP; ++r) acc[r] = b1;
+        for (int k = 0; k < 8 + F; ++k) fma_rows(acc, w.w1t[(size_t)k * HP + j], x0 + k * RP);
+#pragma unroll
+        for (int q = 0; q < RP / 4; ++q)
+            reinterpret_cast<float4 *>(y1 + j * RP)[q] =
+                live ? make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f),
+                                   fmaxf(acc[4 * q + 3], 0.f))
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RP; ++r) acc[r] = b2;
+        for (int k = 0; k < h; ++k) fma_rows(acc, w.w2t[(size_t)k * HP + j], y1 + k * RP);
+#pragma unroll
+        for (int r = 0; r < RP; ++r) {
+            const int row = r0 + r;
+            const int e = row / Z;
+            const float v = fmaxf(acc[r], 0.f);
+#pragma unroll
+            for (int ee = 0; ee < EB; ++ee)
+                if (row < n_rows && e == ee) psum[ee] += v;
+        }
+    }
+
+    // ---- per env: zone_emb = zone_net_.4(mean) ; c = combine_net_([obs, zone_emb]) ; actor / critic heads
+    __syncthreads();
+    const float inv_z = 1.0f / (float)Z;
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+        vb[e * HP + j] = live ? psum[e] * inv_z : 0.f;
+        if (j < 8) va[e * (8 + HP) + j] = e < n_env ? obs[(size_t)(env0 + e) * 8 + j] : 0.f;
+    }
+    __syncthreads();
+    float t[EB];
+    matvec(t, w.w3t, w.b3, vb, HP, h, j);                                  // zone_net_.4 (no activation)
+#pragma unroll
+    for (int e = 0; e < EB; ++e) va[e * (8 + HP) + 8 + j] = live ? t[e] : 0.f;
+    __syncthreads();
+    matvec(t, w.wct, w.bc, va, 8 + HP, 8 + h, j);                          // combine_net_ -> embedding c
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EB; ++e) vb[e * HP + j] = live ? t[e] : 0.f;       // c
+    __syncthreads();
+    float hv[EB];                                                           // relu(critic.0(c))
+#pragma unroll
+    for (int e = 0; e < EB; ++e) hv[e] = 0.f;
+    if (w.has_critic) matvec(hv, w.wv1t, w.bv1, vb, HP, h, j);
+    matvec(t, w.wat, w.ba, vb, HP, h, j);                                  // actor.enc_.0.0
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+        va[e * (8 + HP) + 8 + j] = live ? fmaxf(t[e], 0.f) : 0.f;          // a = relu(enc(c))
+        vb[e * HP + j] = live ? fmaxf(hv[e], 0.f) : 0.f;                   // relu(critic.0(c))
+    }
+    __syncthreads();
+    // ---- heads: 8 rows of (h + 1) floats -- mu_ 0-1, std_ 0-1 on a; critic.2 / critic_mu, critic_sigma on the critic
+    // hidden; one (env, row) dot product per thread
+    __shared__ float hd[EB * 8];
+    if (j < EB * 8) {
+        const int e = j >> 3, row = j & 7;
+        const float *wr = w.heads + (size_t)row * (HP + 1);
+        const float *x = row < 4 ? va + e * (8 + HP) + 8 : vb + e * HP;
+        float s = wr[HP];
+        for (int k = 0; k < h; ++k) s = __builtin_fmaf(wr[k], x[k], s);
+        hd[j] = s;
+    }
+    __syncthreads();
+    if (j < n_env) {
+        const int env = env0 + j;
+        const float *o = hd + 8 * j;
+        const float v = w.has_critic ? o[4] : 0.f;
+        if (w.has_critic) {
+            value[env] = v;
+            if (w.distributional && value_sigma) value_sigma[env] = softplus03(o[5]) + 1e-3f;
+        }
+        head_outputs(env, o[0], o[1], o[2], o[3], v, mu, stdv, act);
+    }
+}
+
+}  // namespace
+
+size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[13])
+{
+    const int h = w.h_dim;
+    out.clear();
+    auto transposed = [&](const float *W, int n_out, int n_in, int in_rows, int in_offset) {
+        // W [n_out][n_in] row-major -> [in_rows][HP], input k placed at row in_offset + k
+        const size_t at = out.size();
+        out.resize(at + (size_t)in_rows * HP, 0.f);
+        for (int o = 0; o < n_out; ++o)
+            for (int k = 0; k < n_in; ++k) out[at + (size_t)(in_offset + k) * HP + o] = W[(size_t)o * n_in + k];
+        return at;
+    };
+    auto bias = [&](const float *b, int n) {
+        const size_t at = out.size();
+        out.resize(at + HP, 0.f);
+        for (int o = 0; o < n; ++o) out[at + o] = b[o];
+        return at;
+    };
+    offs[0] = transposed(w.zone_w1, h, 8 + F, KIN, 0);   offs[1] = bias(w.zone_b1, h);
+    offs[2] = transposed(w.zone_w2, h, h, HP, 0);        offs[3] = bias(w.zone_b2, h);
+    offs[4] = transposed(w.zone_w3, h, h, HP, 0);        offs[5] = bias(w.zone_b3, h);
+    offs[6] = transposed(w.comb_w, h, 8 + h, 8 + HP, 0); offs[7] = bias(w.comb_b, h);    // [obs (8), zone_emb (h)]
+    offs[8] = transposed(w.enc_w, h, h, HP, 0);          offs[9] = bias(w.enc_b, h);
+    if (w.critic_w1) {
+        offs[10] = transposed(w.critic_w1, h, h, HP, 0);
+        offs[11] = bias(w.critic_b1, h);
+    } else {
+        offs[10] = offs[11] = 0;
+    }
+    offs[12] = out.size();
+    out.resize(out.size() + 8 * (size_t)(HP + 1), 0.f);
+    auto head_row = [&](int row, const float *W, const float *b) {
+        for (int k = 0; k < h; ++k) out[offs[12] + (size_t)row * (HP + 1) + k] = W[k];
+        out[offs[12] + (size_t)row * (HP + 1) + HP] = b[0];
+    };
+    head_row(0, w.mu_w, w.mu_b);          head_row(1, w.mu_w + h, w.mu_b + 1);
+    head_row(2, w.std_w, w.std_b);        head_row(3, w.std_w + h, w.std_b + 1);
+    if (w.critic_w1) head_row(4, w.critic_w2, w.critic_b2);
+    if (w.critic_w1 && w.critic_sigma_w) head_row(5, w.critic_sigma_w, w.critic_sigma_b);
+    return out.size();
+}
+
+hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const float *obs, const float *zone_obs, float *mu,
+                                  float *stdv, float *value, float *value_sigma, const MlpAction &act, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mlp_f32, dim3((N + EB - 1) / EB), dim3(HP), 0, s, w, N, Z, F, obs, zone_obs, mu, stdv, value,
+                       value_sigma, act);
+    return hipGetLastError();
+}
+
+}  // namespace zenvk

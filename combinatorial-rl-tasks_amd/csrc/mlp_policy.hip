@@ -33,6 +33,7 @@
 #include <cstring>
 
 #include "mlp_policy.hpp"
+#include "mlp_head_out.hpp"
 
 namespace zenvk {
 namespace {
@@ -607,35 +608,7 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
     }
 }
 
-// ------------------------------------------------------------------------------------------ sampling
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
-{
-    for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-
-// a = mu, or Normal(mu, std).sample(): Box-Muller on two Philox uniforms keyed by (seed, global env, step)
-__device__ __forceinline__ float2 mlp_action(const MlpAction &act, int env, float2 m, float2 sd)
-{
-    if (act.mode != 1) return m;
-    const uint64_t g = act.env_index0 + (uint64_t)env;
-    uint32_t c[4] = { (uint32_t)g, (uint32_t)(g >> 32), act.step_index, 0x4D4C50u };
-    philox4x32_10(c, (uint32_t)act.seed, (uint32_t)(act.seed >> 32));
-    const float u1 = ((float)(c[0] >> 8) + 0.5f) * 5.9604644775390625e-08f;     // (0, 1)
-    const float u2 = ((float)(c[1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
-    const float rad = sqrtf(-2.0f * logf(u1));
-    return make_float2(m.x + sd.x * rad * cosf(6.283185307179586f * u2), m.y + sd.y * rad * sinf(6.283185307179586f * u2));
-}
-
 // ------------------------------------------------------------------------------------------ kernel 2
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
 // (Fetching the next layer's fragments into registers during the current layer's products and committing them
 // to a second LDS buffer afterwards was slower than plain staging: 48 us against 34 us.)
 // 8 waves per workgroup (two per SIMD), 32 envs per wave.  The layers' fragment images are staged into two LDS
@@ -686,7 +659,8 @@ __device__ __forceinline__ void head_layer(const uint4 *buf, int lane, const bf1
 
 __global__ __launch_bounds__(kHeadWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf16 *__restrict__ pooled,
-                float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value, MlpAction act)
+                float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value,
+                float *__restrict__ value_sigma, MlpAction act)
 {
     extern __shared__ uint4 wl2[];          // two buffers of kImgFrags KiB
     uint4 *const bufA = wl2, *const bufB = wl2 + kImgFrags * kWave;
@@ -728,8 +702,11 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
         f32x16 hv = zero16();
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) hv = mfma(as_frag(bufB[kk * kWave + lane]), xb[kk], hv);
-        value_out = hv[0];
-        if (h == 0 && valid) value[env] = value_out;
+        value_out = hv[0];                                      // critic.2, or critic_mu (distributional)
+        if (h == 0 && valid) {
+            value[env] = value_out;
+            if (value_sigma) value_sigma[env] = softplus03(hv[1]) + 1e-3f;   // flat_model.py:57-60
+        }
     }
     // ---- a = relu(Wa c)   (actor.enc_)                                                          xa -> xb
     stage_fence();
@@ -740,33 +717,7 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
     f32x16 hd = zero16();
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) hd = mfma(as_frag(bufB[kk * kWave + lane]), xb[kk], hd);
-    if (h == 0 && valid) {
-        const float2 m = make_float2(2.0f * (sigmoidf_(hd[0]) - 0.5f), 2.0f * (sigmoidf_(hd[1]) - 0.5f));
-        const float2 sd = make_float2(sigmoidf_(hd[2]) + 1e-3f, sigmoidf_(hd[3]) + 1e-3f);
-        reinterpret_cast<float2 *>(mu)[env] = m;
-        reinterpret_cast<float2 *>(stdv)[env] = sd;
-        if (act.mode >= 0) {
-            const float2 a = mlp_action(act, env, m, sd);
-            reinterpret_cast<float2 *>(act.actions)[env] = a;
-            const MlpRecord &rc = act.rec;
-            if (rc.action) {
-                const size_t slot = (size_t)rc.t * rc.N + env;      // time-major [T][N]
-                reinterpret_cast<float2 *>(rc.action)[slot] = a;
-                // Normal(mu, std).log_prob(a), per action dimension (base.py:160)
-                const float z0 = (a.x - m.x) / sd.x, z1 = (a.y - m.y) / sd.y;
-                reinterpret_cast<float2 *>(rc.log_prob)[slot] =
-                    make_float2(-0.5f * z0 * z0 - logf(sd.x) - 0.91893853320467274178f,
-                                -0.5f * z1 * z1 - logf(sd.y) - 0.91893853320467274178f);
-                rc.value[slot] = value_out;
-                if (rc.t == 0) {
-                    rc.mask[slot] = rc.cur_mask[env];            // self.masks[i] = self.mask (:149), BEFORE this step
-                } else {
-                    rc.mask[slot] = rc.prev_done[env] ? 0.f : 1.f;                 // self.mask = 1 - done (:150)
-                    rc.reward[slot - rc.N] = rc.prev_shaped ? (float)rc.prev_shaped[env] : rc.prev_reward[env];
-                }
-            }
-        }
-    }
+    if (h == 0 && valid) head_outputs(env, hd[0], hd[1], hd[2], hd[3], value_out, mu, stdv, act);
 }
 
 // ------------------------------------------------------------------------------------------ experiences
@@ -886,8 +837,10 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
         offs[6] = out.size() * 2;
         pack_image(out, kMlpNT, kMlpKS, hidden(w.critic_w1, w.critic_b1), k_from_acc);
         offs[7] = out.size() * 2;
+        // row 0: critic.2 (or critic_mu), row 1: critic_sigma of the distributional critic (flat_model.py:35-41)
         pack_image(out, 1, kMlpKS, [&](int row, int, int k) -> float {
-            if (row > 0 || k > h) return 0.f;
+            if (row > 1 || k > h || (row == 1 && !w.critic_sigma_w)) return 0.f;
+            if (row == 1) return k == h ? w.critic_sigma_b[0] : w.critic_sigma_w[k];
             return k == h ? w.critic_b2[0] : w.critic_w2[k];
         }, k_from_acc);
     }
@@ -895,8 +848,10 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
 }
 
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
-                              void *pooled_v, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s)
+                              void *pooled_v, float *mu, float *stdv, float *value, float *value_sigma,
+                              const MlpAction &act, hipStream_t s)
 {
+    if (img.f32) return launch_mlp_forward_f32(*img.f32, N, Z, F, obs, zone_obs, mu, stdv, value, value_sigma, act, s);
     __bf16 *pooled = static_cast<__bf16 *>(pooled_v);
     const dim3 grid((N + 4 * kWave - 1) / (4 * kWave));   // one workgroup per 4 groups of 64 envs
     const size_t lds = (size_t)(NT * KS + NT) * kWave * sizeof(uint4);
@@ -935,7 +890,7 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_head), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_head);
     hipLaunchKernelGGL(k_mlp_head, dim3((N + kHeadWaves * 32 - 1) / (kHeadWaves * 32)), dim3(kHeadWaves * kWave), lds_head, s,
-                       img, N, obs, pooled, mu, stdv, value, act);
+                       img, N, obs, pooled, mu, stdv, value, img.distributional ? value_sigma : nullptr, act);
     return hipGetLastError();
 }
 

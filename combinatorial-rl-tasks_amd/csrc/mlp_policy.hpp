@@ -27,8 +27,28 @@ struct MlpImages {
     const void *wa;     // [NT][KS]     actor.enc_.0.0  A operand, accumulator order
     const void *wh;     // [1][KS]      actor.mu_ / actor.std_ (rows 0-1 / 2-3), accumulator order
     const void *wv1;    // [NT][KS]     critic.0 (null: no value head), accumulator order
-    const void *wv2;    // [1][KS]      critic.2 (row 0), accumulator order
+    const void *wv2;    // [1][KS]      critic.2 or critic_mu (row 0) and critic_sigma (row 1), accumulator order
+    const struct MlpF32 *f32;   // non-null: the float32 path (mlp_f32.hip) runs instead of the bf16 MFMA kernels
+    int distributional;         // critic_mu / critic_sigma heads (flat_model.py:35-41) instead of critic.2
 };
+
+// The float32 path's weights: every matrix TRANSPOSED ([in][kMlpHP], so that consecutive threads = consecutive output
+// features read consecutive floats) and zero-padded to kMlpHP columns; biases [kMlpHP].  Device pointers.
+struct MlpF32 {
+    int h, distributional, has_critic, pad;
+    const float *w1t, *b1;      // zone_net_.0   [16][HP]: k = obs 0..7, zone row 0..F-1
+    const float *w2t, *b2;      // zone_net_.2   [HP][HP]
+    const float *w3t, *b3;      // zone_net_.4
+    const float *wct, *bc;      // combine_net_  [8 + HP][HP]: k = obs 0..7, then zone_emb
+    const float *wat, *ba;      // actor.enc_.0.0
+    const float *wv1t, *bv1;    // critic.0
+    const float *heads;         // [8][HP + 1] rows: mu_ 0-1, std_ 0-1, critic.2 / critic_mu, critic_sigma, 0, 0; bias last
+};
+// floats needed for the device image and the packer (offsets of the arrays above, in floats, in `offs[13]`)
+size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[13]);
+hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const float *obs, const float *zone_obs, float *mu,
+                                  float *stdv, float *value, float *value_sigma, const struct MlpAction &act,
+                                  hipStream_t s);
 
 // Packs the float32 state_dict tensors into one host buffer of fragments; offsets (in bytes) of the
 // images are returned in `offs` (the last two only when the critic tensors are given).  h = hidden width (<= 191), F = zone features (6 or 7).
@@ -60,7 +80,8 @@ inline MlpAction no_mlp_action() { return MlpAction{ -1, 0u, 0ull, 0ull, nullptr
 // obs [N,8], zone_obs [N,Z,F] float32 (device) -> mu, std [N,2] float32 (device).
 // pooled: scratch [N][kMlpHP] bf16 (device).
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
-                              void *pooled, float *mu, float *stdv, float *value, const MlpAction &act, hipStream_t s);
+                              void *pooled, float *mu, float *stdv, float *value, float *value_sigma,
+                              const MlpAction &act, hipStream_t s);
 
 // Experience buffers of one collect_experiences() call (base.py:131-216), all time-major [T][N][...] (the
 // observations are written in place by the step kernel)

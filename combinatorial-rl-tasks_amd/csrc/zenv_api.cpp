@@ -82,7 +82,9 @@ struct zenv {
     void *mlp_mem = nullptr;
     MlpImages mlp{};
     void *mlp_pooled = nullptr;
-    float *mlp_mu = nullptr, *mlp_std = nullptr, *mlp_value = nullptr;
+    float *mlp_mu = nullptr, *mlp_std = nullptr, *mlp_value = nullptr, *mlp_value_sigma = nullptr;
+    void *mlp_f32_mem = nullptr;        // float32 path (ZENV_MLP_F32): transposed float32 weights
+    MlpF32 mlp_f32{};
     bool mlp_ready = false;
     // goal-conditioned variant (zenv_goal_enable)
     bool goal_enabled = false;
@@ -226,6 +228,7 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_POLICY_MU: return { h->mlp_mu, h->mlp_mu ? N * 2 * 4 : 0 };
     case ZENV_F_POLICY_STD: return { h->mlp_std, h->mlp_std ? N * 2 * 4 : 0 };
     case ZENV_F_POLICY_VALUE: return { h->mlp_value, h->mlp_value ? N * 4 : 0 };
+    case ZENV_F_POLICY_VALUE_SIGMA: return { h->mlp_value_sigma, h->mlp_value_sigma ? N * 4 : 0 };
     case ZENV_F_SHAPED_REWARD: return { p.shaped, p.shaped ? N * 8 : 0 };
     case ZENV_F_NEED_GOAL: return { p.need_goal, p.need_goal ? N : 0 };
     case ZENV_F_AVAILABLE_GOALS: return { p.available, p.available ? N * 4 : 0 };
@@ -467,7 +470,8 @@ extern "C" int zenv_destroy(zenv_t *h)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_self) (void)hipFree(h->d_self);
-    for (void *m : { h->mlp_mem, h->mlp_pooled, (void *)h->mlp_mu, (void *)h->mlp_std, (void *)h->mlp_value,
+    for (void *m : { h->mlp_mem, h->mlp_f32_mem, (void *)h->mlp_value_sigma, h->mlp_pooled, (void *)h->mlp_mu,
+                     (void *)h->mlp_std, (void *)h->mlp_value,
                      (void *)h->p.visit_zone, (void *)h->p.term_xy, (void *)h->p.goal, (void *)h->p.goal_last,
                      (void *)h->p.goal_xy, (void *)h->p.shaped, (void *)h->p.need_goal, (void *)h->p.available,
                      (void *)h->goal_in, (void *)h->goal_bad, h->exp_mem, (void *)h->p.order_pos,
@@ -825,6 +829,11 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     const int n_critic = (w->critic_w1 != nullptr) + (w->critic_b1 != nullptr) + (w->critic_w2 != nullptr) +
                          (w->critic_b2 != nullptr);
     if (n_critic != 0 && n_critic != 4) return fail(ZENV_E_ARG, "give all four critic tensors or none");
+    const int n_sigma = (w->critic_sigma_w != nullptr) + (w->critic_sigma_b != nullptr);
+    if (n_sigma == 1 || (n_sigma == 2 && n_critic == 0))
+        return fail(ZENV_E_ARG, "the distributional critic needs critic.0, critic_mu (as critic_w2 / _b2) and critic_sigma");
+    if (w->precision != ZENV_MLP_BF16 && w->precision != ZENV_MLP_F32)
+        return fail(ZENV_E_ARG, "unknown zenv_mlp_weights.precision %d", w->precision);
     std::vector<uint16_t> img;
     size_t offs[8];
     if (pack_images(*w, h->p.F, img, offs) != 0)
@@ -833,18 +842,37 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t N = (size_t)h->n_env;
+    h->mlp_ready = false;
     if (h->mlp_mem) HIP_TRY(hipFree(h->mlp_mem));   // its size depends on whether there is a critic
     h->mlp_mem = nullptr;
+    if (h->mlp_f32_mem) HIP_TRY(hipFree(h->mlp_f32_mem));
+    h->mlp_f32_mem = nullptr;
     HIP_TRY(hipMalloc(&h->mlp_mem, img.size() * 2));
     if (!h->mlp_value) HIP_TRY(hipMalloc((void **)&h->mlp_value, N * sizeof(float)));
     HIP_TRY(hipMemsetAsync(h->mlp_value, 0, N * sizeof(float), h->stream));
+    if (!h->mlp_value_sigma) HIP_TRY(hipMalloc((void **)&h->mlp_value_sigma, N * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(h->mlp_value_sigma, 0, N * sizeof(float), h->stream));
     if (!h->mlp_pooled) HIP_TRY(hipMalloc(&h->mlp_pooled, N * kMlpHP * sizeof(uint16_t)));
     if (!h->mlp_mu) HIP_TRY(hipMalloc((void **)&h->mlp_mu, N * 2 * sizeof(float)));
     if (!h->mlp_std) HIP_TRY(hipMalloc((void **)&h->mlp_std, N * 2 * sizeof(float)));
     HIP_TRY(hipMemcpy(h->mlp_mem, img.data(), img.size() * 2, hipMemcpyHostToDevice));
     const char *base = static_cast<const char *>(h->mlp_mem);
     h->mlp = MlpImages{ base + offs[0], base + offs[1], base + offs[2], base + offs[3], base + offs[4], base + offs[5],
-                        n_critic ? base + offs[6] : nullptr, n_critic ? base + offs[7] : nullptr };
+                        n_critic ? base + offs[6] : nullptr, n_critic ? base + offs[7] : nullptr, nullptr,
+                        n_sigma == 2 ? 1 : 0 };
+    if (w->precision == ZENV_MLP_F32) {
+        std::vector<float> f32;
+        size_t fo[13];
+        pack_f32(*w, h->p.F, f32, fo);
+        HIP_TRY(hipMalloc(&h->mlp_f32_mem, f32.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(h->mlp_f32_mem, f32.data(), f32.size() * sizeof(float), hipMemcpyHostToDevice));
+        const float *fb = static_cast<const float *>(h->mlp_f32_mem);
+        h->mlp_f32 = MlpF32{ w->h_dim, n_sigma == 2 ? 1 : 0, n_critic ? 1 : 0, 0,
+                             fb + fo[0], fb + fo[1], fb + fo[2], fb + fo[3], fb + fo[4], fb + fo[5], fb + fo[6],
+                             fb + fo[7], fb + fo[8], fb + fo[9], n_critic ? fb + fo[10] : nullptr,
+                             n_critic ? fb + fo[11] : nullptr, fb + fo[12] };
+        h->mlp.f32 = &h->mlp_f32;
+    }
     h->mlp_ready = true;
     return ZENV_OK;
 }
@@ -857,7 +885,7 @@ extern "C" int zenv_mlp_forward(zenv_t *h)
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
-                               h->mlp_std, h->mlp_value, no_mlp_action(), h->stream));
+                               h->mlp_std, h->mlp_value, h->mlp_value_sigma, no_mlp_action(), h->stream));
     return ZENV_OK;
 }
 
@@ -876,7 +904,7 @@ static int run_policy(zenv_t *h, const StepPolicy &pol, const MlpRecord *rec = n
     const MlpAction act{ pol.policy == ZENV_POLICY_MLP_SAMPLE ? 1 : 0, pol.step_index, pol.seed, pol.env_index0, pol.out,
                          rec ? *rec : MlpRecord{} };
     HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
-                               h->mlp_std, h->mlp_value, act, h->stream));
+                               h->mlp_std, h->mlp_value, h->mlp_value_sigma, act, h->stream));
     return ZENV_OK;
 }
 
@@ -948,7 +976,7 @@ extern "C" int zenv_collect(zenv_t *h, int T, uint64_t policy_seed, uint64_t env
                               h->p.done_out, h->stream));
     // next_value = value(obs_T) (:177-187), then the GAE recursion
     HIP_TRY(launch_mlp_forward(h->mlp, h->n_env, h->p.Z, h->p.F, h->p.obs, h->p.zone_obs, h->mlp_pooled, h->mlp_mu,
-                               h->mlp_std, h->mlp_value, no_mlp_action(), h->stream));
+                               h->mlp_std, h->mlp_value, h->mlp_value_sigma, no_mlp_action(), h->stream));
     HIP_TRY(launch_exp_gae(h->exp, h->n_env, h->mlp_value, discount, gae_lambda, h->stream));
     return ZENV_OK;
 }

@@ -15,13 +15,14 @@ EVAL_SEED0 = 1000000     # evaluate.py:47
 
 
 def evaluate(env_id, policy, n_maps=100, n_runs_per_map=5, env_seed0=EVAL_SEED0, device=0,
-             policy_seed=0, pkl_path=None, max_steps=None, argmax=False):
+             policy_seed=0, pkl_path=None, max_steps=None, argmax=False, precision="f32"):
     """policy: ZENV_POLICY_* (on-device scripted policy), a callable
     ``policy(obs (B,8) float32, zone_obs (B,Z,F) float32) -> actions (B,2)`` running on the host
     (e.g. the reference's ``Agent.get_actions`` behind a small adapter), or an ACModel ``state_dict``
     (main/src/flat_model.py:24-52 names; what ``utils.Agent`` loads, main/src/utils/agent.py:15-28): the actor
     then runs on the device (``csrc/mlp_policy.hip``), ``dist.sample()`` per step as ``Agent.get_actions`` does
-    (agent.py:41-44), or the mean with ``argmax=True``.
+    (agent.py:41-44), or the mean with ``argmax=True``; ``precision`` "f32" (default: the reference's own arithmetic,
+    actions within 1e-5 of its torch float32 modules) or "bf16" (the MFMA kernels, ~20x faster).
 
     Returns ``{"return": [[...]], "length": [[...]], "goal_met": [[...]]}``."""
     cfg = config_for_id(env_id) if isinstance(env_id, str) else env_id
@@ -32,7 +33,7 @@ def evaluate(env_id, policy, n_maps=100, n_runs_per_map=5, env_seed0=EVAL_SEED0,
     env.reset()
     if isinstance(policy, dict):
         from .vec_env import mlp_tensors_from_state_dict
-        env.load_mlp(mlp_tensors_from_state_dict(policy))
+        env.load_mlp(mlp_tensors_from_state_dict(policy), precision=precision)
         policy = nat.POLICY_MLP_MEAN if argmax else nat.POLICY_MLP_SAMPLE
     goal = np.zeros(n, bool)
     horizon = cfg.num_steps if max_steps is None else max_steps

@@ -22,7 +22,7 @@ _FIELD_DTYPES = {
     nat.F_ACTIONS: np.float32, nat.F_POLICY_MU: np.float32, nat.F_POLICY_STD: np.float32,
     nat.F_POLICY_VALUE: np.float32, nat.F_SHAPED_REWARD: np.float64, nat.F_NEED_GOAL: np.uint8,
     nat.F_AVAILABLE_GOALS: np.uint32, nat.F_GOAL: np.int32, nat.F_ORDER_VAL: np.float32,
-    nat.F_EXCEPTION: np.uint8,
+    nat.F_EXCEPTION: np.uint8, nat.F_POLICY_VALUE_SIGMA: np.float32,
 }
 
 
@@ -80,6 +80,10 @@ def mlp_tensors_from_state_dict(sd):
     if "critic.0.weight" in sd and "critic.2.weight" in sd:      # non-distributional critic, flat_model.py:43-47
         names.update({"critic_w1": "critic.0.weight", "critic_b1": "critic.0.bias",
                       "critic_w2": "critic.2.weight", "critic_b2": "critic.2.bias"})
+    elif "critic.0.weight" in sd and "critic_mu.weight" in sd:   # distributional_value=True, flat_model.py:35-41
+        names.update({"critic_w1": "critic.0.weight", "critic_b1": "critic.0.bias",
+                      "critic_w2": "critic_mu.weight", "critic_b2": "critic_mu.bias",
+                      "critic_sigma_w": "critic_sigma.weight", "critic_sigma_b": "critic_sigma.bias"})
     return {k: np.asarray(sd[v].detach().cpu().numpy() if hasattr(sd[v], "detach") else sd[v], np.float32)
             for k, v in names.items()}
 
@@ -267,20 +271,25 @@ class ZoneVecEnv:
                 self.get(nat.F_GOAL))
 
     # ------------------------------------------------------------------ actor network
-    def load_mlp(self, tensors):
+    def load_mlp(self, tensors, precision="bf16"):
         """The reference's ZoneEnvModel + actor (env_model.py:48-79, policy_network.py:12-53) for the
         device policies POLICY_MLP_MEAN / POLICY_MLP_SAMPLE.  tensors: dict of float32 arrays named as in
-        ``_native.MLP_TENSORS`` (see ``mlp_tensors_from_state_dict``), state_dict layout [out][in]."""
+        ``_native.MLP_TENSORS`` (see ``mlp_tensors_from_state_dict``), state_dict layout [out][in].
+        precision "bf16": bf16 MFMA kernels (fast; mu / std within 4e-2 of torch float32); "f32": float32 FMA kernels
+        (~20x slower; within 1e-5 of torch float32 -- what evaluate() uses for a checkpoint)."""
         F = self.zone_feat
         h = int(np.asarray(tensors["zone_b1"]).shape[0])
         want = {"zone_w1": (h, 8 + F), "zone_b1": (h,), "zone_w2": (h, h), "zone_b2": (h,), "zone_w3": (h, h),
                 "zone_b3": (h,), "comb_w": (h, 8 + h), "comb_b": (h,), "enc_w": (h, h), "enc_b": (h,),
                 "mu_w": (2, h), "mu_b": (2,), "std_w": (2, h), "std_b": (2,),
-                "critic_w1": (h, h), "critic_b1": (h,), "critic_w2": (1, h), "critic_b2": (1,)}
+                "critic_w1": (h, h), "critic_b1": (h,), "critic_w2": (1, h), "critic_b2": (1,),
+                "critic_sigma_w": (1, h), "critic_sigma_b": (1,)}
         keep = {}
-        w = nat.MlpWeights(h_dim=h)
-        names = nat.MLP_TENSORS + (nat.MLP_CRITIC_TENSORS if "critic_w1" in tensors else ())
+        w = nat.MlpWeights(h_dim=h, precision={"bf16": nat.MLP_BF16, "f32": nat.MLP_F32}[precision])
+        names = nat.MLP_TENSORS + (nat.MLP_CRITIC_TENSORS if "critic_w1" in tensors else ()) + (
+            nat.MLP_SIGMA_TENSORS if "critic_sigma_w" in tensors else ())
         self._mlp_has_critic = "critic_w1" in tensors
+        self._mlp_distributional = "critic_sigma_w" in tensors
         for name in names:
             a = np.ascontiguousarray(tensors[name], np.float32)
             if a.shape != want[name]:
@@ -298,6 +307,8 @@ class ZoneVecEnv:
             if not getattr(self, "_mlp_has_critic", False):
                 raise ValueError("load_mlp was called without critic tensors")
             out += (self.get(nat.F_POLICY_VALUE),)
+            if getattr(self, "_mlp_distributional", False):     # value = (mu, sigma), flat_model.py:57-60
+                out += (self.get(nat.F_POLICY_VALUE_SIGMA),)
         return out
 
     # ------------------------------------------------------------------ one PPO rollout

@@ -79,9 +79,10 @@ enum {
     ZENV_F_EXP_ADVANTAGE = 27,   /* float32 [T,N]    GAE (:190-196) */
     ZENV_F_EXP_RETURN = 28,      /* float32 [T,N]    value + advantage (:226) */
     ZENV_F_ORDER_VAL = 29,       /* float32 [N,Z]    TSPOrderEnv's 7th row feature 0.5^(position in the route), 0 when visited */
+    ZENV_F_POLICY_VALUE_SIGMA = 31, /* float32 [N]   the distributional critic's sigma (flat_model.py:57-60) */
     ZENV_F_EXCEPTION = 30,       /* uint8   [N]      info['exception'] of the env's LAST FINISHED episode: 1 = it was ended by
                                   *                    Engine.step's MujocoException path (valid once done; see zenv_step) */
-    ZENV_F_COUNT = 31
+    ZENV_F_COUNT = 32
 };
 
 /* scripted on-device action sources (the build's own; used by bench/tests) */
@@ -247,9 +248,14 @@ int zenv_route_ranks(const double *robot_xy, const double *zone_xy, int num_zone
  * policy_network.py:12-53, Box action space), evaluated on bf16 MFMA with float32 accumulation from
  * the handle's own obs / zone_obs buffers.  Pointers are host float32 tensors in the state_dict's
  * layout (row-major [out][in]); F = zenv_zone_feat(cfg).  h_dim <= 191 (the reference uses 185). */
+enum {
+    ZENV_MLP_BF16 = 0,  /* bf16 MFMA, float32 accumulation: ~20x faster, mu / std within 4e-2 of the reference's float32 */
+    ZENV_MLP_F32 = 1    /* float32 FMA throughout: mu / std / value within 1e-5 of the reference's torch float32 --
+                         * the mode in which evaluate() with a checkpoint reproduces the reference's arithmetic */
+};
 typedef struct zenv_mlp_weights {
     int32_t h_dim;
-    int32_t reserved;
+    int32_t precision;              /* ZENV_MLP_* */
     const float *zone_w1, *zone_b1; /* env_model.zone_net_.0  [h, 8+F], [h]   input = [obs, zone row] */
     const float *zone_w2, *zone_b2; /* env_model.zone_net_.2  [h, h],   [h] */
     const float *zone_w3, *zone_b3; /* env_model.zone_net_.4  [h, h],   [h] */
@@ -259,7 +265,11 @@ typedef struct zenv_mlp_weights {
     const float *std_w, *std_b;     /* actor.std_             [2, h],   [2] */
     /* critic of flat_model.ACModel (:43-47, non-distributional): all four NULL = no value head */
     const float *critic_w1, *critic_b1; /* critic.0           [h, h],   [h] */
-    const float *critic_w2, *critic_b2; /* critic.2           [1, h],   [1] */
+    const float *critic_w2, *critic_b2; /* critic.2           [1, h],   [1]   (distributional: critic_mu) */
+    /* distributional critic (ACModel(distributional_value=True), flat_model.py:35-41,57-60): both non-NULL ->
+     * value = critic_mu(relu(critic.0(x))) in ZENV_F_POLICY_VALUE and softplus_{beta=0.3}(critic_sigma(.)) + 1e-3 in
+     * ZENV_F_POLICY_VALUE_SIGMA; collect_experiences uses the mean only (base.py:140-141,193-194) */
+    const float *critic_sigma_w, *critic_sigma_b; /*         [1, h],   [1] */
 } zenv_mlp_weights;
 int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w);
 /* mu = 2 (sigmoid(mu_(x)) - 0.5), std = sigmoid(std_(x)) + 1e-3 of the current observations into

@@ -13,11 +13,12 @@ Only tests/ and bench.py may import it.
 import numpy as np
 import torch
 
+# (also restated: ACModel's distributional critic, flat_model.py:35-41,56-60)
 TENSORS = ("zone_w1", "zone_b1", "zone_w2", "zone_b2", "zone_w3", "zone_b3", "comb_w", "comb_b",
            "enc_w", "enc_b", "mu_w", "mu_b", "std_w", "std_b")
 
 
-def random_tensors(F, h=185, seed=0, bias_scale=0.1, critic=False):
+def random_tensors(F, h=185, seed=0, bias_scale=0.1, critic=False, distributional=False):
     """Weights drawn like flat_model.init_params (:13-19: rows of N(0,1) normalised to unit norm); the
     biases, zero there, get small random values so that the bias path is exercised."""
     g = torch.Generator().manual_seed(seed)
@@ -34,9 +35,11 @@ def random_tensors(F, h=185, seed=0, bias_scale=0.1, critic=False):
     t["enc_w"], t["enc_b"] = lin(h, h)
     t["mu_w"], t["mu_b"] = lin(2, h)
     t["std_w"], t["std_b"] = lin(2, h)
-    if critic:
-        t["critic_w1"], t["critic_b1"] = lin(h, h)          # flat_model.py:43-47
-        t["critic_w2"], t["critic_b2"] = lin(1, h)
+    if critic or distributional:
+        t["critic_w1"], t["critic_b1"] = lin(h, h)          # flat_model.py:43-47 / :35-38
+        t["critic_w2"], t["critic_b2"] = lin(1, h)          # critic.2, or critic_mu (:40)
+    if distributional:
+        t["critic_sigma_w"], t["critic_sigma_b"] = lin(1, h)   # critic_sigma (:41)
     return {k: v.numpy().astype(np.float32) for k, v in t.items()}
 
 
@@ -56,7 +59,11 @@ def forward_fp32(t, obs, zone_obs):
     mu = 2 * (torch.sigmoid(a @ t["mu_w"].T + t["mu_b"]) - 0.5)                      # :49
     std = torch.sigmoid(a @ t["std_w"].T + t["std_b"]) + 1e-3                        # :50
     if "critic_w1" in t:                                                             # flat_model.py:62-64
-        v = (torch.relu(emb @ t["critic_w1"].T + t["critic_b1"]) @ t["critic_w2"].T + t["critic_b2"]).squeeze(1)
+        hidden = torch.relu(emb @ t["critic_w1"].T + t["critic_b1"])
+        v = (hidden @ t["critic_w2"].T + t["critic_b2"]).squeeze(1)
+        if "critic_sigma_w" in t:                                                    # :56-60, Softplus(beta=0.3)
+            sigma = torch.nn.functional.softplus(hidden @ t["critic_sigma_w"].T + t["critic_sigma_b"], beta=0.3) + 1e-3
+            return mu.numpy(), std.numpy(), v.numpy(), sigma.squeeze(1).numpy()
         return mu.numpy(), std.numpy(), v.numpy()
     return mu.numpy(), std.numpy()
 
@@ -85,5 +92,8 @@ def forward_bf16_emulated(t, obs, zone_obs):
     if "critic_w1" in t:
         v1 = _bf(torch.relu(c @ t["critic_w1"].T + t["critic_b1"]).float()).double()
         v = (v1 @ t["critic_w2"].T + t["critic_b2"]).float().squeeze(1)
+        if "critic_sigma_w" in t:
+            sg = torch.nn.functional.softplus((v1 @ t["critic_sigma_w"].T + t["critic_sigma_b"]).float(), beta=0.3) + 1e-3
+            return mu.numpy(), std.numpy(), v.numpy(), sg.squeeze(1).numpy()
         return mu.numpy(), std.numpy(), v.numpy()
     return mu.numpy(), std.numpy()
