@@ -104,6 +104,7 @@ _PROTOTYPES = {
     "zenv_route_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "zenv_goal_enable": (C.c_int, [_H]),
     "zenv_set_goals": (C.c_int, [_H, C.c_void_p]),
+    "zenv_solver_goals": (C.c_int, [_H, C.c_void_p]),
     "zenv_mlp_load": (C.c_int, [_H, C.c_void_p]),
     "zenv_mlp_forward": (C.c_int, [_H]),
     "zenv_get": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int]),

@@ -1969,6 +1969,36 @@ __global__ __launch_bounds__(256) void k_goal_step(DevParams p)
     p.available[env] = p.task == ZENV_TASK_COLOUR_MATCH ? full : (~p.vis[env] & full);
 }
 
+// ColourMatchSolverEnv.solver_get_next_goal (zone-goals/envs/colour_match_solver_env.py:57-97): among the zones whose
+// colour is NOT the target colour of some cheapest recolouring plan, the one nearest to the robot (ties: lowest index --
+// the reference sorts (distance, index) tuples).
+__global__ __launch_bounds__(256) void k_solver_goal(DevParams p, int32_t *__restrict__ out)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.N) return;
+    const uint64_t cp = p.colpack[env];
+    int n[3] = { 0, 0, 0 };                                    // Blue, Green, Red
+    for (int z = 0; z < p.Z; ++z) n[(int)((cp >> (2 * z)) & 3ull) % 3] += 1;
+    const int to[3] = { n[1] * 2 + n[2], n[2] * 2 + n[0], n[0] * 2 + n[1] };   // dist_to_blue / _green / _red
+    const int mn = min(to[0], min(to[1], to[2]));
+    EnvRegs e;
+    const double2 qa = p.qa[env], fa = p.fa[env], fb = p.fb[env];
+    e.q0 = qa.x; e.q1 = qa.y; e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
+    double rx, ry;
+    world_pos(e, rx, ry);
+    int best = -1;
+    double bd = 0.0;
+    for (int z = 0; z < p.Z; ++z) {
+        const int c = (int)((cp >> (2 * z)) & 3ull) % 3;
+        if (!(to[(c + 1) % 3] == mn || to[(c + 2) % 3] == mn)) continue;   // a plan that recolours this zone is cheapest
+        const double2 zz = p.zxy[(size_t)z * p.N + env];
+        const double dx = zz.x - rx, dy = zz.y - ry;
+        const double d = sqrt(dx * dx + dy * dy);
+        if (best < 0 || d < bd) { best = z; bd = d; }
+    }
+    out[env] = best;
+}
+
 // =========================================================================== K7: solver-ordered TSP
 // TSPOrderEnv (main/envs/TSP_order_env.py:13-113): the zones carry a visiting order (a route from a TSP solver,
 // here the bank's aux column: rank of every zone), the observation gets the feature 0.5^(position in the remaining
@@ -2434,6 +2464,12 @@ hipError_t launch_order_step(const DevParams &p, hipStream_t s)
 hipError_t launch_goal_set(const DevParams &p, const int32_t *new_goal, int32_t *bad, hipStream_t s)
 {
     hipLaunchKernelGGL(k_goal_set, dim3((p.N + 255) / 256), dim3(256), 0, s, p, new_goal, bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_solver_goal(const DevParams &p, int32_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_solver_goal, dim3((p.N + 255) / 256), dim3(256), 0, s, p, out);
     return hipGetLastError();
 }
 

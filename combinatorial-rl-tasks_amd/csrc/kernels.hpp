@@ -33,6 +33,8 @@ hipError_t launch_reset(const DevParams &p, const uint8_t *mask, hipStream_t s);
 hipError_t launch_goal_set(const DevParams &p, const int32_t *new_goal, int32_t *bad, hipStream_t s);
 hipError_t launch_goal_step(const DevParams &p, hipStream_t s);
 hipError_t launch_goal_clear(const DevParams &p, const uint8_t *mask, hipStream_t s);
+// ColourMatchSolverEnv.solver_get_next_goal for every env -> out[N] (device)
+hipError_t launch_solver_goal(const DevParams &p, int32_t *out, hipStream_t s);
 // solver-ordered variant (TSP_order_env.py): routes = the bank's aux column
 hipError_t launch_order_reset(const DevParams &p, const uint8_t *mask, hipStream_t s);
 hipError_t launch_order_step(const DevParams &p, hipStream_t s);

@@ -509,25 +509,35 @@ static int upload_bank(zenv *h, const std::vector<double> &robot4, const std::ve
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    for (void *&m : h->bank_mem) {
-        if (m) HIP_TRY(hipFree(m));
-        m = nullptr;
-    }
+    // allocate and fill the new bank first; the handle switches to it only when all of it is on the device (a failure
+    // half way leaves the old bank -- and bank_ready -- exactly as they were)
     const size_t S = seeds.size();
-    HIP_TRY(hipMalloc(&h->bank_mem[0], robot4.size() * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->bank_mem[1], zone.size() * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->bank_mem[2], aux.size() * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&h->bank_mem[3], S * sizeof(int64_t)));
-    HIP_TRY(hipMemcpy(h->bank_mem[0], robot4.data(), robot4.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->bank_mem[1], zone.data(), zone.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->bank_mem[2], aux.data(), aux.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->bank_mem[3], seeds.data(), S * sizeof(int64_t), hipMemcpyHostToDevice));
+    const size_t bytes[4] = { robot4.size() * sizeof(double), zone.size() * sizeof(double), aux.size() * sizeof(int32_t),
+                              S * sizeof(int64_t) };
+    const void *src[4] = { robot4.data(), zone.data(), aux.data(), seeds.data() };
+    void *fresh[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < 4 && err == hipSuccess; ++i) {
+        err = hipMalloc(&fresh[i], bytes[i]);
+        if (err == hipSuccess) err = hipMemcpy(fresh[i], src[i], bytes[i], hipMemcpyHostToDevice);
+    }
+    if (err != hipSuccess) {
+        for (void *m : fresh)
+            if (m) (void)hipFree(m);
+        return fail(ZENV_E_HIP, "uploading the layout bank: %s", hipGetErrorString(err));
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (h->bank_mem[i]) (void)hipFree(h->bank_mem[i]);
+        h->bank_mem[i] = fresh[i];
+    }
     h->p.bank_robot = static_cast<const double *>(h->bank_mem[0]);
     h->p.bank_zone = static_cast<const double *>(h->bank_mem[1]);
     h->p.bank_aux = static_cast<const int32_t *>(h->bank_mem[2]);
     h->p.bank_seed = static_cast<const int64_t *>(h->bank_mem[3]);
     h->p.bank_size = static_cast<int32_t>(S);
     h->bank_ready = true;
+    if (h->p.sched_mode == SCHED_FIXED_SEEDS && h->p.seed_max - h->p.seed_min + 1 != (int64_t)S)
+        h->sched_ready = false;  // that schedule draws slots of the bank it was made for: the next reset starts a default one
     return ZENV_OK;
 }
 
@@ -819,6 +829,20 @@ extern "C" int zenv_set_goals(zenv_t *h, const int32_t *goals)
     return ZENV_OK;
 }
 
+extern "C" int zenv_solver_goals(zenv_t *h, int32_t *goals)
+{
+    if (!h || !goals) return fail(ZENV_E_ARG, "null argument");
+    if (h->cfg.task != ZENV_TASK_COLOUR_MATCH) return fail(ZENV_E_ARG, "solver_get_next_goal is a ColourMatch function");
+    if (!h->goal_enabled) return fail(ZENV_E_STATE, "zenv_goal_enable first");
+    if (!h->was_reset) return fail(ZENV_E_STATE, "reset before asking for goals");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(launch_solver_goal(h->p, h->goal_in, h->stream));
+    HIP_TRY(hipMemcpyAsync(goals, h->goal_in, sizeof(int32_t) * (size_t)h->n_env, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ZENV_OK;
+}
+
 // ============================================================================ actor network
 extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
 {
@@ -915,6 +939,9 @@ extern "C" int zenv_collect(zenv_t *h, int T, uint64_t policy_seed, uint64_t env
     if (T < 1) return fail(ZENV_E_ARG, "frames_per_proc must be positive");
     if (!h->was_reset) return fail(ZENV_E_STATE, "Environment must be reset before stepping");
     if (!h->mlp_ready || !h->mlp.wv1) return fail(ZENV_E_STATE, "zenv_mlp_load with actor and critic weights first");
+    if (h->order_enabled)
+        return fail(ZENV_E_STATE, "solver-ordered envs are stepped with zenv_step (their order feature is not part of "
+                                  "the network input this call evaluates)");
     int rc = use_device(h);
     if (rc) return rc;
     const size_t N = (size_t)h->n_env, ZF = (size_t)h->p.Z * h->p.F;
@@ -1229,6 +1256,22 @@ extern "C" int zenv_set_state(zenv_t *h, const void *src, int64_t bytes)
     int64_t head[2];
     std::memcpy(head, in, 16);
     in += 16;
+    {
+        // MuJoCo resets a state that holds a NaN / Inf (mj_checkPos / mj_checkVel) and the kernels rely on a finite one
+        // (include/zenv.h, exception path): a blob with a non-finite joint state or placement is refused
+        const char *scan = in;
+        for (const Alloc &a : h->allocs) {
+            if (!a.is_state) continue;
+            void **s0 = a.slot;
+            if (s0 == (void **)&h->p.qa || s0 == (void **)&h->p.qb || s0 == (void **)&h->p.qc ||
+                s0 == (void **)&h->p.fa || s0 == (void **)&h->p.fb) {
+                const double *d = reinterpret_cast<const double *>(scan);
+                for (size_t i = 0; i < a.bytes / sizeof(double); ++i)
+                    if (!std::isfinite(d[i])) return fail(ZENV_E_ARG, "state blob holds a non-finite joint state");
+            }
+            scan += a.bytes;
+        }
+    }
     for (const Alloc &a : h->allocs) {
         if (!a.is_state) continue;
         HIP_TRY(hipMemcpy(*a.slot, in, a.bytes, hipMemcpyHostToDevice));

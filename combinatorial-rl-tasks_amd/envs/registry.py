@@ -1,6 +1,6 @@
 """The gym registry of main/envs/__init__.py:7-141 for the ids on the MI355X hot path."""
-from .zone_envs import (ColourMatchEnv, ColourMatchNextCityEnv, TimedTSPEnv, TimedTSPNextCityEnv, TSPEnv,
-                        TSPHardEnv, TSPNextCityEnv, TSPOrderEnv)
+from .zone_envs import (ColourMatchEnv, ColourMatchNextCityEnv, ColourMatchSolverEnv, TimedTSPEnv,
+                        TimedTSPNextCityEnv, TSPEnv, TSPHardEnv, TSPNextCityEnv, TSPOrderEnv, TSPOrderTestEnv)
 
 config_point = {                      # __init__.py:7-14
     "robot_base": "xmls/point.xml", "num_cities": 15, "walled": False,
@@ -42,6 +42,8 @@ REGISTRY = {
     "PointTSP-v3": (TSPNextCityEnv, config_point),         # :104-106 goal-conditioned
     "PointTTSP-v3": (TimedTSPNextCityEnv, config_point),   # zone-goals/envs/__init__.py:140-142
     "ColourMatch-v3": (ColourMatchNextCityEnv, config_point_colour),   # zone-goals/envs/__init__.py:151-153
+    "ColourMatch-v2": (ColourMatchSolverEnv, config_point_colour),     # zone-goals/envs/__init__.py:148-150
+    "PointTSP-v21": (TSPOrderTestEnv, config_point),                   # zone-goals/envs/__init__.py:102-104
 }
 
 # registered by the reference but outside this build (other robots)

@@ -369,3 +369,21 @@ class ColourMatchNextCityEnv(ColourMatchEnv):
     def get_available_goals(self):
         assert self.goal_zone is None
         return np.ones(self.num_cities, dtype=bool)
+
+
+class ColourMatchSolverEnv(ColourMatchNextCityEnv):
+    """ColourMatch-v2 (zone-goals/envs/colour_match_solver_env.py:11-220): ColourMatchNextCityEnv plus the scripted
+    high-level policy ``solver_get_next_goal`` -- the nearest zone that a cheapest recolouring plan has to cycle."""
+
+    def solver_get_next_goal(self):
+        return int(self._vec.solver_goals()[0])                            # :57-97
+
+
+class TSPOrderTestEnv(TSPOrderEnv):
+    """PointTSP-v21 (zone-goals/envs/TSP_order_test_env.py:11-104): TSPOrderEnv's observation (route feature) without
+    the shaped reward in info."""
+
+    def step(self, action):
+        obs, reward, done, info = super().step(action)
+        info.pop("shaped_reward", None)                                    # :74: plain super().step()
+        return obs, reward, done, info

@@ -15,7 +15,7 @@ from .envs.wrappers import FixedSeedsWrapper, WaitWrapper, ZoneWrapper
 from .envs.zone_envs import ColourMatchNextCityEnv, TSPNextCityEnv, ZoneEnvBase
 from .vec_env import ZoneVecEnv
 
-_PLAIN_EPISODES = 256   # bank depth for envs that are not behind a FixedSeedsWrapper
+_PLAIN_EPISODES = 256   # default bank depth for envs that are not behind a FixedSeedsWrapper
 
 
 def _unwrap(env):
@@ -32,8 +32,12 @@ def _unwrap(env):
 class ParallelEnv:
     """A batch of zone envs stepped by one MI355X kernel launch."""
 
-    def __init__(self, envs, device=0):
+    def __init__(self, envs, device=0, episodes_per_env=_PLAIN_EPISODES):
+        """episodes_per_env: only for plain seeded envs (no FixedSeedsWrapper) -- how many episodes of env i
+        (Engine.reset's seeds _seed, _seed + 1, ...) are sampled ahead into the device bank.  Stepping past the last
+        one raises instead of silently replaying another env's maps."""
         assert len(envs) >= 1, "No environment given."
+        self._plain_depth = None
         self.envs = envs
         self.observation_space = envs[0].observation_space
         self.action_space = envs[0].action_space
@@ -60,10 +64,11 @@ class ParallelEnv:
             for b in bases:
                 if b._seed is None:
                     b.seed(None)
-                seeds.append(int(b._seed) + np.arange(_PLAIN_EPISODES, dtype=np.int64))
+                seeds.append(int(b._seed) + np.arange(int(episodes_per_env), dtype=np.int64))
             self._vec.build_bank_seeds(np.concatenate(seeds))
-            self._vec.schedule_sequential(first=np.arange(self.num_envs, dtype=np.int32) * _PLAIN_EPISODES,
+            self._vec.schedule_sequential(first=np.arange(self.num_envs, dtype=np.int32) * int(episodes_per_env),
                                           stride=1)
+            self._plain_depth = int(episodes_per_env)
         else:
             raise ValueError("mixing seeded and FixedSeedsWrapper envs is not supported")
         self._goals = all(isinstance(b, (TSPNextCityEnv, ColourMatchNextCityEnv)) for b in bases)
@@ -135,6 +140,12 @@ class ParallelEnv:
         was_finished = getattr(self, "_finished", np.zeros(self.num_envs, bool))
         goal_info = self._vec.goal_info() if getattr(self, "_goals", False) else None
         exc = self._vec.get(nat.F_EXCEPTION) if d.any() else None
+        if self._plain_depth is not None and auto_reset and d.any():
+            # episode k of env i sits in slot i * depth + k: the reset that follows the depth-th episode end would
+            # take env i + 1's first map (Engine.reset would play seed _seed + depth)
+            if int(self._vec.get(nat.F_EPISODES).max()) >= self._plain_depth:
+                raise RuntimeError(f"ParallelEnv: an env finished its {self._plain_depth} pre-sampled episodes; build "
+                                   "it with a larger episodes_per_env, or wrap the envs in FixedSeedsWrapper")
         results = []
         for i in range(self.num_envs):
             info = {} if was_finished[i] else {"cost": 0}   # WaitWrapper no-op: info = {}

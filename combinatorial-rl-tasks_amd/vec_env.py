@@ -265,6 +265,13 @@ class ZoneVecEnv:
             raise ValueError(f"goals must have shape ({self.num_envs},)")
         check(lib().zenv_set_goals(self._h, g.ctypes.data))
 
+    def solver_goals(self):
+        """ColourMatchSolverEnv.solver_get_next_goal (zone-goals/envs/colour_match_solver_env.py:57-97) of every env:
+        int32 [N], the nearest zone a cheapest recolouring plan has to cycle."""
+        g = np.empty(self.num_envs, np.int32)
+        check(lib().zenv_solver_goals(self._h, g.ctypes.data))
+        return g
+
     def goal_info(self):
         """(shaped_reward float64 [N], need_next_goal bool [N], available uint32 bit masks [N], goal int32 [N])."""
         return (self.get(nat.F_SHAPED_REWARD), self.get(nat.F_NEED_GOAL).astype(bool), self.get(nat.F_AVAILABLE_GOALS),

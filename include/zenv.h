@@ -230,6 +230,10 @@ int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_
  * the goal arrays are not part of zenv_get_state(). */
 int zenv_goal_enable(zenv_t *h);
 int zenv_set_goals(zenv_t *h, const int32_t *goals);
+/* ColourMatchSolverEnv.solver_get_next_goal (zone-goals/envs/colour_match_solver_env.py:57-97, id ColourMatch-v2) for
+ * every env of a goal-conditioned ColourMatch handle: the nearest zone that a cheapest recolouring plan has to cycle
+ * (ties: lowest index) into goals[N] (host).  Feed the entries of the envs that need a goal to zenv_set_goals(). */
+int zenv_solver_goals(zenv_t *h, int32_t *goals);
 
 /* ---- solver-ordered variant: TSPOrderEnv, main/envs/TSP_order_env.py:13-113 (PointTSP-v2) ----
  * TSP handles only; call before building the bank.  The route of an episode is the bank's aux column (rank of

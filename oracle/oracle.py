@@ -124,6 +124,7 @@ def lib():
                                   C.c_void_p, C.c_void_p]
         L.orc_rollout.restype = C.c_int64
         L.orc_set_goal.argtypes = [C.POINTER(Env), C.c_int]
+        L.orc_solver_next_goal.argtypes = [C.POINTER(Env)]
         L.orc_order_reset.argtypes = [C.POINTER(Env), C.c_void_p]
         L.orc_step_order.argtypes = [C.POINTER(Env), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.POINTER(C.c_double)]
@@ -207,6 +208,9 @@ class OracleEnv:
     def set_goal(self, goal):
         if lib().orc_set_goal(C.byref(self.e), int(goal)) != 0:
             raise AssertionError("goal zone must be unvisited")
+
+    def solver_next_goal(self):
+        return lib().orc_solver_next_goal(C.byref(self.e))
 
     def step_goal(self, action):
         a = (C.c_float * 2)(float(action[0]), float(action[1]))

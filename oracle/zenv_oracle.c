@@ -646,6 +646,27 @@ int orc_step_goal(orc_env *e, const float action[2], double *reward, int *done, 
     return 0;
 }
 
+int orc_solver_next_goal(const orc_env *e)
+{
+    /* zone-goals/envs/colour_match_solver_env.py:57-97 */
+    const int Z = e->cfg.num_zones;
+    int n[3] = { 0, 0, 0 };
+    for (int z = 0; z < Z; z++) n[e->colour[z]]++;
+    int to[3] = { n[1] * 2 + n[2], n[2] * 2 + n[0], n[0] * 2 + n[1] };   /* dist_to_blue, _green, _red */
+    int mn = to[0] < to[1] ? to[0] : to[1];
+    if (to[2] < mn) mn = to[2];
+    int best = -1;
+    double bd = 0.0;
+    for (int z = 0; z < Z; z++) {
+        int c = e->colour[z];
+        if (!(to[(c + 1) % 3] == mn || to[(c + 2) % 3] == mn)) continue;
+        double dx = e->zone_xy[z][0] - e->xpos[0], dy = e->zone_xy[z][1] - e->xpos[1];
+        double d = sqrt(dx * dx + dy * dy);
+        if (best < 0 || d < bd) { best = z; bd = d; }                      /* candidate_zones.sort()[0]: (dist, index) */
+    }
+    return best;
+}
+
 /* =====================================================================================
  * obs  (ZoneEnvBase.py:190-192,217-224; TSP_env.py:31-35; TTSP_env.py:23-27,86-92;
  * colour_match_env.py:75-80; wrappers.py:136-142).  Values are the reference's float64

@@ -142,6 +142,8 @@ int64_t orc_rollout(const orc_config *cfg, int n_env, int n_steps, int policy,
  * orc_set_goal: -1 when the zone is out of range or visited (set_goal's assert).  orc_step_goal: -2
  * without a goal (step's assert); otherwise orc_step plus info['shaped_reward'] / info['need_next_goal']. */
 int orc_set_goal(orc_env *e, int goal);
+/* ColourMatchSolverEnv.solver_get_next_goal, zone-goals/envs/colour_match_solver_env.py:57-97 (ColourMatch task) */
+int orc_solver_next_goal(const orc_env *e);
 int orc_step_goal(orc_env *e, const float action[2], double *reward, int *done, int *goal_met,
                   double *shaped_reward, int *need_next_goal);
 
