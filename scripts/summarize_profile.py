@@ -56,6 +56,8 @@ def fit(values, steps):
         return 0.0, sum(values) / max(sum(steps), 1)
     mx, my = sum(steps) / n, sum(values) / n
     b = sum((x - mx) * (y - my) for x, y in zip(steps, values)) / sum((x - mx) ** 2 for x in steps)
+    if b < 0:           # a counter that does not grow with the step count (state reads): all of it is per launch
+        return my, 0.0
     return my - b * mx, b
 
 
@@ -72,7 +74,7 @@ for sub in ("stats", "stats_per_step"):
                                                   "pct": float(r["Percentage"])}
 
 workloads = sorted({os.path.basename(d)[len("pmc_fetch_"):].rsplit("_", 1)[0].replace("_per", "")
-                    for d in glob.glob(os.path.join(out, "pmc_fetch_*"))})
+                    for d in glob.glob(os.path.join(out, "pmc_fetch_*")) if os.path.isdir(d)})
 for w in workloads:
     for mode, kern in (("persistent", "k_rollout_lane"), ("per_step", "k_step_lane")):
         steps = launch_steps(no_settle=(mode == "per_step")) if mode == "persistent" else None
@@ -134,6 +136,13 @@ for w in workloads:
                     ent["pmc_run_ns_per_step"] = sum(durs) / len(durs)
                     ent["gpu_clock_ghz"] = round(ent["gpu_cycles_per_step"] / ent["pmc_run_ns_per_step"], 3)
         traffic.setdefault(f"{w}@65536", {})[mode] = ent
+    # GRBM_GUI_ACTIVE / duration reads high on dispatches far below 0.3 ms (MI355X_MICROARCH.md, DVFS give-back): the
+    # per-step kernel's cycles are its measured duration at the clock of the same workload's persistent launches
+    ps, pe = traffic[f"{w}@65536"].get("per_step"), traffic[f"{w}@65536"].get("persistent")
+    if ps and pe and "gpu_clock_ghz" in pe and "pmc_run_ns_per_step" in ps:
+        ps["gpu_clock_ghz"] = pe["gpu_clock_ghz"]
+        ps["gpu_cycles_per_step"] = ps["pmc_run_ns_per_step"] * pe["gpu_clock_ghz"]
+        ps["clock_note"] = "clock of the persistent launches of the same workload (short dispatches read high)"
 summary["pmc"] = traffic
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
