@@ -467,16 +467,30 @@ __device__ __forceinline__ void wave_lds_fence()
 // expands RPC consecutive rows = G whole float4 into the wave-private staging slab, which
 // is then read back lane-linear so that one store instruction covers 1 KiB of contiguous HBM.
 // Cache policy of the tile stores (buffer_store aux bits: 1 = sc0, 2 = nt, 16 = sc1).
-// zone_obs is write-once, read-by-nobody-in-this-launch streaming output (39 MB per step at
-// N = 65 536, more than the aggregate L2): marking it non-temporal keeps it from pushing the
-// step's re-read state (zone positions, joint state: 24 MB) out of the XCD L2s.  Measured on
-// PointTSP-25: plain 14.0 us, sc1 12.8 us, nt 12.65 us per launch.
-#ifndef ZENV_STORE_AUX
-#define ZENV_STORE_AUX 2
+// zone_obs is write-once, read-by-nobody-in-this-launch streaming output (39 MB per step at N = 65 536, Z = 25: more
+// than the aggregate L2).  Which policy is fastest depends on the kernel and on the size of a tile's row block
+// (round 2, same box, us per step -- scripts/exp_variant.py -DZENV_STORE_AUX=<bits>):
+//                          plain (0)   nt (2)   sc1 (16)
+//   K1p PointTSP-25          5.84       6.38      5.26      sc1 = write-through, the line leaves the XCD's L2
+//   K1p TimedTSP-25          7.14       7.77      6.43      (MI355X_MICROARCH.md, stores of each flavour): the
+//   K1p PointTSP-15          3.83       3.99      3.79      row stream no longer competes with its own write-back
+//   K1p ColourMatch-6        2.83       3.01      2.97      small blocks are best left to the L2
+//   K1  PointTSP-25         15.27      13.73     13.23
+//   K1  TimedTSP-25         20.60      18.71     17.97
+//   K1  ColourMatch-6       12.72      11.98     12.13
+// ZENV_STORE_AUX (diagnostic builds) overrides the choice everywhere.
+template <int ZF>
+struct StorePolicy {
+#ifdef ZENV_STORE_AUX
+    static constexpr int kRollout = ZENV_STORE_AUX, kStep = ZENV_STORE_AUX;
+#else
+    static constexpr int kRollout = ZF >= 80 ? 16 : 0;     // persistent kernel's stream wave
+    static constexpr int kStep = ZF >= 100 ? 16 : 2;       // per-step kernel (ZF = 0: zone count known at run time only)
 #endif
+};
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
-template <int TASK>
+template <int TASK, int AUX>
 __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage, float *dst, int n_rows,
                                               int lane)
 {
@@ -513,7 +527,7 @@ __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage,
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const v4f_t val = { t[g].x, t[g].y, t[g].z, t[g].w };
-            __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + g * kWave + lane) * 16, 0, ZENV_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + g * kWave + lane) * 16, 0, AUX);
         }
     }
     // last, partial iteration
@@ -535,7 +549,7 @@ __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage,
             if (i < n4) {
                 const float4 tv = stage[i];
                 const v4f_t val = { tv.x, tv.y, tv.z, tv.w };
-                __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + i) * 16, 0, ZENV_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + i) * 16, 0, AUX);
             }
         }
         wave_lds_fence();
@@ -1193,7 +1207,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
     if (role == 0) {
         const int n_blk = min(kWave, N - env0);
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 1)   // diagnostic builds only: ZENV_EXP bit 0 drops the flush
-        flush_entries<TASK>(ents, stage, p.zone_obs + (size_t)env0 * Z * F, n_blk * Z, lane);
+        flush_entries<TASK, StorePolicy<ZT * F>::kStep>(ents, stage, p.zone_obs + (size_t)env0 * Z * F, n_blk * Z, lane);
 #endif
         asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]),
                      "v"(pf[7]), "v"(pf[8]));
@@ -1324,6 +1338,7 @@ __device__ __forceinline__ void flush_static(const DevParams &p, const typename 
 {
     constexpr int F = TaskTraits<TASK>::F, RPC = TaskTraits<TASK>::RPC, G = TaskTraits<TASK>::G;
     constexpr int ZB = (ZT + 3) & ~3;
+    constexpr int AUX = StorePolicy<ZT * F>::kRollout;
     const int n_chunks = n_rows / RPC;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(dst, 0, n_rows * F * (int)sizeof(float), 0x00020000);
@@ -1356,7 +1371,7 @@ __device__ __forceinline__ void flush_static(const DevParams &p, const typename 
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const v4f_t val = { t[g].x, t[g].y, t[g].z, t[g].w };
-            __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + g * kWave + lane) * 16, 0, ZENV_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + g * kWave + lane) * 16, 0, AUX);
         }
     }
     if (c0 < n_chunks) {
@@ -1376,7 +1391,7 @@ __device__ __forceinline__ void flush_static(const DevParams &p, const typename 
             if (i < n4) {
                 const float4 tv = stage[i];
                 const v4f_t val = { tv.x, tv.y, tv.z, tv.w };
-                __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + i) * 16, 0, ZENV_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (c0 * G + i) * 16, 0, AUX);
             }
         }
         wave_lds_fence();

@@ -17,17 +17,18 @@ else:
     subprocess.run([B._hipcc()] + B.FLAGS + flags + ["-o", so] + [os.path.join(B.CSRC, s) for s in B.SOURCES], check=True)
     nat.LIB_PATH = so
 import combinatorial_rl_tasks_amd as Z
-wl0 = [w for w in wl if w != "steady"]
+wl0 = [w for w in wl if w not in ("steady", "perstep")]
+mode = "per_step" if "perstep" in wl else "persistent"
 task, zones, keep = {"tsp": (0, 25, .4), "timed": (1, 25, .4), "colour": (2, 6, .55), "tsp15": (0, 15, .55)}[wl0[0] if wl0 else "tsp"]
 n = 65536
 cfg = Z.default_config(task, zones, zones_keepout=keep)
 env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n); env.reset()
 if "steady" in wl:      # past the power controller's transient, envs desynchronised
     env.build_bank(1, 4 * n, n_threads=16); env.schedule_sequential(stride=n); env.reset()
-    env.rollout(6000, Z.POLICY_GREEDY)
+    env.rollout(6000, Z.POLICY_GREEDY, mode=mode)
     T = 4096
 else:
-    env.rollout(30, Z.POLICY_GREEDY)
+    env.rollout(30, Z.POLICY_GREEDY, mode=mode)
     T = 300
-tot, k = env.rollout(T, Z.POLICY_GREEDY, time_step_kernel=True)
+tot, k = env.rollout(T, Z.POLICY_GREEDY, time_step_kernel=True, mode=mode, event_stride=16)
 print(flags, wl, "kernel avg us %.2f  loop us/step %.2f" % (k * 1e3, tot / T * 1e3))
