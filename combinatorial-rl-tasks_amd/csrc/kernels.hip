@@ -1515,12 +1515,16 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
     constexpr int ZH = (ZT + 1) / 2;
     constexpr int ZB = (ZT + 3) & ~3;                            // cooldown bytes per env, padded
     constexpr bool kColour = TASK == ZENV_TASK_COLOUR_MATCH;
-    // Which wave wins the SIMD's issue slot when both are ready.  Measured in steady state: when the
-    // tile's row block is big (Z = 25: 38-45 KB per step) the stream wave is the slower one and its few
-    // VALU instructions sit on the critical path of its store stream, so it goes first (PointTSP-25
-    // 6.50 -> 6.27 us, TimedTSP-25 8.14 -> 7.82); with small row blocks the env wave's dependent
-    // instruction stream is the bottleneck and it goes first (PointTSP-15 5.08 -> 4.89).
-    constexpr bool kStreamFirst = ZT * F >= 120;
+    // Which wave wins the SIMD's issue slot when both are ready (s_setprio 3 for one of them).  Measured per workload in
+    // steady state, same box, us per step env-first / stream-first (round 2, after the store-policy change):
+    // PointTSP-25 5.23 / 5.43, TimedTSP-25 6.54 / 6.39, PointTSP-15 3.75 / 3.68, ColourMatch-6 2.82 / 3.04 -- the
+    // stream wave goes first where its expansion work per byte is highest (7-float rows with a deadline division per
+    // row; mid-size 6-float blocks), the env wave's dependent instruction stream otherwise.
+#ifdef ZENV_STREAM_FIRST
+    constexpr bool kStreamFirst = ZENV_STREAM_FIRST != 0;
+#else
+    constexpr bool kStreamFirst = TASK == ZENV_TASK_TIMED_TSP ? ZT * F >= 100 : (ZT * F >= 80 && ZT * F < 120);
+#endif
     const int lane = threadIdx.x & (kWave - 1);
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
     const int env0 = blockIdx.x * kWave;
