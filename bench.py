@@ -260,6 +260,7 @@ def main():
         per_step = per_step_rate(env, task, zones, policy, shard, args.workload) \
             if (args.mode == "persistent" and not distributed) else None
         mlp = None if (args.no_mlp or distributed) else mlp_policy_rate(env, zones)
+        host_rt = None if (args.no_mlp or distributed) else host_roundtrip_rate(env)
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is an N = 1 figure (rank 0 only)
             cpu = cpu_baseline(cfg, task, zones, keepout, policy)
@@ -284,7 +285,7 @@ def main():
                     "mean_last_return_all_ranks": float(np.mean(returns[returns != 0]))
                     if (returns != 0).any() else 0.0,
                     "parity_spot_check": spot, "steady_state": steady, "per_step_launch_mode": per_step,
-                    "mlp_policy": mlp},
+                    "mlp_policy": mlp, "host_policy_roundtrip_pcie_inclusive": host_rt},
         }
         print(json.dumps(out), flush=True)
     env.close()
@@ -407,6 +408,33 @@ def per_step_rate(env, task, zones, policy, shard, workload, steps=2000):
                     "env_steps_per_s": round(env.num_envs * steps / (ms * 1e-3), 1),
                     "frac_of_hbm_peak": blk["frac"]})
         return blk
+    except Exception as ex:  # the bench line must still print
+        return f"error: {ex}"
+
+
+def host_roundtrip_rate(env, steps=24):
+    """Side measurement (never `value`): the PCIe-inclusive rate of the legacy host-policy surface -- what
+    ParallelEnv.step costs a CPU-resident policy: actions H2D + one step-kernel launch + obs / zone_obs / reward /
+    done / goal_met D2H, per step, from and into page-locked host memory (zenv_host_alloc / zenv_get_many)."""
+    try:
+        import combinatorial_rl_tasks_amd as Z
+        n = env.num_envs
+        fields = (Z.F_OBS, Z.F_ZONE_OBS, Z.F_REWARD, Z.F_DONE, Z.F_GOAL_MET)
+        dtypes = (np.float32, np.float32, np.float32, np.uint8, np.uint8)
+        a = env.pinned_array((n, 2), np.float32)
+        a[:] = 0
+        bufs = [env.pinned_array(env._shape(f), t) for f, t in zip(fields, dtypes)]
+        for _ in range(4):
+            env.step(a, auto_reset=True)
+            env.results_into(fields, bufs)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            env.step(a, auto_reset=True)
+            env.results_into(fields, bufs)
+        dt = (time.perf_counter() - t0) / steps
+        mb = (a.nbytes + sum(b.nbytes for b in bufs)) / 1e6
+        return {"ms_per_step": round(dt * 1e3, 3), "env_steps_per_s": round(n / dt, 1), "pcie_mb_per_step": round(mb, 1),
+                "pcie_gb_per_s": round(mb / dt / 1e3, 1), "host_memory": "page-locked", "steps": steps}
     except Exception as ex:  # the bench line must still print
         return f"error: {ex}"
 
