@@ -264,6 +264,15 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is an N = 1 figure (rank 0 only)
             cpu = cpu_baseline(cfg, task, zones, keepout, policy)
+        # the figures to compare rounds by ride inside `roofline` as well (compact), beside the timed region's own
+        if roofline is not None:
+            def compact(b):
+                return None if not isinstance(b, dict) else {
+                    k: b.get(k) for k in ("kernel", "steps_per_launch", "kernel_us_per_step", "kernel_avg_us", "achieved",
+                                          "frac", "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch",
+                                          "traffic", "steps", "launches", "env_steps_per_s")}
+            roofline["steady_state"] = compact(steady)
+            roofline["per_step_kernel"] = compact(per_step)
         out = {
             "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
