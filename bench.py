@@ -197,21 +197,29 @@ def main():
         if k > 0:
             env.rollout(k, policy, policy_seed=0x5EED, env_index0=shard.env_index0, mode=args.mode)
 
-    def fence():
+    def local_sync():
         env.sync()
         torch.cuda.synchronize()
+
+    def fence():
+        local_sync()
         if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The K timed steps, bracketed by barrier + synchronize on both sides.  A rank's clock stops when ITS device has
+    # finished (after its own synchronize, before it enters the closing barrier): the figure reported is the MAX over
+    # ranks, i.e. the time until the slowest rank was done -- the barrier's own latency (an RCCL round, tens of
+    # microseconds) is not part of anybody's K steps.
     fence()
     t0 = time.perf_counter()
     ms_total, ms_kernel = env.rollout(args.steps, policy, policy_seed=0x5EED,
                                       env_index0=shard.env_index0, auto_reset=True,
                                       time_step_kernel=not args.no_kernel_events,
                                       mode=args.mode, event_stride=args.event_stride)
-    fence()
+    local_sync()
     elapsed = time.perf_counter() - t0
+    fence()
 
     # rank-local results, then the one collective of the job: all-gather of episodic returns
     returns = shard.gather_returns(env)          # float32 [world * n_env] on every rank

@@ -1079,7 +1079,10 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
         rc = ensure_self(h);
         if (rc) return rc;
     }
-    HIP_TRY(hipEventRecord(h->events[0], h->stream));
+    // persistent launches that carry their own begin/end events need no bracket events: the span from the first
+    // begin to the last end is the loop (two marker packets less on the stream -- it shows on a 20-step call)
+    const bool own_bracket = !(persistent && per_kernel);
+    if (own_bracket) HIP_TRY(hipEventRecord(h->events[0], h->stream));
     if (persistent && steps > 0) {
         StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };
         if (!have_a0) HIP_TRY(launch_policy(h->p, pol, h->stream));   // a_0; every launch leaves the next action behind
@@ -1111,7 +1114,7 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
         HIP_TRY(launch_step(h->p, h->p.actions, auto_reset, next, h->stream, e0, e1));
         h->step_count += 1;
     }
-    HIP_TRY(hipEventRecord(h->events[1], h->stream));
+    if (own_bracket) HIP_TRY(hipEventRecord(h->events[1], h->stream));
     if (fused && (steps > 0 || have_a0)) {
         h->act_tag.valid = true;
         h->act_tag.policy = policy;
@@ -1119,8 +1122,10 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
         h->act_tag.index0 = env_index0;
         h->act_tag.step = h->step_count;
     }
-    HIP_TRY(hipEventSynchronize(h->events[1]));
-    if (ms_total) HIP_TRY(hipEventElapsedTime(ms_total, h->events[0], h->events[1]));
+    hipEvent_t ev_first = own_bracket ? h->events[0] : h->events[2];
+    hipEvent_t ev_last = own_bracket ? h->events[1] : h->events[3 + 2 * (n_sampled - 1)];
+    HIP_TRY(hipEventSynchronize(ev_last));
+    if (ms_total) HIP_TRY(hipEventElapsedTime(ms_total, ev_first, ev_last));
     if (per_kernel) {
         double sum = 0.0;
         for (int i = 0; i < n_sampled; ++i) {
