@@ -253,7 +253,11 @@ class TSPOrderEnv(TSPEnv):
     (7th row feature 0.5^i for the i-th city of the remaining route) and info['shaped_reward'] is the progress
     towards the next city of the route.  The reference gets the route from OR-tools (:49-50, not available
     here); this class uses the library's nearest-neighbour + 2-opt tour, or ``route_fn(robot_xyrot, zone_xy)
-    -> rank[Z]`` when the caller brings a solver."""
+    -> rank[Z]`` when the caller brings a solver.
+
+    Deliberate deviation: the reference's reset() builds the first observation BEFORE generate_route() (:108-113), so
+    an episode's first obs carries the order feature of the previous episode's leftover route (all zeros after a
+    finished episode); here the first obs already shows the new episode's route."""
 
     def __init__(self, config, route_fn=None, **kw):
         self._route_fn = route_fn
