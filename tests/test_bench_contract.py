@@ -1,0 +1,68 @@
+"""bench.py's arithmetic, on the CPU: the algorithmic byte counts of SURVEY.md 8(d), the two byte bases of the
+roofline block, the PMC record scaled to the steps of a launch, the VALU-issue fraction -- and that the committed
+profiles/traffic.json carries a record for every workload and launch mode the bench can be asked for."""
+import json
+import os
+
+import pytest
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_algorithmic_bytes_are_survey_8d():
+    assert bench.algorithmic_bytes(0, 25, 1) == 1247          # PointTSP-25:   521 + 726
+    assert bench.algorithmic_bytes(1, 25, 1) == 1447          # TimedTSP-25:   621 + 826
+    assert bench.algorithmic_bytes(2, 6, 1) == 485            # ColourMatch-6: 204 + 281
+    assert bench.algorithmic_bytes(0, 15, 1) == 827           # PointTSP-15:   351 + 476
+    # a launch of K steps publishes the outputs K times and moves the state once
+    assert bench.algorithmic_bytes(0, 25, 256) == pytest.approx(637 + (521 + 89) / 256)
+    assert round(bench.algorithmic_bytes(0, 25, 256), 1) == 639.4
+
+
+def test_roofline_block_is_self_consistent():
+    pmc = {"hbm_bytes_per_step": 39.27e6, "hbm_bytes_fixed_per_launch": 81.0e6, "valu_insts_per_simd_step": 1767.2,
+           "gpu_cycles_per_step": 11440.1, "gpu_clock_ghz": 1.989, "source": "test"}
+    b = bench.roofline_block(0, 25, 65536, 5.24e-6, 256, True, pmc)
+    assert b["peak"] == 8000.0 and b["bound"] == "hbm" and b["unit"] == "GB/s"
+    assert b["achieved"] == pytest.approx(639.4 * 65536 / 5.24e-6 / 1e9, rel=1e-3)
+    assert b["frac"] == pytest.approx(b["achieved"] / 8000.0, abs=1e-4)
+    assert b["kernel_avg_us"] == pytest.approx(5.24 * 256, rel=1e-6) and b["env_steps_per_launch"] == 65536 * 256
+    assert b["algorithmic_bytes_per_launch"] == pytest.approx(639.4 * 65536 * 256, rel=1e-4)
+    # the traffic is that of THIS launch length, and traffic / duration stays a bandwidth below the peak
+    assert b["traffic"] == pytest.approx(81.0e6 + 256 * 39.27e6, rel=1e-9)
+    assert b["traffic"] / (b["kernel_avg_us"] * 1e-6) < 8.0e12
+    short = bench.roofline_block(0, 25, 65536, 5.9e-6, 20, True, pmc)
+    assert short["traffic"] == pytest.approx(81.0e6 + 20 * 39.27e6, rel=1e-9)
+    assert short["traffic"] / (short["kernel_avg_us"] * 1e-6) < 8.0e12
+    # both byte bases: the per-step formula does not apply to a persistent launch, and is THE base of a one-step launch
+    assert b["byte_bases"]["survey_8d"]["bytes_per_env_step"] == 1247 and not b["byte_bases"]["survey_8d"]["applies"]
+    one = bench.roofline_block(0, 25, 65536, 13.6e-6, 1, False, None)
+    assert one["byte_bases"]["survey_8d"]["applies"] and one["byte_bases"]["outputs_only"]["bytes_per_env_step"] == 1247
+    assert one["traffic"] is None and one["valu_issue"] is None and one["kernel"] == "k_step_lane"
+    v = b["valu_issue"]
+    assert v["frac_pmc"] == pytest.approx(4 * 1767.2 / 11440.1, abs=1e-4)
+    assert v["frac_live"] == pytest.approx(4 * 1767.2 / (5.24e3 * 1.989), abs=1e-3)
+
+
+def test_committed_pmc_record_covers_every_workload_and_mode():
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        t = json.load(f)
+    for w, (task, zones, _) in bench.WORKLOADS.items():
+        for mode in ("persistent", "per_step"):
+            pmc = bench.load_pmc(w, 65536, mode)
+            assert pmc is not None and pmc == t[f"{w}@65536"][mode], (w, mode)
+            for key in ("hbm_bytes_per_step", "hbm_bytes_fixed_per_launch", "valu_insts_per_simd_step",
+                        "gpu_cycles_per_step", "gpu_clock_ghz", "source", "method"):
+                assert key in pmc, (w, mode, key)
+            assert os.path.exists(os.path.join(ROOT, os.path.dirname(pmc["source"]))), pmc["source"]
+            # measured traffic stays near the algorithmic bytes (no wasted re-reads).  The per-step kernel of the
+            # smallest workload reads 1.28x: its two waves both load the pose and the action (56 B per env), and
+            # FETCH_SIZE's gfx950 doubling is calibrated for 16-byte-per-lane loads only, not for its byte-wide
+            # cooldown loads (MI355X_MICROARCH.md, HBM: other widths are uncalibrated)
+            alg = bench.algorithmic_bytes(task, zones, 256 if mode == "persistent" else 1) * 65536
+            assert pmc["hbm_bytes_per_step"] < (1.05 if mode == "persistent" else 1.35) * alg, (w, mode)
+            # ... and a VALU-issue fraction is a fraction
+            assert 0.05 < 4 * pmc["valu_insts_per_simd_step"] / pmc["gpu_cycles_per_step"] < 1.0
+    assert bench.load_pmc("PointTSP-25", 12345, "persistent") is None
