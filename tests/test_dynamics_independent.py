@@ -1,9 +1,9 @@
 """An INDEPENDENT derivation of one MuJoCo step of the Point robot, asserted against the oracle's closed form.
 
-The oracle (oracle/zenv_oracle.c: mj_substep) and the HIP kernels solve the 3-dof system in a hand-reduced closed
+The oracle (oracle/zenv_oracle.c: mj_env_step) and the HIP kernels (physics_step) solve the 3-dof system in a hand-reduced closed
 form (Schur complement on the hinge row), co-designed so that both produce the same bits.  GPU == oracle therefore
 proves the port, not the physics.  This file restates the physics the generic way MuJoCo's documentation describes
-its pipeline -- without looking at mj_substep's algebra -- in plain numpy float64:
+its pipeline -- without looking at that algebra -- in plain numpy float64:
 
   * kinematics of a planar rigid body on three joints (slide x, slide y, hinge z at the body origin);
   * joint-space inertia M(q) = sum over geoms of  Jv^T m Jv + Jw^T I_com Jw  (what the composite-rigid-body
