@@ -13,6 +13,13 @@
 // by L2 -- every workgroup streams the same 0.6 MB), each thread keeps RP = 32 row accumulators in registers.
 // ~1 FMA per LDS-or-global access byte is not what bounds this kernel: its float32 vector FMAs are (61 GFMA per step
 // at N = 65 536, Z = 25 = 0.8 ms at the 157 TFLOP/s vector peak; measured: DESIGN.md section 4).
+//
+// The zone part -- 84 % of the FLOPs, GEMM-shaped -- runs on the float32 MATRIX instruction instead
+// (k_mlp_zone_f32m: v_mfma_f32_32x32x2_f32, bit for bit a k-ordered fmaf chain at the vector rate, one VGPR per
+// operand): a 32x32 result has its column (zone row / env slot) on the lane and its rows (features) in the 16
+// registers, so relu(layer 1) IS layer 2's B operand register by register when layer 2's weights are packed in that
+// k order; both weight images (147 KB + 12 KB) sit in LDS, one workgroup per CU.  It leaves the per-env zone means in
+// a float32 scratch array; k_mlp_f32 then runs only its per-env head on them (pooled_in).
 #include <hip/hip_runtime.h>
 
 #include "mlp_head_out.hpp"
@@ -56,7 +63,8 @@ __device__ __forceinline__ void matvec(float (&out)[EB], const float *__restrict
 __global__ __launch_bounds__(HP) void k_mlp_f32(MlpF32 w, int N, int Z, int F, const float *__restrict__ obs,
                                                 const float *__restrict__ zone_obs, float *__restrict__ mu,
                                                 float *__restrict__ stdv, float *__restrict__ value,
-                                                float *__restrict__ value_sigma, MlpAction act)
+                                                float *__restrict__ value_sigma, MlpAction act,
+                                                const float *__restrict__ pooled_in)
 {
     __shared__ __align__(16) float x0[KIN * RP];        // zone_net_.0 input of the pass      [k][row]
     __shared__ __align__(16) float y1[HP * RP];         // relu(zone_net_.0) of the pass      [k][row]
@@ -74,7 +82,12 @@ __global__ __launch_bounds__(HP) void k_mlp_f32(MlpF32 w, int N, int Z, int F, c
     float psum[EB];
 #pragma unroll
     for (int e = 0; e < EB; ++e) psum[e] = 0.f;
-    for (int r0 = 0; r0 < n_rows; r0 += RP) {
+    if (pooled_in) {
+        // the per-env sums over the zone rows come from k_mlp_zone_f32m
+#pragma unroll
+        for (int e = 0; e < EB; ++e) psum[e] = e < n_env ? pooled_in[(size_t)(env0 + e) * HP + j] : 0.f;
+    }
+    for (int r0 = 0; r0 < (pooled_in ? 0 : n_rows); r0 += RP) {
         __syncthreads();                                  // the previous pass is done with x0 / y1
         for (int i = j; i < KIN * RP; i += HP) {
             const int k = i / RP, r = i % RP, row = r0 + r;
@@ -167,9 +180,117 @@ __global__ __launch_bounds__(HP) void k_mlp_f32(MlpF32 w, int N, int Z, int F, c
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ zone part on the f32 MFMA
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int NT = HP / 32;        // 6 output tiles of 32 features
+constexpr int KS1 = KIN / 2;       // 8 k-steps of zone_net_.0 (K = 2 per v_mfma_f32_32x32x2_f32)
+constexpr int KS2 = HP / 2;        // 96 k-steps of zone_net_.2
+constexpr int kZoneWaves = 4;
+constexpr size_t kZoneLds = (size_t)(NT * KS2 + NT * KS1) * 64 * sizeof(float);   // 159 744 B of the CU's 163 840
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// One wave per 64 envs, two groups of 32; a tile = zone t of the group's 32 envs (zone-major, like k_mlp_zone1), so
+// column n of every tile is env slot n and the per-env sum over the zone rows is a register-wise add.
+//   Y1[f][row] = sum_k W1[f][k] X0[k][row]        A = W1 image (natural k), B = the lane's input values
+//   Y2[f][row] = sum_k W2[f][k] relu(Y1)[k][row]  A = W2 image (k in accumulator order), B = relu(Y1) registers
+// Biases ride in a constant-1 slot (input k = 15, hidden feature h), as in the bf16 kernels.
+__global__ __launch_bounds__(kZoneWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_mlp_zone_f32m(MlpF32 w, int N, int Z, int F, const float *__restrict__ obs, const float *__restrict__ zone_obs,
+                     float *__restrict__ pooled)
+{
+    extern __shared__ __align__(16) float zl[];
+    float *w2s = zl, *w1s = zl + NT * KS2 * 64;
+    {
+        const float4 *s2 = reinterpret_cast<const float4 *>(w.w2m), *s1 = reinterpret_cast<const float4 *>(w.w1m);
+        float4 *d2 = reinterpret_cast<float4 *>(w2s), *d1 = reinterpret_cast<float4 *>(w1s);
+        for (int i = threadIdx.x; i < NT * KS2 * 16; i += kZoneWaves * 64) d2[i] = s2[i];
+        for (int i = threadIdx.x; i < NT * KS1 * 16; i += kZoneWaves * 64) d1[i] = s1[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int env0 = (blockIdx.x * kZoneWaves + wave) * 64;
+    for (int e_base = 0; e_base < 64 && env0 + e_base < N; e_base += 32) {
+        const bool valid = env0 + e_base + r < N;
+        const int env = valid ? env0 + e_base + r : env0;
+        // B operand of k-step s: X0[k = 2 s + h][row]; k 0..7 = the env's obs, 8..8+F-1 = the zone row, 15 = 1
+        float xo[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xo[s] = valid ? obs[(size_t)env * 8 + 2 * s + h] : 0.f;
+        f32x16 P[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) P[n][i] = 0.f;
+        for (int t = 0; t < Z; ++t) {
+            const float *row = zone_obs + ((size_t)env * Z + t) * F;
+            float xz[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int jf = 2 * s + h;                       // zone feature index of this lane half
+                xz[s] = (valid && jf < F) ? row[jf] : 0.f;
+            }
+            if (h == 1) xz[3] = 1.0f;                           // k = 15: the constant that carries the biases
+            // ---- zone_net_.0 + ReLU: the results stay in registers as layer 2's B operands
+            f32x16 a1[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS1; ++s)
+                    acc = mfma32(w1s[(n * KS1 + s) * 64 + lane], s < 4 ? xo[s] : xz[s - 4], acc);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a1[n][i] = fmaxf(acc[i], 0.f);
+            }
+            // ---- zone_net_.2 + ReLU, summed over the tiles (= over the env's zone rows).  36 chunks of 16 k-steps; the
+            // 16 weight fragments of chunk c + 1 are read from LDS before the 16 MFMAs of chunk c go out (explicit
+            // double buffer between scheduling barriers: left alone, the scheduler hoists hundreds of the 576
+            // independent reads and spills)
+            float wa[2][16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wa[0][i] = w2s[i * 64 + lane];
+            f32x16 acc;
+#pragma unroll
+            for (int c = 0; c < NT * (KS2 / 16); ++c) {
+                const int n2 = c / (KS2 / 16), sc = c % (KS2 / 16);
+                if (c + 1 < NT * (KS2 / 16)) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) wa[(c + 1) & 1][i] = w2s[((c + 1) * 16 + i) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (sc == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc = mfma32(wa[c & 1][i], a1[sc][i], acc);
+                if (sc == KS2 / 16 - 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) P[n2][i] += fmaxf(acc[i], 0.f);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // register i of lane (slot r, half h) of tile n2 is feature 32 n2 + (i & 3) + 8 (i >> 2) + 4 h of env slot r
+        if (valid) {
+#pragma unroll
+            for (int n2 = 0; n2 < NT; ++n2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    pooled[(size_t)env * HP + 32 * n2 + (i & 3) + 8 * (i >> 2) + 4 * h] = P[n2][i];
+        }
+    }
+}
 }  // namespace
 
-size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[13])
+size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[15])
 {
     const int h = w.h_dim;
     out.clear();
@@ -208,14 +329,51 @@ size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_
     head_row(2, w.std_w, w.std_b);        head_row(3, w.std_w + h, w.std_b + 1);
     if (w.critic_w1) head_row(4, w.critic_w2, w.critic_b2);
     if (w.critic_w1 && w.critic_sigma_w) head_row(5, w.critic_sigma_w, w.critic_sigma_b);
+    // ---- images of the two zone layers for k_mlp_zone_f32m: fragment (tile n, k-step s) = 64 floats, lane (r, hh) holds
+    // W[32 n + r][k(s, hh)].  zone_net_.0: natural k = 2 s + hh (k 15 = the bias slot; row h_dim keeps the constant 1);
+    // zone_net_.2: k in the accumulator order of a 32x32 result, k(s, hh) = 32 (s / 16) + (i & 3) + 8 (i >> 2) + 4 hh
+    // with i = s % 16, column h_dim = the bias.
+    auto w1ext = [&](int o, int k) -> float {
+        if (o == h) return k == 15 ? 1.f : 0.f;
+        if (o > h) return 0.f;
+        if (k == 15) return w.zone_b1[o];
+        return k < 8 + F ? w.zone_w1[(size_t)o * (8 + F) + k] : 0.f;
+    };
+    auto w2ext = [&](int o, int k) -> float {
+        if (o == h) return k == h ? 1.f : 0.f;
+        if (o > h || k > h) return 0.f;
+        return k == h ? w.zone_b2[o] : w.zone_w2[(size_t)o * h + k];
+    };
+    offs[13] = out.size();
+    for (int n = 0; n < NT; ++n)
+        for (int s = 0; s < KS1; ++s)
+            for (int lane = 0; lane < 64; ++lane) out.push_back(w1ext(32 * n + (lane & 31), 2 * s + (lane >> 5)));
+    offs[14] = out.size();
+    for (int n = 0; n < NT; ++n)
+        for (int s = 0; s < KS2; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = s % 16;
+                out.push_back(w2ext(32 * n + (lane & 31), 32 * (s / 16) + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)));
+            }
     return out.size();
 }
 
 hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const float *obs, const float *zone_obs, float *mu,
                                   float *stdv, float *value, float *value_sigma, const MlpAction &act, hipStream_t s)
 {
+    const float *pooled_in = nullptr;
+    if (w.pooled && w.h + 1 <= HP - 0) {
+        // zone part on the matrix instruction (one workgroup of 4 waves x 64 envs per CU, both weight images in LDS)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone_f32m),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kZoneLds);
+        hipLaunchKernelGGL(k_mlp_zone_f32m, dim3((N + kZoneWaves * 64 - 1) / (kZoneWaves * 64)), dim3(kZoneWaves * 64),
+                           kZoneLds, s, w, N, Z, F, obs, zone_obs, w.pooled);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        pooled_in = w.pooled;
+    }
     hipLaunchKernelGGL(k_mlp_f32, dim3((N + EB - 1) / EB), dim3(HP), 0, s, w, N, Z, F, obs, zone_obs, mu, stdv, value,
-                       value_sigma, act);
+                       value_sigma, act, pooled_in);
     return hipGetLastError();
 }
 

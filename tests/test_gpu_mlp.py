@@ -65,12 +65,15 @@ def test_mlp_value_head(zenv_mod):
 @pytest.mark.parametrize("env_id,n,steps,h", [("PointTSP-v0", 203, 40, 185), ("PointTTSP-v0", 130, 25, 185),
                                               ("ColourMatch-v0", 77, 60, 185), ("PointTSP-v1", 65, 10, 33),
                                               ("PointTSP-v4", 9, 30, 191)])
-def test_float32_mode_reproduces_the_reference_arithmetic(zenv_mod, env_id, n, steps, h):
+@pytest.mark.parametrize("zone_part", ["mfma", "valu"])
+def test_float32_mode_reproduces_the_reference_arithmetic(zenv_mod, env_id, n, steps, h, zone_part, monkeypatch):
     """ZENV_MLP_F32: mu, std, value (and the distributional sigma) within 1e-5 of the torch float32 restatement of
     env_model.py:70-79 / policy_network.py:47-50 / flat_model.py:52-68 -- the tolerance north_star states for rewards,
     applied to the network that produces the actions."""
     from oracle import policy_ref as P
     Z = zenv_mod
+    if zone_part == "valu":          # the zone layers inside k_mlp_f32 instead of on v_mfma_f32_32x32x2_f32
+        monkeypatch.setenv("ZENV_MLP_F32_VALU", "1")
     env = _env_with_obs(Z, env_id, n, steps)
     for distributional in (False, True):
         t = P.random_tensors(env.zone_feat, h=h, seed=5, critic=True, distributional=distributional)
