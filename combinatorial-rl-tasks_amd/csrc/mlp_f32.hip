@@ -187,11 +187,89 @@ constexpr int NT = HP / 32;        // 6 output tiles of 32 features
 constexpr int KS1 = KIN / 2;       // 8 k-steps of zone_net_.0 (K = 2 per v_mfma_f32_32x32x2_f32)
 constexpr int KS2 = HP / 2;        // 96 k-steps of zone_net_.2
 constexpr int kZoneWaves = 4;
+constexpr int kMfmaMinEnvs = 16384;
 constexpr size_t kZoneLds = (size_t)(NT * KS2 + NT * KS1) * 64 * sizeof(float);   // 159 744 B of the CU's 163 840
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Y = W [obs; X] for a 32-env group, all on registers: X (NT accumulator tiles, feature in registers, env on the lane) is
+// the B operand in accumulator order, OBS_STEPS leading k-steps take the lane's obs values (natural order); fragments
+// from memory, 16 per chunk, double-buffered like the W2 reads.  The constant-1 feature carries the bias through.
+typedef __attribute__((address_space(1))) float gfloat;
+template <int OBS_STEPS, bool RELU>
+__device__ __forceinline__ void head_layer_f32m(const float *__restrict__ img, int lane, const f32x16 (&x)[NT],
+                                                const float (&xo)[4], f32x16 (&y)[NT])
+{
+    static_assert(OBS_STEPS == 0 || OBS_STEPS == 4, "obs rides in 4 k-steps or not at all");
+    // a running pointer, opaque to the compiler: a chunk's 16 fragments sit at immediate offsets 0 .. 3840 B from it.
+    // (Indexed from the image base, every chunk wants its own 64-bit offset in SGPRs -- hundreds of them, hoisted
+    // out of the loops, spilled into VGPR lanes, which then spill in turn: 4 800 scratch instructions.)
+    const gfloat *pf = (const gfloat *)(img + lane);     // address space 1: global_load, not flat_load
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        f32x16 acc;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(pf));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if (OBS_STEPS) {
+            float wo[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wo[s] = pf[s * 64];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma32(wo[s], xo[s], acc);
+            pf += OBS_STEPS * 64;
+            asm volatile("" : "+v"(pf));
+        }
+        float wa[2][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wa[0][i] = pf[i * 64];
+#pragma unroll
+        for (int c = 0; c < KS2 / 16; ++c) {
+            pf += 16 * 64;
+            asm volatile("" : "+v"(pf));
+            if (c + 1 < KS2 / 16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) wa[(c + 1) & 1][i] = pf[i * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = mfma32(wa[c & 1][i], x[c][i], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y[n][i] = RELU ? fmaxf(acc[i], 0.f) : acc[i];
+    }
+}
+// the heads: one output tile whose first rows are the few outputs (register i of lane half 0 = row i for i < 4)
+__device__ __forceinline__ f32x16 head_rows_f32m(const float *__restrict__ img, int lane, const f32x16 (&x)[NT])
+{
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const gfloat *pf = (const gfloat *)(img + lane);
+    float wa[2][16];
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(pf));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wa[0][i] = pf[i * 64];
+#pragma unroll
+    for (int c = 0; c < KS2 / 16; ++c) {
+        pf += 16 * 64;
+        asm volatile("" : "+v"(pf));
+        if (c + 1 < KS2 / 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wa[(c + 1) & 1][i] = pf[i * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = mfma32(wa[c & 1][i], x[c][i], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
 }
 
 // One wave per 64 envs, two groups of 32; a tile = zone t of the group's 32 envs (zone-major, like k_mlp_zone1), so
@@ -201,7 +279,8 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
 // Biases ride in a constant-1 slot (input k = 15, hidden feature h), as in the bf16 kernels.
 __global__ __launch_bounds__(kZoneWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_mlp_zone_f32m(MlpF32 w, int N, int Z, int F, const float *__restrict__ obs, const float *__restrict__ zone_obs,
-                     float *__restrict__ pooled)
+                     float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value,
+                     float *__restrict__ value_sigma, MlpAction act)
 {
     extern __shared__ __align__(16) float zl[];
     float *w2s = zl, *w1s = zl + NT * KS2 * 64;
@@ -278,19 +357,38 @@ void k_mlp_zone_f32m(MlpF32 w, int N, int Z, int F, const float *__restrict__ ob
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // register i of lane (slot r, half h) of tile n2 is feature 32 n2 + (i & 3) + 8 (i >> 2) + 4 h of env slot r
-        if (valid) {
+        // ---- the per-env head, still on the matrix instruction: register i of lane (slot r, half h) of tile n is
+        // feature 32 n + (i & 3) + 8 (i >> 2) + 4 h of env slot r -- the B operand of the next product as it stands.
+        // These layers' images do not fit beside W2 in LDS: their fragments come from L2 (256 B per wave and MFMA).
+        const float inv_z = 1.0f / (float)Z;
 #pragma unroll
-            for (int n2 = 0; n2 < NT; ++n2)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    pooled[(size_t)env * HP + 32 * n2 + (i & 3) + 8 * (i >> 2) + 4 * h] = P[n2][i];
+            for (int i = 0; i < 16; ++i) P[n][i] *= inv_z;              // the mean; its feature h_dim is the constant 1
+        f32x16 e3[NT], cc[NT];
+        head_layer_f32m<0, false>(w.w3m, lane, P, xo, e3);               // zone_net_.4 (no activation)
+        head_layer_f32m<4, false>(w.wcm, lane, e3, xo, cc);              // combine_net_([obs, zone_emb]) -> c
+        float v_mu = 0.f, v_sigma = 0.f;
+        if (w.has_critic) {
+            head_layer_f32m<0, true>(w.wv1m, lane, cc, xo, e3);          // relu(critic.0(c))
+            f32x16 hv = head_rows_f32m(w.whvm, lane, e3);                // rows 0 / 1: critic.2 or critic_mu / critic_sigma
+            v_mu = hv[0];
+            v_sigma = hv[1];
+        }
+        head_layer_f32m<0, true>(w.wam, lane, cc, xo, e3);               // a = relu(actor.enc_(c))
+        const f32x16 hd = head_rows_f32m(w.whm, lane, e3);               // rows 0-1 mu_, 2-3 std_
+        if (h == 0 && valid) {
+            if (w.has_critic) {
+                value[env] = v_mu;
+                if (w.distributional && value_sigma) value_sigma[env] = softplus03(v_sigma) + 1e-3f;
+            }
+            head_outputs(env, hd[0], hd[1], hd[2], hd[3], v_mu, mu, stdv, act);
         }
     }
 }
 }  // namespace
 
-size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[15])
+size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[21])
 {
     const int h = w.h_dim;
     out.clear();
@@ -348,32 +446,77 @@ size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_
     for (int n = 0; n < NT; ++n)
         for (int s = 0; s < KS1; ++s)
             for (int lane = 0; lane < 64; ++lane) out.push_back(w1ext(32 * n + (lane & 31), 2 * s + (lane >> 5)));
+    auto k_acc = [](int s, int hh) { const int i = s % 16; return 32 * (s / 16) + (i & 3) + 8 * (i >> 2) + 4 * hh; };
     offs[14] = out.size();
     for (int n = 0; n < NT; ++n)
         for (int s = 0; s < KS2; ++s)
+            for (int lane = 0; lane < 64; ++lane) out.push_back(w2ext(32 * n + (lane & 31), k_acc(s, lane >> 5)));
+    // ---- the head layers as images of the same kind (input k in accumulator order; the constant-1 feature h_dim of
+    // every hidden vector carries the bias and is passed on by row h_dim): zone_net_.4, combine_net_ (4 leading
+    // k-steps = obs in natural order), critic.0, actor.enc_.0.0; the two head images have 32 rows of which the first
+    // few are outputs
+    auto hidden = [&](const float *W, const float *b, int in_off, int in_stride) {
+        return [=](int o, int k) -> float {
+            if (o == h) return k == h ? 1.f : 0.f;
+            if (o > h || k > h) return 0.f;
+            return k == h ? b[o] : W[(size_t)o * in_stride + in_off + k];
+        };
+    };
+    auto pack_hidden = [&](auto ext, const float *Wobs, int in_stride) {
+        const size_t at = out.size();
+        for (int n = 0; n < NT; ++n) {
+            if (Wobs)
+                for (int s = 0; s < 4; ++s)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int o = 32 * n + (lane & 31), k = 2 * s + (lane >> 5);
+                        out.push_back(o < h ? Wobs[(size_t)o * in_stride + k] : 0.f);
+                    }
+            for (int s = 0; s < KS2; ++s)
+                for (int lane = 0; lane < 64; ++lane) out.push_back(ext(32 * n + (lane & 31), k_acc(s, lane >> 5)));
+        }
+        return at;
+    };
+    auto pack_rows = [&](std::initializer_list<std::pair<const float *, const float *>> rows) {
+        const size_t at = out.size();
+        std::vector<std::pair<const float *, const float *>> rv(rows);
+        for (int s = 0; s < KS2; ++s)
             for (int lane = 0; lane < 64; ++lane) {
-                const int i = s % 16;
-                out.push_back(w2ext(32 * n + (lane & 31), 32 * (s / 16) + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)));
+                const int o = lane & 31, k = k_acc(s, lane >> 5);
+                float v = 0.f;
+                if (o < (int)rv.size() && rv[o].first && k <= h) v = k == h ? rv[o].second[0] : rv[o].first[k];
+                out.push_back(v);
             }
+        return at;
+    };
+    offs[15] = pack_hidden(hidden(w.zone_w3, w.zone_b3, 0, h), nullptr, 0);
+    offs[16] = pack_hidden(hidden(w.comb_w, w.comb_b, 8, 8 + h), w.comb_w, 8 + h);
+    offs[17] = pack_hidden(hidden(w.enc_w, w.enc_b, 0, h), nullptr, 0);
+    offs[18] = pack_rows({ { w.mu_w, w.mu_b }, { w.mu_w + h, w.mu_b + 1 }, { w.std_w, w.std_b }, { w.std_w + h, w.std_b + 1 } });
+    offs[19] = offs[20] = 0;
+    if (w.critic_w1) {
+        offs[19] = pack_hidden(hidden(w.critic_w1, w.critic_b1, 0, h), nullptr, 0);
+        offs[20] = pack_rows({ { w.critic_w2, w.critic_b2 }, { w.critic_sigma_w, w.critic_sigma_b } });
+    }
     return out.size();
 }
 
 hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const float *obs, const float *zone_obs, float *mu,
                                   float *stdv, float *value, float *value_sigma, const MlpAction &act, hipStream_t s)
 {
-    const float *pooled_in = nullptr;
-    if (w.pooled && w.h + 1 <= HP - 0) {
-        // zone part on the matrix instruction (one workgroup of 4 waves x 64 envs per CU, both weight images in LDS)
+    // A wave of the MFMA kernel works through its 64 envs' zone tiles one after the other: ~1.1 ms whatever N is, as
+    // long as there is at most one wave per SIMD (N <= 65 536).  Small batches (evaluate(): 500 envs) are faster on the
+    // vector-ALU kernel, which spreads 4 envs per workgroup over the chip: measured crossover N ~ 20 000.
+    if (w.on_mfma && N >= kMfmaMinEnvs) {
+        // the whole network on the float32 matrix instruction (one workgroup of 4 waves x 64 envs per CU, the two zone
+        // layers' images in LDS)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone_f32m),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kZoneLds);
         hipLaunchKernelGGL(k_mlp_zone_f32m, dim3((N + kZoneWaves * 64 - 1) / (kZoneWaves * 64)), dim3(kZoneWaves * 64),
-                           kZoneLds, s, w, N, Z, F, obs, zone_obs, w.pooled);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        pooled_in = w.pooled;
+                           kZoneLds, s, w, N, Z, F, obs, zone_obs, mu, stdv, value, value_sigma, act);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(k_mlp_f32, dim3((N + EB - 1) / EB), dim3(HP), 0, s, w, N, Z, F, obs, zone_obs, mu, stdv, value,
-                       value_sigma, act, pooled_in);
+                       value_sigma, act, nullptr);
     return hipGetLastError();
 }
 

@@ -43,12 +43,14 @@ struct MlpF32 {
     const float *wat, *ba;      // actor.enc_.0.0
     const float *wv1t, *bv1;    // critic.0
     const float *heads;         // [8][HP + 1] rows: mu_ 0-1, std_ 0-1, critic.2 / critic_mu, critic_sigma, 0, 0; bias last
-    const float *w1m, *w2m;     // MFMA fragment images of zone_net_.0 / .2 (k_mlp_zone_f32m): [6][8][64], [6][96][64]
-    float *pooled;              // scratch [N][HP]: per-env sums of relu(zone_net_.2) over the zone rows (null: the
-                                // zone part runs on the vector ALU inside k_mlp_f32)
+    // MFMA fragment images (k_mlp_zone_f32m; [tiles][k-steps][64 lanes]): zone_net_.0 [6][8], zone_net_.2 [6][96],
+    // zone_net_.4 [6][96], combine_net_ [6][100], actor.enc_ [6][96], actor heads [1][96], critic.0 [6][96], critic
+    // heads [1][96]
+    const float *w1m, *w2m, *w3m, *wcm, *wam, *whm, *wv1m, *whvm;
+    int on_mfma, pad2;          // 0: the vector-ALU kernel k_mlp_f32 (diagnostic, ZENV_MLP_F32_VALU=1)
 };
-// floats needed for the device image and the packer (offsets of the arrays above, in floats, in `offs[15]`)
-size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[15]);
+// floats needed for the device image and the packer (offsets of the arrays above, in floats, in `offs[21]`)
+size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[21]);
 hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const float *obs, const float *zone_obs, float *mu,
                                   float *stdv, float *value, float *value_sigma, const struct MlpAction &act,
                                   hipStream_t s);

@@ -84,7 +84,6 @@ struct zenv {
     void *mlp_pooled = nullptr;
     float *mlp_mu = nullptr, *mlp_std = nullptr, *mlp_value = nullptr, *mlp_value_sigma = nullptr;
     void *mlp_f32_mem = nullptr;        // float32 path (ZENV_MLP_F32): transposed float32 weights
-    float *mlp_pooled_f32 = nullptr;    // ... and its scratch [N][kMlpHP]
     MlpF32 mlp_f32{};
     bool mlp_ready = false;
     // goal-conditioned variant (zenv_goal_enable)
@@ -471,8 +470,7 @@ extern "C" int zenv_destroy(zenv_t *h)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_self) (void)hipFree(h->d_self);
-    for (void *m : { h->mlp_mem, h->mlp_f32_mem, (void *)h->mlp_pooled_f32, (void *)h->mlp_value_sigma, h->mlp_pooled,
-                     (void *)h->mlp_mu,
+    for (void *m : { h->mlp_mem, h->mlp_f32_mem, (void *)h->mlp_value_sigma, h->mlp_pooled, (void *)h->mlp_mu,
                      (void *)h->mlp_std, (void *)h->mlp_value,
                      (void *)h->p.visit_zone, (void *)h->p.term_xy, (void *)h->p.goal, (void *)h->p.goal_last,
                      (void *)h->p.goal_xy, (void *)h->p.shaped, (void *)h->p.need_goal, (void *)h->p.available,
@@ -888,19 +886,18 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
                         n_sigma == 2 ? 1 : 0 };
     if (w->precision == ZENV_MLP_F32) {
         std::vector<float> f32;
-        size_t fo[15];
+        size_t fo[21];
         pack_f32(*w, h->p.F, f32, fo);
-        // (diagnostic: ZENV_MLP_F32_VALU=1 keeps the zone part on the vector ALU, inside k_mlp_f32)
-        const bool zone_on_mfma = std::getenv("ZENV_MLP_F32_VALU") == nullptr;
-        if (zone_on_mfma && !h->mlp_pooled_f32)
-            HIP_TRY(hipMalloc((void **)&h->mlp_pooled_f32, N * kMlpHP * sizeof(float)));
+        // (diagnostic: ZENV_MLP_F32_VALU=1 runs the network on the vector ALU, k_mlp_f32, instead of the f32 MFMA)
+        const bool on_mfma = std::getenv("ZENV_MLP_F32_VALU") == nullptr;
         HIP_TRY(hipMalloc(&h->mlp_f32_mem, f32.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->mlp_f32_mem, f32.data(), f32.size() * sizeof(float), hipMemcpyHostToDevice));
         const float *fb = static_cast<const float *>(h->mlp_f32_mem);
         h->mlp_f32 = MlpF32{ w->h_dim, n_sigma == 2 ? 1 : 0, n_critic ? 1 : 0, 0,
                              fb + fo[0], fb + fo[1], fb + fo[2], fb + fo[3], fb + fo[4], fb + fo[5], fb + fo[6],
                              fb + fo[7], fb + fo[8], fb + fo[9], n_critic ? fb + fo[10] : nullptr,
-                             n_critic ? fb + fo[11] : nullptr, fb + fo[12], fb + fo[13], fb + fo[14], zone_on_mfma ? h->mlp_pooled_f32 : nullptr };
+                             n_critic ? fb + fo[11] : nullptr, fb + fo[12], fb + fo[13], fb + fo[14], fb + fo[15], fb + fo[16], fb + fo[17], fb + fo[18],
+                             n_critic ? fb + fo[19] : nullptr, n_critic ? fb + fo[20] : nullptr, on_mfma ? 1 : 0, 0 };
         h->mlp.f32 = &h->mlp_f32;
     }
     h->mlp_ready = true;
