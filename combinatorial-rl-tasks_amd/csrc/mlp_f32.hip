@@ -187,7 +187,7 @@ constexpr int NT = HP / 32;        // 6 output tiles of 32 features
 constexpr int KS1 = KIN / 2;       // 8 k-steps of zone_net_.0 (K = 2 per v_mfma_f32_32x32x2_f32)
 constexpr int KS2 = HP / 2;        // 96 k-steps of zone_net_.2
 constexpr int kZoneWaves = 4;
-constexpr int kMfmaMinEnvs = 16384;
+constexpr int kMfmaMinEnvs = 10240;
 constexpr size_t kZoneLds = (size_t)(NT * KS2 + NT * KS1) * 64 * sizeof(float);   // 159 744 B of the CU's 163 840
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
@@ -280,7 +280,7 @@ __device__ __forceinline__ f32x16 head_rows_f32m(const float *__restrict__ img, 
 __global__ __launch_bounds__(kZoneWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_mlp_zone_f32m(MlpF32 w, int N, int Z, int F, const float *__restrict__ obs, const float *__restrict__ zone_obs,
                      float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value,
-                     float *__restrict__ value_sigma, MlpAction act)
+                     float *__restrict__ value_sigma, MlpAction act, int envs_per_wave)
 {
     extern __shared__ __align__(16) float zl[];
     float *w2s = zl, *w1s = zl + NT * KS2 * 64;
@@ -293,8 +293,8 @@ void k_mlp_zone_f32m(MlpF32 w, int N, int Z, int F, const float *__restrict__ ob
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int env0 = (blockIdx.x * kZoneWaves + wave) * 64;
-    for (int e_base = 0; e_base < 64 && env0 + e_base < N; e_base += 32) {
+    const int env0 = (blockIdx.x * kZoneWaves + wave) * envs_per_wave;     // 64, or 32 when that still fills the chip
+    for (int e_base = 0; e_base < envs_per_wave && env0 + e_base < N; e_base += 32) {
         const bool valid = env0 + e_base + r < N;
         const int env = valid ? env0 + e_base + r : env0;
         // B operand of k-step s: X0[k = 2 s + h][row]; k 0..7 = the env's obs, 8..8+F-1 = the zone row, 15 = 1
@@ -503,16 +503,18 @@ size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_
 hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const float *obs, const float *zone_obs, float *mu,
                                   float *stdv, float *value, float *value_sigma, const MlpAction &act, hipStream_t s)
 {
-    // A wave of the MFMA kernel works through its 64 envs' zone tiles one after the other: ~1.1 ms whatever N is, as
-    // long as there is at most one wave per SIMD (N <= 65 536).  Small batches (evaluate(): 500 envs) are faster on the
-    // vector-ALU kernel, which spreads 4 envs per workgroup over the chip: measured crossover N ~ 20 000.
-    if (w.on_mfma && N >= kMfmaMinEnvs) {
-        // the whole network on the float32 matrix instruction (one workgroup of 4 waves x 64 envs per CU, the two zone
-        // layers' images in LDS)
+    // A wave of the MFMA kernel works through its envs' zone tiles one group of 32 after the other: ~0.55 ms per group
+    // whatever N is, as long as there is at most one wave per SIMD -- one group per wave up to N = 32 768, two above.
+    // Small batches (evaluate(): 500 envs) are faster on the vector-ALU kernel, which spreads 4 envs per workgroup over
+    // the chip (0.50 ms at N = 8 192, 0.86 ms at 16 384): crossover N ~ 10 000.
+    if (w.on_mfma == 2 || (w.on_mfma == 1 && N >= kMfmaMinEnvs)) {
+        // the whole network on the float32 matrix instruction (one workgroup of 4 waves per CU, the two zone layers'
+        // images in LDS)
+        const int epw = N <= 32768 ? 32 : 64;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone_f32m),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kZoneLds);
-        hipLaunchKernelGGL(k_mlp_zone_f32m, dim3((N + kZoneWaves * 64 - 1) / (kZoneWaves * 64)), dim3(kZoneWaves * 64),
-                           kZoneLds, s, w, N, Z, F, obs, zone_obs, mu, stdv, value, value_sigma, act);
+        hipLaunchKernelGGL(k_mlp_zone_f32m, dim3((N + kZoneWaves * epw - 1) / (kZoneWaves * epw)), dim3(kZoneWaves * 64),
+                           kZoneLds, s, w, N, Z, F, obs, zone_obs, mu, stdv, value, value_sigma, act, epw);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_mlp_f32, dim3((N + EB - 1) / EB), dim3(HP), 0, s, w, N, Z, F, obs, zone_obs, mu, stdv, value,

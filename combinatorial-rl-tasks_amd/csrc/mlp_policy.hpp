@@ -47,7 +47,8 @@ struct MlpF32 {
     // zone_net_.4 [6][96], combine_net_ [6][100], actor.enc_ [6][96], actor heads [1][96], critic.0 [6][96], critic
     // heads [1][96]
     const float *w1m, *w2m, *w3m, *wcm, *wam, *whm, *wv1m, *whvm;
-    int on_mfma, pad2;          // 0: the vector-ALU kernel k_mlp_f32 (diagnostic, ZENV_MLP_F32_VALU=1)
+    int on_mfma, pad2;          // 0: always the vector-ALU kernel k_mlp_f32 (ZENV_MLP_F32_VALU=1); 2: always the MFMA kernel
+                                // (ZENV_MLP_F32_MFMA=1); 1: by batch size
 };
 // floats needed for the device image and the packer (offsets of the arrays above, in floats, in `offs[21]`)
 size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[21]);

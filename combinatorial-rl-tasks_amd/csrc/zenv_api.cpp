@@ -889,7 +889,8 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
         size_t fo[21];
         pack_f32(*w, h->p.F, f32, fo);
         // (diagnostic: ZENV_MLP_F32_VALU=1 runs the network on the vector ALU, k_mlp_f32, instead of the f32 MFMA)
-        const bool on_mfma = std::getenv("ZENV_MLP_F32_VALU") == nullptr;
+        // ZENV_MLP_F32_MFMA=1 the MFMA kernel whatever the batch; default: by batch size, see launch_mlp_forward_f32)
+        const int on_mfma = std::getenv("ZENV_MLP_F32_VALU") ? 0 : std::getenv("ZENV_MLP_F32_MFMA") ? 2 : 1;
         HIP_TRY(hipMalloc(&h->mlp_f32_mem, f32.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->mlp_f32_mem, f32.data(), f32.size() * sizeof(float), hipMemcpyHostToDevice));
         const float *fb = static_cast<const float *>(h->mlp_f32_mem);
@@ -897,7 +898,7 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
                              fb + fo[0], fb + fo[1], fb + fo[2], fb + fo[3], fb + fo[4], fb + fo[5], fb + fo[6],
                              fb + fo[7], fb + fo[8], fb + fo[9], n_critic ? fb + fo[10] : nullptr,
                              n_critic ? fb + fo[11] : nullptr, fb + fo[12], fb + fo[13], fb + fo[14], fb + fo[15], fb + fo[16], fb + fo[17], fb + fo[18],
-                             n_critic ? fb + fo[19] : nullptr, n_critic ? fb + fo[20] : nullptr, on_mfma ? 1 : 0, 0 };
+                             n_critic ? fb + fo[19] : nullptr, n_critic ? fb + fo[20] : nullptr, on_mfma, 0 };
         h->mlp.f32 = &h->mlp_f32;
     }
     h->mlp_ready = true;

@@ -74,6 +74,8 @@ def test_float32_mode_reproduces_the_reference_arithmetic(zenv_mod, env_id, n, s
     Z = zenv_mod
     if zone_part == "valu":          # the zone layers inside k_mlp_f32 instead of on v_mfma_f32_32x32x2_f32
         monkeypatch.setenv("ZENV_MLP_F32_VALU", "1")
+    else:                            # batches this small default to k_mlp_f32: pin the MFMA kernel
+        monkeypatch.setenv("ZENV_MLP_F32_MFMA", "1")
     env = _env_with_obs(Z, env_id, n, steps)
     for distributional in (False, True):
         t = P.random_tensors(env.zone_feat, h=h, seed=5, critic=True, distributional=distributional)
