@@ -147,6 +147,10 @@ def main():
                          "~6 us of launch path, so timing all of them would distort `value`)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the per-launch HIP events around the step kernel")
+    ap.add_argument("--dispatch-events", action="store_true",
+                    help="persistent mode: begin/end events on every dispatch of the TIMED region (hipExtLaunchKernel; "
+                         "costs ~17 us of wall per call -- scripts/launch_overhead.py) instead of the two events recorded "
+                         "on the stream right before and after its launches; the steady-state side run always has them")
     args = ap.parse_args()
     if args.unfused:
         args.mode = "unfused"
@@ -164,11 +168,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
+    # ZENV_BENCH_REHEARSAL=gloo: the driver's N-rank launch line on a box with fewer GPUs than ranks (tests only: ranks
+    # share the cards, the process group runs over gloo because RCCL refuses two ranks on one device)
+    rehearsal = os.environ.get("ZENV_BENCH_REHEARSAL") == "gloo"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     distributed = world > 1 or os.environ.get("ZENV_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank rehearsal
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import combinatorial_rl_tasks_amd as Z
     from combinatorial_rl_tasks_amd import sharding
@@ -211,11 +223,14 @@ def main():
     # finished (after its own synchronize, before it enters the closing barrier): the figure reported is the MAX over
     # ranks, i.e. the time until the slowest rank was done -- the barrier's own latency (an RCCL round, tens of
     # microseconds) is not part of anybody's K steps.
+    # persistent mode: the launches of the region sit between two hipEventRecord()s on the kernel's stream (on one launch
+    # that bracket reads within 0.2 us of the dispatch's own begin/end events, which cost 17 us of host path per call)
+    timed_dispatch_events = (not args.no_kernel_events) and (args.mode != "persistent" or args.dispatch_events)
     fence()
     t0 = time.perf_counter()
     ms_total, ms_kernel = env.rollout(args.steps, policy, policy_seed=0x5EED,
                                       env_index0=shard.env_index0, auto_reset=True,
-                                      time_step_kernel=not args.no_kernel_events,
+                                      time_step_kernel=timed_dispatch_events,
                                       mode=args.mode, event_stride=args.event_stride)
     local_sync()
     elapsed = time.perf_counter() - t0
@@ -224,7 +239,7 @@ def main():
     # rank-local results, then the one collective of the job: all-gather of episodic returns
     returns = shard.gather_returns(env)          # float32 [world * n_env] on every rank
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -239,9 +254,11 @@ def main():
         roofline = None
         if args.steps > 0 and (ms_kernel is not None or not args.unfused):
             # Duration of the dominant kernel per step, from HIP events on the kernel's stream over the timed
-            # region.  persistent: EVERY launch of the region carries begin/end events of the dispatch itself
-            # (hipExtLaunchKernel), summed / steps -- what rocprofv3's kernel trace reports for the same
-            # dispatches.  per_step: the events that bracket the back-to-back loop / steps (an upper bound: it
+            # region.  persistent: two events recorded on the stream right before and after the region's launches
+            # (one launch for --steps <= 256: the bracket is that dispatch + the sub-microsecond gaps around it), or,
+            # with --dispatch-events, begin/end events of every dispatch (hipExtLaunchKernel) summed / steps -- what
+            # rocprofv3's kernel trace reports for the same dispatches; the steady-state block below always uses those.
+            # per_step: the events that bracket the back-to-back loop / steps (an upper bound: it
             # includes the ~0.5 us gaps between launches; timing every dispatch would slow the loop), with the
             # begin/end events of every event_stride-th dispatch beside it.
             loop_s = ms_total / 1e3 / args.steps
@@ -256,7 +273,9 @@ def main():
                 "kernel_launches_timed": n_launches if not args.unfused else
                 (args.steps + args.event_stride - 1) // args.event_stride,
                 "timing": ("begin/end HIP events of every dispatch of the timed region" if persistent and
-                           ms_kernel is not None else "HIP events around the back-to-back launch loop / steps"),
+                           ms_kernel is not None else
+                           "hipEventRecord on the kernel's stream right before and after the region's launch(es)"
+                           if persistent else "HIP events around the back-to-back launch loop / steps"),
                 "loop_us_per_step": round(loop_s * 1e6, 3),
                 "sampled_dispatch_avg_us": None if ms_kernel is None else round(ms_kernel * 1e3, 3),
             })

@@ -56,4 +56,7 @@ class EnvShard:
             return env.get(nat.F_LAST_RETURN).astype(np.float32)
         buf = torch.empty(self.n, dtype=torch.float64, device=f"cuda:{env.device}")
         env.get_into_device(nat.F_LAST_RETURN, buf.data_ptr())
-        return self.all_gather(buf.to(torch.float32)).cpu().numpy()
+        local = buf.to(torch.float32)
+        if dist.get_backend() != "nccl":          # gloo (CPU tests, rehearsals): gather host tensors
+            local = local.cpu()
+        return self.all_gather(local).cpu().numpy()
