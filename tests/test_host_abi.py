@@ -199,3 +199,38 @@ def test_c_demo_compiles_and_links(zenv_mod, tmp_path):
                     os.path.join(ROOT, "examples", "c_abi_demo.c"), "-o", exe, "-L", lib_dir, "-lzenv_hip",
                     "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined"], check=True)
     assert os.path.exists(exe)
+
+
+def test_host_sampler_against_live_numpy_restatement(zenv_mod):
+    """Beyond the 100 committed golden seeds: the C++ host sampler against the numpy restatement that wrote the goldens
+    (tests/golden/make_golden.py: real RandomState draws), on random seeds, zone counts 1..32 and keepouts, incl. tight
+    layouts that restart and the task randomness of TimedTSP / ColourMatch (TTSP_env.py:19-21, colour_match_env.py:57-68)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    Zm = zenv_mod
+    rs = np.random.RandomState(2024)
+    restarts_seen = 0
+    tight = [(25, 0.45), (15, 0.58), (6, 0.9), (15, 0.55), (25, 0.4)]          # layouts that restart (dozens of times)
+    for case in range(170):
+        task = int(rs.randint(0, 3))
+        if case < 2 * len(tight):
+            zones, keepout = tight[case % len(tight)]
+        else:
+            zones = int(rs.randint(1, 33))
+            choices = ([0.4, 0.55, 0.7] if zones <= 6 else [0.3, 0.4, 0.55] if zones <= 15 else
+                       [0.25, 0.3, 0.4] if zones <= 25 else [0.25, 0.3])
+            keepout = float(rs.choice(choices))
+        seed = int(rs.randint(0, 2 ** 31 - 2))
+        cfg = Zm.default_config(task, zones, zones_keepout=keepout)
+        robot, zxy, aux, restarts = Zm.sample_layout(cfg, seed)
+        r_np, z_np, restarts_np = G.sample_layout(seed, zones, keepout)
+        assert np.array_equal(robot, r_np) and np.array_equal(zxy, z_np), (case, task, zones, keepout, seed)
+        assert restarts == restarts_np
+        restarts_seen += restarts
+        if task == 1:
+            assert np.array_equal(aux, (np.random.RandomState(seed).beta(3, 1.5, zones) * cfg.num_steps).astype(np.int64))
+        elif task == 2:
+            assert np.array_equal(aux, np.random.RandomState(seed).choice(3, zones))
+    assert restarts_seen > 20                    # the whole-layout restart path was exercised
