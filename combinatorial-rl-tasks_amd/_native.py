@@ -29,6 +29,8 @@ E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE = -1, -2, -3, -4, -5
  F_SHAPED_REWARD, F_NEED_GOAL, F_AVAILABLE_GOALS, F_GOAL,
  F_EXP_OBS, F_EXP_ZONE_OBS, F_EXP_ACTION, F_EXP_LOG_PROB, F_EXP_VALUE, F_EXP_REWARD, F_EXP_MASK,
  F_EXP_ADVANTAGE, F_EXP_RETURN, F_ORDER_VAL, F_EXCEPTION, F_POLICY_VALUE_SIGMA) = range(32)
+(RESULT_OBS, RESULT_REWARD, RESULT_DONE, RESULT_GOAL_MET, RESULT_EXCEPTION, RESULT_ZONE_OBS) = range(6)
+N_RESULTS = 6
 
 
 MLP_TENSORS = ("zone_w1", "zone_b1", "zone_w2", "zone_b2", "zone_w3", "zone_b3", "comb_w", "comb_b",
@@ -114,6 +116,8 @@ _PROTOTYPES = {
     "zenv_host_alloc": (C.c_void_p, [C.c_int64]),
     "zenv_host_free": (C.c_int, [C.c_void_p]),
     "zenv_get_many": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "zenv_results_layout": (C.c_int64, [_H, C.POINTER(C.c_int64)]),
+    "zenv_step_results": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p]),
     "zenv_set_stream": (C.c_int, [_H, C.c_void_p]),
     "zenv_step_count": (C.c_int64, [_H]),
     "zenv_state_bytes": (C.c_int64, [_H]),

@@ -48,6 +48,7 @@ struct Alloc {
     void **slot;
     size_t bytes;
     bool is_state;   // part of zenv_get_state/zenv_set_state
+    int64_t slab_off = -1;   // >= 0: lives at this offset of the handle's results slab (one hipMalloc, one download)
 };
 
 }  // namespace
@@ -63,6 +64,11 @@ struct zenv {
     DevParams self_shadow{};         // what d_self holds
     bool self_valid = false;
     std::vector<Alloc> allocs;
+    // The per-step results (obs, reward, done, goal_met, exception, zone_obs) share ONE allocation, 256-byte aligned
+    // pieces in that order, so that a host policy fetches them with one copy (zenv_step_results).
+    void *results_slab = nullptr;
+    int64_t results_off[ZENV_N_RESULTS] = {};
+    int64_t results_bytes = 0;
     void *bank_mem[4] = { nullptr, nullptr, nullptr, nullptr };
     uint8_t *d_mask = nullptr;
     bool bank_ready = false;
@@ -427,10 +433,18 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
     want(h, p.seed, N, true);
     want(h, p.slot_first, N, true); want(h, p.episode_idx, N, true);
     want(h, p.pcg, 4 * N, true); want(h, p.pcg_buf, 2 * N, true);
-    want(h, p.obs, 8 * N, true); want(h, p.zone_obs, Z * F * N, true);
-    want(h, p.reward, N, true); want(h, p.actions, 2 * N, true);
-    want(h, p.done_out, N, true); want(h, p.goal_met, N, true);
-    want(h, p.exception, N, true);
+    want(h, p.actions, 2 * N, true);
+    {   // results slab, in ZENV_RESULT_* order
+        const size_t first = h->allocs.size();
+        want(h, p.obs, 8 * N, true); want(h, p.reward, N, true); want(h, p.done_out, N, true);
+        want(h, p.goal_met, N, true); want(h, p.exception, N, true); want(h, p.zone_obs, Z * F * N, true);
+        int64_t off = 0;
+        for (int i = 0; i < ZENV_N_RESULTS; ++i) {
+            h->allocs[first + i].slab_off = h->results_off[i] = off;
+            off += (int64_t)((h->allocs[first + i].bytes + 255) / 256 * 256);
+        }
+        h->results_bytes = off;
+    }
     want(h, p.dbg, 16 * ((N + 63) / 64), false);
 
     hipError_t err = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
@@ -439,7 +453,17 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
         delete h;
         return fail(ZENV_E_HIP, "hipStreamCreate: %s", hipGetErrorString(err));
     }
+    err = hipMalloc(&h->results_slab, (size_t)h->results_bytes);
+    if (err == hipSuccess) err = hipMemsetAsync(h->results_slab, 0, (size_t)h->results_bytes, h->stream);
+    if (err != hipSuccess) {
+        zenv_destroy(h);
+        return fail(ZENV_E_HIP, "hipMalloc(%lld): %s", (long long)h->results_bytes, hipGetErrorString(err));
+    }
     for (Alloc &a : h->allocs) {
+        if (a.slab_off >= 0) {
+            *a.slot = static_cast<char *>(h->results_slab) + a.slab_off;
+            continue;
+        }
         err = hipMalloc(a.slot, a.bytes);
         if (err == hipSuccess) err = hipMemsetAsync(*a.slot, 0, a.bytes, h->stream);
         if (err != hipSuccess) {
@@ -465,7 +489,8 @@ extern "C" int zenv_destroy(zenv_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (Alloc &a : h->allocs)
-        if (*a.slot) (void)hipFree(*a.slot);
+        if (*a.slot && a.slab_off < 0) (void)hipFree(*a.slot);
+    if (h->results_slab) (void)hipFree(h->results_slab);
     for (void *m : h->bank_mem)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
@@ -1187,6 +1212,29 @@ extern "C" int zenv_get_many(zenv_t *h, int n_fields, const int *fields, void *c
         if (!f.ptr || !dst[i]) return fail(ZENV_E_ARG, "unknown field %d or null destination", fields[i]);
         HIP_TRY(hipMemcpyAsync(dst[i], f.ptr, f.bytes, hipMemcpyDeviceToHost, h->stream));
     }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ZENV_OK;
+}
+
+extern "C" int64_t zenv_results_layout(const zenv_t *h, int64_t *offsets)
+{
+    if (!h) return 0;
+    if (offsets)
+        for (int i = 0; i < ZENV_N_RESULTS; ++i) offsets[i] = h->results_off[i];
+    return h->results_bytes;
+}
+
+extern "C" int zenv_step_results(zenv_t *h, const float *actions, int auto_reset, void *host_slab)
+{
+    if (!h || !host_slab) return fail(ZENV_E_ARG, "null argument");
+    if (actions) {
+        const int rc = zenv_step(h, actions, 0, auto_reset);
+        if (rc) return rc;
+    } else {
+        const int rc = use_device(h);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(host_slab, h->results_slab, (size_t)h->results_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return ZENV_OK;
 }

@@ -78,7 +78,7 @@ class ParallelEnv:
     # ------------------------------------------------------------------ reference surface
     def reset(self):
         self._vec.reset()
-        self._finished = np.zeros(self.num_envs, bool)
+        self._finished = None
         return self._obs_list()
 
     def step(self, actions):
@@ -118,8 +118,8 @@ class ParallelEnv:
     # ------------------------------------------------------------------ array surface
     def step_arrays(self, actions, auto_reset=True):
         """(obs (P,8), zone_obs (P,Z,F), reward (P,), done (P,), goal_met (P,)) float32/bool."""
-        self._vec.step(np.asarray(actions, np.float32).reshape(self.num_envs, 2), auto_reset=auto_reset)
-        return self._vec.results()
+        return self._vec.step_results(np.asarray(actions, np.float32).reshape(self.num_envs, 2),
+                                      auto_reset=auto_reset)[:5]
 
     @property
     def vec(self):
@@ -128,34 +128,41 @@ class ParallelEnv:
 
     # ------------------------------------------------------------------ helpers
     def _obs_list(self):
-        o, zo = self._vec.observations()
+        o, zo = self._vec.step_results(None, copy=False)[:2]
         o = o.astype(np.float64)
         zo = zo.astype(np.float64)
-        return [{"zone_obs": zo[i], "obs": o[i]} for i in range(self.num_envs)]
+        return [{"zone_obs": z, "obs": x} for z, x in zip(zo, o)]
 
     def _step(self, actions, auto_reset):
-        o, zo, r, d, g = self.step_arrays(actions, auto_reset)
-        o = o.astype(np.float64)
+        a = np.asarray(actions, np.float32).reshape(self.num_envs, 2)
+        o, zo, r, d, g, exc = self._vec.step_results(a, auto_reset=auto_reset, copy=False)
+        o = o.astype(np.float64)            # the reference's obs are float64 (ZoneWrapper concatenates float64)
         zo = zo.astype(np.float64)
-        was_finished = getattr(self, "_finished", np.zeros(self.num_envs, bool))
-        goal_info = self._vec.goal_info() if getattr(self, "_goals", False) else None
-        exc = self._vec.get(nat.F_EXCEPTION) if d.any() else None
-        if self._plain_depth is not None and auto_reset and d.any():
+        P = self.num_envs
+        was_finished = getattr(self, "_finished", None)
+        any_done = bool(d.any())
+        if self._plain_depth is not None and auto_reset and any_done:
             # episode k of env i sits in slot i * depth + k: the reset that follows the depth-th episode end would
             # take env i + 1's first map (Engine.reset would play seed _seed + depth)
             if int(self._vec.get(nat.F_EPISODES).max()) >= self._plain_depth:
                 raise RuntimeError(f"ParallelEnv: an env finished its {self._plain_depth} pre-sampled episodes; build "
                                    "it with a larger episodes_per_env, or wrap the envs in FixedSeedsWrapper")
-        results = []
-        for i in range(self.num_envs):
-            info = {} if was_finished[i] else {"cost": 0}   # WaitWrapper no-op: info = {}
-            if g[i]:
-                info["goal_met"] = True
-            if d[i] and not was_finished[i] and exc[i]:
-                info = {"exception": True}                   # Engine.step's MujocoException branch
-            if goal_info is not None:
-                info["shaped_reward"] = float(goal_info[0][i])
-                info["need_next_goal"] = bool(goal_info[1][i])
-            results.append(({"zone_obs": zo[i], "obs": o[i]}, float(r[i]), bool(d[i]), info))
-        self._finished = np.zeros(self.num_envs, bool) if auto_reset else (was_finished | d)
-        return zip(*results)
+        # info dicts: {'cost': 0} for everybody, then the few envs with something to say
+        infos = [{"cost": 0} for _ in range(P)]
+        if was_finished is not None and was_finished.any():
+            for i in np.flatnonzero(was_finished):
+                infos[i] = {}                                 # WaitWrapper no-op: info = {}
+        if any_done:
+            for i in np.flatnonzero(g):
+                infos[i]["goal_met"] = True
+            for i in np.flatnonzero(exc & d):
+                if was_finished is None or not was_finished[i]:
+                    infos[i] = {"exception": True}            # Engine.step's MujocoException branch
+        if getattr(self, "_goals", False):
+            shaped, need = self._vec.goal_info()[:2]
+            for i, (sr, ng) in enumerate(zip(shaped.tolist(), need.tolist())):
+                infos[i]["shaped_reward"] = sr
+                infos[i]["need_next_goal"] = bool(ng)
+        self._finished = None if auto_reset else (d.copy() if was_finished is None else (was_finished | d))
+        obs = tuple({"zone_obs": z, "obs": x} for z, x in zip(zo, o))
+        return obs, tuple(r.astype(np.float64).tolist()), tuple(d.tolist()), tuple(infos)

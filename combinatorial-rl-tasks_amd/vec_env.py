@@ -152,6 +152,10 @@ class ZoneVecEnv:
         if getattr(self, "_h", None) is not None and self._h.value:
             lib().zenv_destroy(self._h)
             self._h = C.c_void_p()
+            if getattr(self, "_slab", None) is not None:     # copy=False views of step_results() die with the env
+                ptr = self._slab.ctypes.data
+                self._slab = self._slab_views = None
+                lib().zenv_host_free(C.c_void_p(ptr))
 
     def __del__(self):
         try:
@@ -420,10 +424,43 @@ class ZoneVecEnv:
         d = (C.c_void_p * len(fields))(*[a.ctypes.data for a in arrays])
         check(lib().zenv_get_many(self._h, len(fields), f, d))
 
+    def _results_slab(self):
+        """One page-locked host image of the handle's results slab, with typed views of its pieces."""
+        if getattr(self, "_slab", None) is None:
+            off = (C.c_int64 * nat.N_RESULTS)()
+            total = lib().zenv_results_layout(self._h, off)
+            raw = self.pinned_array((total,), np.uint8)
+            N, Zn, F = self.num_envs, self.num_zones, self.zone_feat
+
+            def view(i, count, dtype, shape):
+                return raw[off[i]:off[i] + count * np.dtype(dtype).itemsize].view(dtype).reshape(shape)
+            self._slab = raw
+            self._slab_views = (view(nat.RESULT_OBS, N * 8, np.float32, (N, 8)),
+                                view(nat.RESULT_ZONE_OBS, N * Zn * F, np.float32, (N, Zn, F)),
+                                view(nat.RESULT_REWARD, N, np.float32, (N,)),
+                                view(nat.RESULT_DONE, N, np.uint8, (N,)).view(bool),
+                                view(nat.RESULT_GOAL_MET, N, np.uint8, (N,)).view(bool),
+                                view(nat.RESULT_EXCEPTION, N, np.uint8, (N,)).view(bool))
+        return self._slab
+
+    def step_results(self, actions=None, auto_reset=True, copy=True):
+        """One env.step() of a host policy in ONE call (zenv_step_results): action upload, step, download of every
+        per-step result, one synchronisation.  actions None: just the download (after reset()).  Returns
+        (obs, zone_obs, reward, done, goal_met, exception); with copy=False the arrays are views of one page-locked
+        buffer that the next call overwrites."""
+        slab = self._results_slab()
+        a = None
+        if actions is not None:
+            a = np.ascontiguousarray(actions, np.float32)
+            if a.shape != (self.num_envs, 2):
+                raise ValueError(f"actions must have shape ({self.num_envs}, 2)")
+        check(lib().zenv_step_results(self._h, None if a is None else a.ctypes.data, int(bool(auto_reset)),
+                                      slab.ctypes.data))
+        return tuple(v.copy() for v in self._slab_views) if copy else self._slab_views
+
     def results(self):
         """(obs, zone_obs, reward, done, goal_met) of the last step, as host arrays."""
-        return (self.get(nat.F_OBS), self.get(nat.F_ZONE_OBS), self.get(nat.F_REWARD),
-                self.get(nat.F_DONE).astype(bool), self.get(nat.F_GOAL_MET).astype(bool))
+        return self.step_results(None)[:5]
 
     # ------------------------------------------------------------------ snapshots / debug
     def get_state(self):

@@ -301,6 +301,24 @@ int zenv_sync(zenv_t *h);
 void *zenv_host_alloc(int64_t bytes);
 int zenv_host_free(void *ptr);
 int zenv_get_many(zenv_t *h, int n_fields, const int *fields, void *const *dst);
+/* The per-step results a host policy reads back -- what one `worker` of the reference pickles into its Pipe after
+ * env.step() (main/src/torch_ac/torch_utils/penv.py:8-12, 52-59) -- live in ONE device allocation, 256-byte aligned
+ * pieces in ZENV_RESULT_* order, so that a step of a small batch (the reference trains with 16 envs,
+ * scripts/train_ppo.py:29-30) costs one upload, one launch, one download and one synchronisation:
+ * zenv_results_layout() returns the slab's size and the piece offsets (offsets may be NULL);
+ * zenv_step_results() = zenv_step(actions on the host) + download of the whole slab into host_slab (page-locked
+ * memory from zenv_host_alloc for DMA) + synchronise; actions == NULL only downloads (after zenv_reset). */
+enum {
+    ZENV_RESULT_OBS = 0,        /* float32 [N][8]            */
+    ZENV_RESULT_REWARD = 1,     /* float32 [N]               */
+    ZENV_RESULT_DONE = 2,       /* uint8   [N]               */
+    ZENV_RESULT_GOAL_MET = 3,   /* uint8   [N]               */
+    ZENV_RESULT_EXCEPTION = 4,  /* uint8   [N]               */
+    ZENV_RESULT_ZONE_OBS = 5,   /* float32 [N][Z][F]         */
+    ZENV_N_RESULTS = 6
+};
+int64_t zenv_results_layout(const zenv_t *h, int64_t *offsets /* [ZENV_N_RESULTS] or NULL */);
+int zenv_step_results(zenv_t *h, const float *actions, int auto_reset, void *host_slab);
 /* Enqueue everything from now on onto the caller's HIP stream (hipStream_t passed as void*; NULL =
  * back to the handle's own stream; the null stream is named by hipStreamLegacy).  The handle first
  * drains the stream it was using.  This is how

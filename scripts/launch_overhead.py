@@ -36,3 +36,15 @@ t0 = time.perf_counter()
 for _ in range(100):
     env.sync(); torch.cuda.synchronize()
 print("idle env.sync + torch sync: %.1f us" % ((time.perf_counter() - t0) * 1e4))
+# bench.py's own sequence: a long settle rollout, W warm-up steps, fence, ONE timed call of `steps` steps, fence
+for rep in range(8):
+    env.rollout(6000 - 5, Z.POLICY_GREEDY)
+    env.rollout(5, Z.POLICY_GREEDY)
+    env.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tot, _ = env.rollout(steps, Z.POLICY_GREEDY, policy_seed=0x5EED, env_index0=0, auto_reset=True, time_step_kernel=False,
+                         mode="persistent", event_stride=16)
+    t1 = time.perf_counter()
+    env.sync(); torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("bench sequence: wall %.1f us (rollout call %.1f), bracket events %.1f us" % ((t2 - t0) * 1e6, (t1 - t0) * 1e6, tot * 1e3))

@@ -271,3 +271,37 @@ def test_order_env_facade(zenv_mod, oracle_mod):
     rev.reset()
     assert rev.route == list(range(14, -1, -1))
     rev.close()
+
+
+@pytest.mark.gpu
+def test_step_results_is_step_plus_every_download(zenv_mod):
+    """zenv_step_results (one upload, one launch, ONE download of the results slab, one synchronisation) against
+    zenv_step + zenv_get of each field; the slab's pieces are 256-byte aligned, in ZENV_RESULT_* order."""
+    import ctypes as C
+    Z = zenv_mod
+    nat = Z._native
+    for env_id, n in (("PointTSP-v0", 16), ("ColourMatch-v0", 1), ("PointTTSP-v0", 333)):
+        cfg = Z.config_for_id(env_id)
+        a_env, b_env = Z.ZoneVecEnv(cfg, n), Z.ZoneVecEnv(cfg, n)
+        off = (C.c_int64 * nat.N_RESULTS)()
+        total = nat.lib().zenv_results_layout(a_env._h, off)
+        sizes = [n * 8 * 4, n * 4, n, n, n, n * cfg.num_zones * a_env.zone_feat * 4]
+        assert list(off) == sorted(off) and all(o % 256 == 0 for o in off) and total % 256 == 0
+        assert all(off[i] + sizes[i] <= (off[i + 1] if i + 1 < nat.N_RESULTS else total) for i in range(nat.N_RESULTS))
+        for e in (a_env, b_env):
+            e.build_bank(1, 4 * n)
+            e.schedule_sequential(stride=n)
+            e.reset()
+        first = a_env.step_results(None)
+        assert np.array_equal(first[0], b_env.get(Z.F_OBS)) and np.array_equal(first[1], b_env.get(Z.F_ZONE_OBS))
+        rs = np.random.RandomState(3)
+        for t in range(40):
+            act = rs.uniform(-1, 1, (n, 2)).astype(np.float32)
+            got = a_env.step_results(act, auto_reset=True, copy=(t % 2 == 0))
+            b_env.step(act, auto_reset=True)
+            for arr, f in zip(got, (Z.F_OBS, Z.F_ZONE_OBS, Z.F_REWARD, Z.F_DONE, Z.F_GOAL_MET, Z.F_EXCEPTION)):
+                assert np.array_equal(np.asarray(arr).astype(b_env.get(f).dtype), b_env.get(f)), (env_id, t, f)
+        with pytest.raises(ValueError):
+            a_env.step_results(np.zeros((n + 1, 2), np.float32))
+        a_env.close()
+        b_env.close()
