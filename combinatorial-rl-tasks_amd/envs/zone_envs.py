@@ -105,16 +105,21 @@ class ZoneEnvBase:
     def step(self, action):
         assert not self.done, "Environment must be reset before stepping"   # Engine.step
         a = np.asarray(action, dtype=np.float32).reshape(1, 2)
-        self._vec.step(a, auto_reset=False)
-        reward = float(self._vec.get(nat.F_REWARD)[0])
-        self.done = bool(self._vec.get(nat.F_DONE)[0])
+        # one call: action upload, step kernel, ONE download of every result, one synchronisation
+        o, zo, r, d, g, exc = self._vec.step_results(a, auto_reset=False, copy=False)
+        reward = float(r[0])
+        self.done = bool(d[0])
         self.steps += 1
         info = {"cost": 0}
-        if self._vec.get(nat.F_GOAL_MET)[0]:
+        if g[0]:
             info["goal_met"] = True
-        if self.done and self._vec.get(nat.F_EXCEPTION)[0]:
+        if self.done and exc[0]:
             info = {"exception": True}       # Engine.step's MujocoException branch: no cost(), no goal test
-        return self.obs(), reward, self.done, info
+        self._fresh = (o[0].astype(np.float64), zo[0].astype(np.float64))
+        try:
+            return self.obs(), reward, self.done, info
+        finally:
+            self._fresh = None
 
     def close(self):
         self._vec.close()
@@ -137,8 +142,11 @@ class ZoneEnvBase:
 
     def obs(self):
         """ZoneEnvBase.obs(): the raw dict, float64 like the reference's numpy arrays."""
-        o = self._vec.get(nat.F_OBS)[0].astype(np.float64)
-        zo = self._vec.get(nat.F_ZONE_OBS)[0].astype(np.float64)
+        if getattr(self, "_fresh", None) is not None:      # inside step(): the arrays that call just downloaded
+            o, zo = self._fresh
+        else:
+            o, zo = self._vec.step_results(None, copy=False)[:2]
+            o, zo = o[0].astype(np.float64), zo[0].astype(np.float64)
         out = {"remaining": o[0:1]}
         for i in range(self.num_cities):
             out[f"zones_lidar_{i}"] = zo[i]

@@ -31,3 +31,15 @@ for P in (1, 16, 256, 4096):
         dt = (time.perf_counter() - t0) / T
         print("P %5d  %-44s %8.1f us/step  %10.0f env-steps/s" % (P, name, dt * 1e6, P / dt))
     pe.close()
+# the single-env gym surface (what one `worker` process of the reference runs)
+e = make_train_env(env_id, rng_seed=1)
+e.reset()
+a1 = np.array([0.5, 0.1], np.float32)
+for _ in range(20):
+    e.step(a1)
+t0 = time.perf_counter()
+for _ in range(300):
+    _, _, done, _ = e.step(a1)
+    if done:
+        e.reset()
+print("single env  env.step (ZoneWrapper dict)                %8.1f us/step" % ((time.perf_counter() - t0) / 300 * 1e6))
