@@ -152,9 +152,10 @@ class ZoneVecEnv:
         if getattr(self, "_h", None) is not None and self._h.value:
             lib().zenv_destroy(self._h)
             self._h = C.c_void_p()
-            if getattr(self, "_slab", None) is not None:     # copy=False views of step_results() die with the env
-                ptr = self._slab.ctypes.data
-                self._slab = self._slab_views = None
+            # the handle's own page-locked images (copy=False views of step_results() die with the env)
+            ptrs = [a.ctypes.data for a in getattr(self, "_own_pinned", [])]
+            self._own_pinned, self._slab, self._slab_views, self._goal_host = [], None, None, None
+            for ptr in ptrs:
                 lib().zenv_host_free(C.c_void_p(ptr))
 
     def __del__(self):
@@ -278,8 +279,12 @@ class ZoneVecEnv:
 
     def goal_info(self):
         """(shaped_reward float64 [N], need_next_goal bool [N], available uint32 bit masks [N], goal int32 [N])."""
-        return (self.get(nat.F_SHAPED_REWARD), self.get(nat.F_NEED_GOAL).astype(bool), self.get(nat.F_AVAILABLE_GOALS),
-                self.get(nat.F_GOAL))
+        if getattr(self, "_goal_host", None) is None:      # page-locked images: four downloads, one synchronisation
+            fields = (nat.F_SHAPED_REWARD, nat.F_NEED_GOAL, nat.F_AVAILABLE_GOALS, nat.F_GOAL)
+            self._goal_host = (fields, [self._own_pinned_array(self._shape(f), _FIELD_DTYPES[f]) for f in fields])
+        fields, arrays = self._goal_host
+        self.results_into(fields, arrays)
+        return (arrays[0].copy(), arrays[1].astype(bool), arrays[2].copy(), arrays[3].copy())
 
     # ------------------------------------------------------------------ actor network (SURVEY 8(f) row 1)
     def load_mlp(self, tensors, precision="bf16"):
@@ -418,6 +423,13 @@ class ZoneVecEnv:
         buf = (C.c_char * max(nbytes, 1)).from_address(ptr)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
+    def _own_pinned_array(self, shape, dtype):
+        a = self.pinned_array(shape, dtype)
+        if getattr(self, "_own_pinned", None) is None:
+            self._own_pinned = []
+        self._own_pinned.append(a)
+        return a
+
     def results_into(self, fields, arrays):
         """Downloads of several fields, one synchronisation (zenv_get_many); arrays should be pinned_array()s."""
         f = (C.c_int * len(fields))(*[int(x) for x in fields])
@@ -429,7 +441,7 @@ class ZoneVecEnv:
         if getattr(self, "_slab", None) is None:
             off = (C.c_int64 * nat.N_RESULTS)()
             total = lib().zenv_results_layout(self._h, off)
-            raw = self.pinned_array((total,), np.uint8)
+            raw = self._own_pinned_array((total,), np.uint8)
             N, Zn, F = self.num_envs, self.num_zones, self.zone_feat
 
             def view(i, count, dtype, shape):
