@@ -351,3 +351,21 @@ def test_evaluate_with_a_checkpoint(zenv_mod):
     assert (ret == ret[:, :1]).all() and (length == length[:, :1]).all()
     smp = evaluate("PointTSP-v1", sd, n_maps=6, n_runs_per_map=3, policy_seed=9, max_steps=120)
     assert np.array(smp["return"]).shape == (6, 3)
+    # the same agent from a reference-style model directory (utils.get_model_state: status.pt -> 'model_state')
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        torch.save({"num_frames": 0, "update": 0, "model_state": sd, "optimizer_state": {}}, os.path.join(d, "status.pt"))
+        again = evaluate("PointTSP-v1", d, n_maps=6, n_runs_per_map=3, argmax=True, max_steps=120)
+    assert again["return"] == det["return"] and again["length"] == det["length"]
+    # a host callable sees the same observations the device policy saw: the mean action of the torch module, on the host
+    model = ex.ActorCritic(6)
+    model.load_state_dict(sd)
+
+    def host_policy(o, zo):
+        with torch.no_grad():
+            dist, _ = model(torch.from_numpy(np.array(o)), torch.from_numpy(np.array(zo)))
+        return dist.mean.numpy()
+    host = evaluate("PointTSP-v1", host_policy, n_maps=6, n_runs_per_map=3, max_steps=120)
+    assert np.array(host["return"]).shape == (6, 3)
+    # the device's float32 mode is within 1e-5 of these torch actions: over 120 steps the visits agree
+    assert (np.array(host["return"]) == ret).mean() >= 0.8

@@ -234,3 +234,28 @@ def test_host_sampler_against_live_numpy_restatement(zenv_mod):
         elif task == 2:
             assert np.array_equal(aux, np.random.RandomState(seed).choice(3, zones))
     assert restarts_seen > 20                    # the whole-layout restart path was exercised
+
+
+def test_load_model_state_reads_a_reference_model_dir(tmp_path):
+    """utils.get_model_state (main/src/utils/storage.py:36-52): status.pt -> 'model_state', from the directory or the file."""
+    import torch
+    from combinatorial_rl_tasks_amd.evaluate import load_model_state
+    from combinatorial_rl_tasks_amd.vec_env import mlp_tensors_from_state_dict
+    from oracle import policy_ref as P
+    t = P.random_tensors(6, seed=2, distributional=True)
+    names = {"zone_w1": "env_model.zone_net_.0.weight", "zone_b1": "env_model.zone_net_.0.bias",
+             "zone_w2": "env_model.zone_net_.2.weight", "zone_b2": "env_model.zone_net_.2.bias",
+             "zone_w3": "env_model.zone_net_.4.weight", "zone_b3": "env_model.zone_net_.4.bias",
+             "comb_w": "env_model.combine_net_.weight", "comb_b": "env_model.combine_net_.bias",
+             "enc_w": "actor.enc_.0.0.weight", "enc_b": "actor.enc_.0.0.bias", "mu_w": "actor.mu_.weight",
+             "mu_b": "actor.mu_.bias", "std_w": "actor.std_.weight", "std_b": "actor.std_.bias",
+             "critic_w1": "critic.0.weight", "critic_b1": "critic.0.bias", "critic_w2": "critic_mu.weight",
+             "critic_b2": "critic_mu.bias", "critic_sigma_w": "critic_sigma.weight", "critic_sigma_b": "critic_sigma.bias"}
+    sd = {names[k]: torch.from_numpy(v) for k, v in t.items()}
+    torch.save({"num_frames": 123, "update": 4, "model_state": sd, "optimizer_state": {"state": {}}}, tmp_path / "status.pt")
+    for where in (str(tmp_path), str(tmp_path / "status.pt")):
+        back = mlp_tensors_from_state_dict(load_model_state(where))
+        assert sorted(back) == sorted(t) and all(np.array_equal(back[k], t[k]) for k in t)
+    torch.save({"num_frames": 0}, tmp_path / "status.pt")
+    with pytest.raises(KeyError):
+        load_model_state(str(tmp_path))
