@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "mlp_policy.hpp"
@@ -383,6 +384,7 @@ __device__ __forceinline__ bf16x8 zone_frag(const ZoneRow &x, const uint4 obs_fr
 }
 
 constexpr int kZone1Waves = 4;
+constexpr int kMlpSplitMaxEnvs = 8192;    // at most this many envs: zone tiles of a 32-env group split over the workgroup's waves
 #ifndef MLP_GAPS
 #define MLP_GAPS 6          // MFMA gaps that carry VALU work in a region ...
 #define MLP_PER_GAP 6       // ... and instructions per gap (32 per region: 16 + 16 conversions)
@@ -479,11 +481,15 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
     for (int kk = 0; kk < KS; ++kk) wf0[kk] = in_agpr(wf[NT & 1][kk]);   // (read a whole chain ago: no wait)
 }
 
-template <int ZT, int F>
+template <int ZT, int F, bool SPLIT>
 __global__ __launch_bounds__(kZone1Waves * kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, const float *__restrict__ zone_obs,
-                 __bf16 *__restrict__ pooled)
+                 __bf16 *__restrict__ pooled, int envs_per_wave)
 {
+    // Batch layout (launch_mlp_forward picks it by N so that a small batch still spreads over the chip):
+    //   !SPLIT: a wave owns envs_per_wave (64 or 32) envs and all their zone tiles;
+    //   SPLIT:  the workgroup's four waves share ONE group of 32 envs, wave w takes zones w, w + 4, ...; the partial
+    //           sums of waves 1-3 meet wave 0's in LDS (behind the weight images).
     extern __shared__ uint4 lds[];
     uint4 *w2s = lds;                       // [NT*KS][64]
     uint4 *w1s = lds + NT * KS * kWave;     // [NT][64]
@@ -511,12 +517,18 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
     __syncthreads();
 
     const int Z = ZT > 0 ? ZT : Z_rt;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: the tile loop's bounds are scalar
     const int r = lane & 31, h = lane >> 5;
-    const int env0 = (blockIdx.x * kZone1Waves + wave) * kWave;
-    if (env0 >= N) return;
-    const int n_env = min(kWave, N - env0);
+    constexpr bool split = SPLIT;
+    const int env0 = split ? (int)blockIdx.x * 32 : (int)(blockIdx.x * kZone1Waves + wave) * envs_per_wave;
+    if (env0 >= N) return;                                    // (split: the whole workgroup, so nobody misses the barrier)
+    const int n_env = min(split ? 32 : envs_per_wave, N - env0);
     const float inv_z = 1.0f / (float)Z;
+    // this wave's tiles: zones z_first, z_first + z_step, ... (n_tiles of them)
+    const int z_first = split ? wave : 0, z_step = split ? kZone1Waves : 1;
+    const int n_tiles = split ? (Z - wave + kZone1Waves - 1) / kZone1Waves : Z;     // !SPLIT, ZT > 0: a constant
+    float *red = reinterpret_cast<float *>(lds + (NT * KS + NT) * kWave);   // [3][NT * 16][64] floats, split only
 #ifdef MLP_STAMP
     int stamp_it = 0;
 #endif
@@ -553,47 +565,65 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
         bf16x8 wf0[KS];
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) wf0[kk] = in_agpr(as_frag(w2s[kk * kWave + lane]));
+        const auto zone_of = [&](int tile) { return z_first + z_step * min(tile, max(n_tiles - 1, 0)); };
         // prologue: layer 1 of tile 0 (not overlapped: once per Z tiles)
-        ZoneRow nxt = load_zone_row<F>(rows, 0);
+        ZoneRow nxt = load_zone_row<F>(rows, min(zone_of(0), Z - 1));
         bf16x8 xa[KS], xb[KS];
         bf16x8 x0n;
         f32x16 a1;
         {
             const bf16x8 x0 = zone_frag<F>(nxt, obs_frag, valid, h);
-            nxt = load_zone_row<F>(rows, min(1, Z - 1));
+            nxt = load_zone_row<F>(rows, min(zone_of(1), Z - 1));
 #pragma unroll
             for (int m = 0; m < NT; ++m) {
                 const f32x16 acc1 = mfma(w1f[m], x0, zero16());
                 acc_to_frags(acc1, true, xa[2 * m], xa[2 * m + 1]);
             }
             x0n = zone_frag<F>(nxt, obs_frag, valid, h);                           // tile 1
-            nxt = load_zone_row<F>(rows, min(2, Z - 1));
+            nxt = load_zone_row<F>(rows, min(zone_of(2), Z - 1));
             a1 = mfma(w1f[0], x0n, zero16());
         }
-        for (int t = 0; t < Z; t += 2) {
+        for (int t = 0; t < n_tiles; t += 2) {
             {
                 const bf16x8 x0nn = zone_frag<F>(nxt, obs_frag, valid, h);         // tile t + 2
                 __builtin_amdgcn_sched_barrier(0);
-                nxt = load_zone_row<F>(rows, min(t + 3, Z - 1));
+                nxt = load_zone_row<F>(rows, zone_of(t + 3));
                 zone_tile(w2s, lane, w1f, ind, xa, xb, x0n, x0nn, a1, pend, pool, wf0 ZT_STAMP_ARGS);
                 x0n = x0nn;
             }
-            if (t + 1 < Z) {
+            if (t + 1 < n_tiles) {
                 const bf16x8 x0nn = zone_frag<F>(nxt, obs_frag, valid, h);         // tile t + 3
                 __builtin_amdgcn_sched_barrier(0);
-                nxt = load_zone_row<F>(rows, min(t + 4, Z - 1));
+                nxt = load_zone_row<F>(rows, zone_of(t + 4));
                 zone_tile(w2s, lane, w1f, ind, xb, xa, x0n, x0nn, a1, pend, pool, wf0 ZT_STAMP_ARGS);
                 x0n = x0nn;
             }
         }
-        // the last chain of the last tile
-        {
+        // the last chain of the last tile (a wave without tiles -- split, Z < 4 -- has nothing pending)
+        if (n_tiles > 0) {
             bf16x8 f0, f1;
             acc_to_frags(pend, true, f0, f1);
             pool_mfma(pool[NT - 1], ind[0], f0);
             pool_mfma(pool[NT - 1], ind[1], f1);
         }
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // asm MFMA results -> v_accvgpr_read
+        if (split) {
+            // waves 1-3 leave their partial sums in LDS ([register][lane]: conflict-free), wave 0 adds them in wave order
+            if (wave > 0) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) red[((wave - 1) * NT * 16 + n * 16 + i) * kWave + lane] = pool[n][i];
+            }
+            __syncthreads();
+            if (wave > 0) return;
+#pragma unroll
+            for (int w = 0; w < kZone1Waves - 1; ++w)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) pool[n][i] += red[(w * NT * 16 + n * 16 + i) * kWave + lane];
+        }
         // ---- the group's means: accumulator register i of lane half h is env slot (i&3) + 8 (i>>2) + 4 h
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -853,21 +883,50 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
 {
     if (img.f32) return launch_mlp_forward_f32(*img.f32, N, Z, F, obs, zone_obs, mu, stdv, value, value_sigma, act, s);
     __bf16 *pooled = static_cast<__bf16 *>(pooled_v);
-    const dim3 grid((N + 4 * kWave - 1) / (4 * kWave));   // one workgroup per 4 groups of 64 envs
-    const size_t lds = (size_t)(NT * KS + NT) * kWave * sizeof(uint4);
+    // Batch layout of the zone kernel.  A wave works through its tiles one after the other (~1.1 us each), so a small
+    // batch laid out like a full one leaves the chip idle for the same 100 us: below kMlpSplitMaxEnvs a workgroup's four
+    // waves share one group of 32 envs (zones w, w + 4, ... each; partial sums meet in LDS), up to 32 768 envs a wave
+    // owns one group of 32, above that two.
+    int epw = N <= 32768 ? 32 : kWave, zsplit = (N <= kMlpSplitMaxEnvs && Z >= kZone1Waves) ? kZone1Waves : 1;
+    if (const char *force = std::getenv("ZENV_MLP_LAYOUT")) {      // diagnostic: "64", "32" or "split"
+        zsplit = std::strcmp(force, "split") == 0 ? kZone1Waves : 1;
+        epw = std::strcmp(force, "64") == 0 ? kWave : 32;
+    }
+#if MLP_KERNEL != 1
+    epw = kWave, zsplit = 1;      // the predecessor kernel knows one layout
+#endif
+    const dim3 grid(zsplit > 1 ? (N + 31) / 32 : (N + kZone1Waves * epw - 1) / (kZone1Waves * epw));
+    const size_t lds = (size_t)(NT * KS + NT) * kWave * sizeof(uint4) +
+                       (zsplit > 1 ? (size_t)(kZone1Waves - 1) * NT * 16 * kWave * sizeof(float) : 0);
 #if MLP_KERNEL == 1
 #define ZENV_MLP_KERNEL k_mlp_zone1
+#define ZENV_MLP_LAYOUT_ARGS , epw
     const dim3 block(kZone1Waves * kWave);
 #else
 #define ZENV_MLP_KERNEL k_mlp_zone
+#define ZENV_MLP_LAYOUT_ARGS
     const dim3 block(kZoneWaves * kWave);
 #endif
+#if MLP_KERNEL == 1
+#define ZENV_MLP_1(KERN)                                                                                          \
+    do {                                                                                                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERN), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds);                                                                      \
+        hipLaunchKernelGGL(KERN, grid, block, lds, s, img, N, Z, obs, zone_obs, pooled ZENV_MLP_LAYOUT_ARGS);      \
+    } while (0)
+#define ZENV_MLP(ZT, FF)                                                                                          \
+    do {                                                                                                          \
+        if (zsplit > 1) ZENV_MLP_1((k_mlp_zone1<ZT, FF, true>));                                                  \
+        else ZENV_MLP_1((k_mlp_zone1<ZT, FF, false>));                                                            \
+    } while (0)
+#else
 #define ZENV_MLP(ZT, FF)                                                                                          \
     do {                                                                                                          \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ZENV_MLP_KERNEL<ZT, FF>),                       \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
         hipLaunchKernelGGL((ZENV_MLP_KERNEL<ZT, FF>), grid, block, lds, s, img, N, Z, obs, zone_obs, pooled);      \
     } while (0)
+#endif
     if (F == 6) {
         switch (Z) {
         case 25: ZENV_MLP(25, 6); break;
@@ -883,7 +942,9 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
         }
     }
 #undef ZENV_MLP
+#undef ZENV_MLP_1
 #undef ZENV_MLP_KERNEL
+#undef ZENV_MLP_LAYOUT_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds_head = 2 * (size_t)kImgFrags * kWave * sizeof(uint4);

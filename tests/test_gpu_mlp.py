@@ -22,9 +22,13 @@ def _env_with_obs(Z, env_id, n, steps, **over):
 
 @pytest.mark.parametrize("env_id,n,steps", [("PointTSP-v0", 64, 0), ("PointTSP-v0", 203, 40), ("PointTTSP-v0", 130, 25),
                                             ("ColourMatch-v0", 77, 60), ("PointTSP-v1", 65, 10)])
-def test_mlp_forward_matches_torch(zenv_mod, env_id, n, steps):
+@pytest.mark.parametrize("layout", ["split", "32", "64"])
+def test_mlp_forward_matches_torch(zenv_mod, env_id, n, steps, layout, monkeypatch):
+    """Every batch layout of the zone kernel (launch_mlp_forward picks by N: zone tiles of a 32-env group split over a
+    workgroup's waves for small batches, 32 or 64 envs per wave above) against both torch restatements."""
     from oracle import policy_ref as P
     Z = zenv_mod
+    monkeypatch.setenv("ZENV_MLP_LAYOUT", layout)
     env = _env_with_obs(Z, env_id, n, steps)
     t = P.random_tensors(env.zone_feat, h=185, seed=5)
     env.load_mlp(t)
@@ -37,6 +41,28 @@ def test_mlp_forward_matches_torch(zenv_mod, env_id, n, steps):
     assert np.abs(mu - mu_e).max() < 4e-3 and np.abs(std - std_e).max() < 4e-3
     assert np.abs(mu - mu_r).max() < 4e-2 and np.abs(std - std_r).max() < 4e-2
     env.close()
+
+
+def test_mlp_layouts_agree_and_the_default_follows_the_batch_size(zenv_mod, monkeypatch):
+    """The three layouts compute the same sums in different orders: outputs agree to float32 reassociation (the zone mean
+    is rounded to bf16 once, so a rare one-ulp flip of that rounding is the largest difference); Z < 4 cannot split."""
+    from oracle import policy_ref as P
+    Z = zenv_mod
+    for env_id, n, over in (("PointTSP-v0", 1000, {}), ("ColourMatch-v0", 97, {}), ("PointTSP-v0", 70, {"num_zones": 3})):
+        env = _env_with_obs(Z, env_id, n, 20, **over)
+        env.load_mlp(P.random_tensors(env.zone_feat, seed=2))
+        out = {}
+        for layout in ("split", "32", "64", None):
+            if layout is None:
+                monkeypatch.delenv("ZENV_MLP_LAYOUT")
+            else:
+                monkeypatch.setenv("ZENV_MLP_LAYOUT", layout)
+            out[layout] = env.mlp_forward()
+        for layout in ("32", "split", None):
+            assert np.abs(out[layout][0] - out["64"][0]).max() < 2e-3 and np.abs(out[layout][1] - out["64"][1]).max() < 2e-3
+        assert np.array_equal(out["32"][0], out["64"][0])             # same order of sums: identical
+        assert np.array_equal(out[None][0], out["split"][0] if env.num_zones >= 4 else out["32"][0])
+        env.close()
 
 
 def test_mlp_value_head(zenv_mod):
