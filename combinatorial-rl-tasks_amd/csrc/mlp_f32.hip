@@ -7,19 +7,21 @@
 // fast mode (their operands carry 8 significant bits).  Only the summation order differs from torch's GEMM, and the
 // mean over an env's zone rows is taken BEFORE zone_net_'s third (activation-free) layer, with which it commutes.
 //
-// Shape: a workgroup of kMlpHP = 192 threads owns EB consecutive envs; thread j owns hidden feature j.  An input
-// row's activations sit in LDS ([k][row], row-contiguous: one ds_read_b128 = 4 rows of a feature, the same address in
-// every lane = a broadcast), the weights are read from memory transposed ([k][j]: 192 consecutive floats per k, served
-// by L2 -- every workgroup streams the same 0.6 MB), each thread keeps RP = 32 row accumulators in registers.
-// ~1 FMA per LDS-or-global access byte is not what bounds this kernel: its float32 vector FMAs are (61 GFMA per step
-// at N = 65 536, Z = 25 = 0.8 ms at the 157 TFLOP/s vector peak; measured: DESIGN.md section 4).
+// Two kernels, chosen by batch size (launch_mlp_forward_f32):
 //
-// The zone part -- 84 % of the FLOPs, GEMM-shaped -- runs on the float32 MATRIX instruction instead
-// (k_mlp_zone_f32m: v_mfma_f32_32x32x2_f32, bit for bit a k-ordered fmaf chain at the vector rate, one VGPR per
-// operand): a 32x32 result has its column (zone row / env slot) on the lane and its rows (features) in the 16
-// registers, so relu(layer 1) IS layer 2's B operand register by register when layer 2's weights are packed in that
-// k order; both weight images (147 KB + 12 KB) sit in LDS, one workgroup per CU.  It leaves the per-env zone means in
-// a float32 scratch array; k_mlp_f32 then runs only its per-env head on them (pooled_in).
+//  * k_mlp_zone_f32m -- the WHOLE network on the float32 MATRIX instruction (v_mfma_f32_32x32x2_f32: bit for bit a
+//    k-ordered fmaf chain at the vector rate, one VGPR per operand).  A 32x32 result has its column (zone row / env
+//    slot) on the lane and its rows (features) in the 16 registers, so relu(layer n) IS layer n + 1's B operand
+//    register by register when that layer's weights are packed in accumulator k order; the two zone layers' images
+//    (147 KB + 12 KB) sit in LDS, one workgroup per CU; the per-env head layers chain on in the same registers with
+//    their images read from L2.  1.12 ms per step at N = 65 536 = 0.76 of the float32 MFMA peak; 0.56 ms from
+//    N = 4 096 to 32 768 (one 32-env group per wave).
+//  * k_mlp_f32 -- vector ALU, for small batches (evaluate(): 500 envs): a workgroup of kMlpHP = 192 threads owns EB
+//    consecutive envs, thread j owns hidden feature j.  An input row's activations sit in LDS ([k][row],
+//    row-contiguous: one ds_read_b128 = 4 rows of a feature, the same address in every lane = a broadcast), the weights
+//    are read from memory transposed ([k][j]: 192 consecutive floats per k, served by L2 -- every workgroup streams
+//    the same 0.6 MB), each thread keeps RP = 32 row accumulators in registers.  (pooled_in: a diagnostic entry that
+//    takes the per-env zone sums from a float32 array instead of computing them.)
 #include <hip/hip_runtime.h>
 
 #include "mlp_head_out.hpp"

@@ -254,7 +254,7 @@ int zenv_route_ranks(const double *robot_xy, const double *zone_xy, int num_zone
  * layout (row-major [out][in]); F = zenv_zone_feat(cfg).  h_dim <= 191 (the reference uses 185). */
 enum {
     ZENV_MLP_BF16 = 0,  /* bf16 MFMA, float32 accumulation: ~20x faster, mu / std within 4e-2 of the reference's float32 */
-    ZENV_MLP_F32 = 1    /* float32 FMA throughout: mu / std / value within 1e-5 of the reference's torch float32 --
+    ZENV_MLP_F32 = 1    /* float32 throughout (f32 MFMA / FMA): mu / std / value within 1e-5 of the reference's torch float32 --
                          * the mode in which evaluate() with a checkpoint reproduces the reference's arithmetic */
 };
 typedef struct zenv_mlp_weights {
