@@ -1,11 +1,12 @@
 """Throughput of zenv_collect (one PPO rollout on the device: actor-critic forward, sampling, record, env step,
-GAE) at N = 65 536 envs."""
+GAE).  usage: python scripts/collect_bench.py [T = 64] [N = 65536]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import combinatorial_rl_tasks_amd as Z
 import combinatorial_rl_tasks_amd._native as nat
-n, T = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 64
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 cfg = Z.default_config(0, 25, zones_keepout=0.40)
 env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n, n_threads=16); env.reset()
 rs = np.random.RandomState(0)
