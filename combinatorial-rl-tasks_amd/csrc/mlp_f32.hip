@@ -137,9 +137,9 @@ __global__ __launch_bounds__(HP) void k_mlp_f32(MlpF32 w, int N, int Z, int F, c
     }
     __syncthreads();
     float t[EB];
-    matvec(t, w.w3t, w.b3, vb, HP, h, j);                                  // zone_net_.4 (no activation)
+    // zone_net_.4 (no activation, applied to the mean) is folded into combine_net_ by pack_f32: [obs; mean] -> c
 #pragma unroll
-    for (int e = 0; e < EB; ++e) va[e * (8 + HP) + 8 + j] = live ? t[e] : 0.f;
+    for (int e = 0; e < EB; ++e) va[e * (8 + HP) + 8 + j] = vb[e * HP + j];
     __syncthreads();
     matvec(t, w.wct, w.bc, va, 8 + HP, 8 + h, j);                          // combine_net_ -> embedding c
     __syncthreads();
@@ -368,8 +368,8 @@ void k_mlp_zone_f32m(MlpF32 w, int N, int Z, int F, const float *__restrict__ ob
 #pragma unroll
             for (int i = 0; i < 16; ++i) P[n][i] *= inv_z;              // the mean; its feature h_dim is the constant 1
         f32x16 e3[NT], cc[NT];
-        head_layer_f32m<0, false>(w.w3m, lane, P, xo, e3);               // zone_net_.4 (no activation)
-        head_layer_f32m<4, false>(w.wcm, lane, e3, xo, cc);              // combine_net_([obs, zone_emb]) -> c
+        // zone_net_.4 (no activation, applied to the mean) is folded into combine_net_ by pack_f32: one layer
+        head_layer_f32m<4, false>(w.wcm, lane, P, xo, cc);               // combine_net_([obs, zone_net_.4(mean)]) -> c
         float v_mu = 0.f, v_sigma = 0.f;
         if (w.has_critic) {
             head_layer_f32m<0, true>(w.wv1m, lane, cc, xo, e3);          // relu(critic.0(c))
@@ -408,10 +408,25 @@ size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_
         for (int o = 0; o < n; ++o) out[at + o] = b[o];
         return at;
     };
+    // zone_net_.4 folded into combine_net_ (no activation between them; the mean commutes with zone_net_.4):
+    //   c = Wc [obs; W3 m + b3] + bc = Wc_obs obs + (Wc_emb W3) m + (Wc_emb b3 + bc), products in float64
+    std::vector<float> combf((size_t)h * (8 + h)), bcf(h);
+    for (int i = 0; i < h; ++i) {
+        const float *ci = w.comb_w + (size_t)i * (8 + h);
+        for (int k = 0; k < 8; ++k) combf[(size_t)i * (8 + h) + k] = ci[k];
+        for (int j = 0; j < h; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < h; ++k) a += (double)ci[8 + k] * (double)w.zone_w3[(size_t)k * h + j];
+            combf[(size_t)i * (8 + h) + 8 + j] = (float)a;
+        }
+        double b = (double)w.comb_b[i];
+        for (int k = 0; k < h; ++k) b += (double)ci[8 + k] * (double)w.zone_b3[k];
+        bcf[i] = (float)b;
+    }
     offs[0] = transposed(w.zone_w1, h, 8 + F, KIN, 0);   offs[1] = bias(w.zone_b1, h);
     offs[2] = transposed(w.zone_w2, h, h, HP, 0);        offs[3] = bias(w.zone_b2, h);
     offs[4] = transposed(w.zone_w3, h, h, HP, 0);        offs[5] = bias(w.zone_b3, h);
-    offs[6] = transposed(w.comb_w, h, 8 + h, 8 + HP, 0); offs[7] = bias(w.comb_b, h);    // [obs (8), zone_emb (h)]
+    offs[6] = transposed(combf.data(), h, 8 + h, 8 + HP, 0); offs[7] = bias(bcf.data(), h);   // [obs (8), zone mean (h)]
     offs[8] = transposed(w.enc_w, h, h, HP, 0);          offs[9] = bias(w.enc_b, h);
     if (w.critic_w1) {
         offs[10] = transposed(w.critic_w1, h, h, HP, 0);
@@ -491,7 +506,7 @@ size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_
         return at;
     };
     offs[15] = pack_hidden(hidden(w.zone_w3, w.zone_b3, 0, h), nullptr, 0);
-    offs[16] = pack_hidden(hidden(w.comb_w, w.comb_b, 8, 8 + h), w.comb_w, 8 + h);
+    offs[16] = pack_hidden(hidden(combf.data(), bcf.data(), 8, 8 + h), combf.data(), 8 + h);
     offs[17] = pack_hidden(hidden(w.enc_w, w.enc_b, 0, h), nullptr, 0);
     offs[18] = pack_rows({ { w.mu_w, w.mu_b }, { w.mu_w + h, w.mu_b + 1 }, { w.std_w, w.std_b }, { w.std_w + h, w.std_b + 1 } });
     offs[19] = offs[20] = 0;

@@ -21,7 +21,7 @@
 //     k_mlp_zone1 (tile t = zone t of 32 envs), which makes S the identity.
 //     The third zone_net_ layer has no activation, so the mean commutes with it and moves into
 //     kernel 2 -- 25x fewer rows for that layer (float reassociation only).
-//   kernel 2 (k_mlp_head), one wave per 64 envs, batch = envs:  e3 = W3 mean(H2); c = Wc [e3; obs];
+//   kernel 2 (k_mlp_head), batch = envs:  c = Wc [W3 mean(H2) + b3; obs] (one folded layer);
 //     a = relu(Wa c); [mu; std] = Wh a  -- a chain of Y = A X products, each taking the previous
 //     accumulator as its B operand.
 // Biases ride in a padded k slot: a constant-1 feature is carried through every layer (slot 15 of the
@@ -703,7 +703,7 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
     const bool critic = img.wv1 != nullptr;
     float value_out = 0.f;
 
-    stage_issue(bufA, img.w3, NT * KS);
+    stage_issue(bufB, img.wc, NT * (KS + 1));
     bf16x8 xa[KS], xb[KS], xo;              // the activations ping-pong between xa and xb
     {
         // the mean is stored in bf16, 8 consecutive features = one fragment
@@ -714,14 +714,13 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         xo = h == 0 ? frag_from_floats(o[0], o[1]) : frag_from_floats(z4, z4);
     }
-    // ---- e3 = W3 mean(H2)   (zone_net_.4 after the mean; no activation)                       xa -> xb
-    stage_fence();
-    stage_issue(bufB, img.wc, NT * (KS + 1));
-    head_layer<KS, false>(bufA, lane, xa, xo, xb);
-    // ---- c = Wc [e3; obs]   (combine_net_; no activation)                                      xb -> xa
+    // ---- c = Wc [W3 mean(H2) + b3; obs]: zone_net_.4 (after the mean) and combine_net_ have no activation between
+    // them, so the host folds them into ONE layer (pack_images: Wc' = Wc_emb W3 in float64)              xa -> xb
     stage_fence();
     stage_issue(bufA, critic ? img.wv1 : img.wa, NT * KS);
-    head_layer<KS + 1, false>(bufB, lane, xb, xo, xa);
+    head_layer<KS + 1, false>(bufB, lane, xa, xo, xb);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) xa[kk] = xb[kk];          // (register renaming: the layers below read c from xa)
     // ---- value = Wv2 relu(Wv1 c)   (critic, flat_model.py:43-47), from the same embedding c     xa -> xb
     if (critic) {
         stage_fence();
@@ -838,11 +837,21 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
     }, k_natural);
     offs[1] = out.size() * 2;
     pack_image(out, kMlpNT, kMlpKS, hidden(w.zone_w2, w.zone_b2), k_from_acc);
-    offs[2] = out.size() * 2;
-    pack_image(out, kMlpNT, kMlpKS, hidden(w.zone_w3, w.zone_b3), k_natural);
-    // combine_net_: torch input order [obs (8), zone_emb (h)]; here k-steps 0..KS-1 = zone_emb in accumulator
-    // order (+ the constant), k-step KS = obs in natural order
-    offs[3] = out.size() * 2;
+    // zone_net_.4 (applied to the zone mean: no activation) folded into combine_net_ (no activation either):
+    //   c = Wc [obs; W3 m + b3] + bc = Wc_obs obs + (Wc_emb W3) m + (Wc_emb b3 + bc),
+    // products in float64, rounded to bf16 once -- one layer and one bf16 rounding of the activations fewer.
+    // torch input order of combine_net_: [obs (8), zone_emb (h)]; here k-steps 0..KS-1 = the mean as it is read from
+    // memory (natural order, + the constant), k-step KS = obs in natural order.
+    std::vector<double> wf((size_t)h * (h + 1));
+    for (int i = 0; i < h; ++i) {
+        const float *ce = w.comb_w + (size_t)i * (8 + h) + 8;
+        for (int j = 0; j <= h; ++j) {
+            double a = j == h ? (double)w.comb_b[i] : 0.0;
+            for (int k = 0; k < h; ++k) a += (double)ce[k] * (j == h ? (double)w.zone_b3[k] : (double)w.zone_w3[(size_t)k * h + j]);
+            wf[(size_t)i * (h + 1) + j] = a;
+        }
+    }
+    offs[2] = offs[3] = out.size() * 2;
     pack_image(out, kMlpNT, kMlpKS + 1, [&](int row, int kk, int k) -> float {
         if (kk == kMlpKS) {
             const int ko = k - 16 * kMlpKS;
@@ -850,8 +859,8 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
         }
         if (row == h) return k == h ? 1.f : 0.f;
         if (row > h || k > h) return 0.f;
-        return k == h ? w.comb_b[row] : w.comb_w[(size_t)row * (8 + h) + 8 + k];
-    }, [](int kk, int hh, int j) { return kk == kMlpKS ? k_natural(kk, hh, j) : k_from_acc(kk, hh, j); });
+        return (float)wf[(size_t)row * (h + 1) + k];
+    }, k_natural);
     offs[4] = out.size() * 2;
     pack_image(out, kMlpNT, kMlpKS, hidden(w.enc_w, w.enc_b), k_from_acc);
     offs[5] = out.size() * 2;

@@ -75,8 +75,13 @@ def _bf(x):
 def forward_bf16_emulated(t, obs, zone_obs):
     """What the MFMA kernels compute, restated in torch: weights, biases and layer inputs rounded to
     bf16, products accumulated in float32 (float64 here; the difference is accumulation order only),
-    the zone mean taken after the second ReLU (zone_net_.4 is linear, so it commutes with the mean)."""
+    the zone mean taken after the second ReLU (zone_net_.4 is linear, so it commutes with the mean -- and folds into
+    combine_net_, which follows it without an activation)."""
+    raw = {k: torch.as_tensor(v, dtype=torch.float32).double() for k, v in t.items()}
     t = {k: _bf(torch.as_tensor(v, dtype=torch.float32)).double() for k, v in t.items()}
+    # zone_net_.4 folded into combine_net_ on the host (float64 products, ONE bf16 rounding): pack_images, mlp_policy.hip
+    w_fold = _bf((raw["comb_w"][:, 8:] @ raw["zone_w3"]).float()).double()
+    b_fold = _bf((raw["comb_w"][:, 8:] @ raw["zone_b3"] + raw["comb_b"]).float()).double()
     obs = _bf(torch.as_tensor(obs, dtype=torch.float32)).double()
     zo = _bf(torch.as_tensor(zone_obs, dtype=torch.float32)).double()
     bs, n_zones = zo.shape[0], zo.shape[1]
@@ -84,8 +89,7 @@ def forward_bf16_emulated(t, obs, zone_obs):
     x = _bf(torch.relu(x @ t["zone_w1"].T + t["zone_b1"]).float()).double()
     x = _bf(torch.relu(x @ t["zone_w2"].T + t["zone_b2"]).float())           # bf16 operand of the pooling product
     pooled = (x.sum(dim=1) * np.float32(1.0 / n_zones)).float()              # float32 sum, then * (1/Z)
-    e3 = _bf((_bf(pooled).double() @ t["zone_w3"].T + t["zone_b3"]).float()).double()
-    c = _bf((torch.cat([obs, e3], dim=-1) @ t["comb_w"].T + t["comb_b"]).float()).double()
+    c = _bf((_bf(pooled).double() @ w_fold.T + obs @ t["comb_w"][:, :8].T + b_fold).float()).double()
     a = _bf(torch.relu(c @ t["enc_w"].T + t["enc_b"]).float()).double()
     mu = 2 * (torch.sigmoid((a @ t["mu_w"].T + t["mu_b"]).float()) - 0.5)
     std = torch.sigmoid((a @ t["std_w"].T + t["std_b"]).float()) + 1e-3
