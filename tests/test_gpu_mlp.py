@@ -395,3 +395,20 @@ def test_evaluate_with_a_checkpoint(zenv_mod):
     assert np.array(host["return"]).shape == (6, 3)
     # the device's float32 mode is within 1e-5 of these torch actions: over 120 steps the visits agree
     assert (np.array(host["return"]) == ret).mean() >= 0.8
+
+
+def test_float32_mfma_kernel_with_two_groups_per_wave(zenv_mod):
+    """N > 32 768: a wave of k_mlp_zone_f32m owns two groups of 32 envs (the layout of the full 65 536-env batch), the
+    last workgroup ragged -- every env against the torch float32 restatement."""
+    from oracle import policy_ref as P
+    Z = zenv_mod
+    n = 32768 + 200 + 17
+    env = _env_with_obs(Z, "ColourMatch-v0", n, 30)
+    t = P.random_tensors(env.zone_feat, h=185, seed=11, distributional=True)
+    env.load_mlp(t, precision="f32")
+    out = env.mlp_forward(with_value=True)
+    obs, zo = env.observations()
+    ref = P.forward_fp32(t, obs, zo)
+    for name, a, b in zip(("mu", "std", "value", "sigma"), out, ref):
+        assert a.shape == b.shape and np.isfinite(a).all() and np.abs(a - b).max() <= 1e-5, (name, float(np.abs(a - b).max()))
+    env.close()
