@@ -64,3 +64,66 @@ def test_random_configuration_all_modes(zenv_mod, oracle_mod, case):
                         (Z.F_LAST_RETURN, "last_return"), (Z.F_LAST_LEN, "last_len")):
             assert np.array_equal(env.get(f), ref[name]), (name,) + what
         env.close()
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_lockstep_with_adversarial_actions_and_reset_patterns(zenv_mod, oracle_mod, case):
+    """External actions, one launch per step, compared after EVERY step: greedy actions mixed with out-of-range values,
+    exact +-1 / 0, +-inf (clipped by Engine.step) and the occasional NaN (Engine.step's exception branch); auto-reset
+    switched on and off from step to step (ParallelEnv.step / step_no_reset: finished envs become masked no-ops) and
+    masked resets of random subsets in between (zenv_reset with a mask)."""
+    from tests.helpers import OracleBatch
+    Z, O = zenv_mod, oracle_mod
+    rs = np.random.RandomState(500 + case)
+    task = case % 3
+    zones = [15, 25, 6, 5, 10, 9, 1, 20][case]
+    if task == 2:
+        zones = min(zones, 12)
+    cfg = Z.default_config(task, zones, zones_keepout=0.3 if zones > 15 else 0.5, num_steps=int(rs.choice([60, 120, 200])),
+                           max_cd=int(rs.choice([150, 5])))
+    n = int(rs.choice([37, 64, 101]))
+    env = Z.ZoneVecEnv(cfg, n)
+    env.build_bank(300, n)
+    env.schedule_sequential()
+    env.reset()
+    ob = OracleBatch(O, oracle_config_from(O, cfg), range(300, 300 + n))
+    o_ref, zo_ref = ob.reset()
+    n_exc = n_masked = 0
+    for t in range(260):
+        a = ob.policy(O.POLICY_GREEDY, o_ref, zo_ref, t)
+        kind = rs.rand(n)
+        wild = rs.uniform(-3, 3, (n, 2)).astype(np.float32)
+        exact = rs.choice(np.array([-1.0, 0.0, 1.0], np.float32), (n, 2))
+        a[kind < 0.15] = wild[kind < 0.15]
+        a[(kind >= 0.15) & (kind < 0.25)] = exact[(kind >= 0.15) & (kind < 0.25)]
+        a[(kind >= 0.25) & (kind < 0.27), 0] = np.inf
+        a[(kind >= 0.27) & (kind < 0.29), 1] = -np.inf
+        nan = kind > 0.997
+        a[nan, int(rs.randint(0, 2))] = np.nan
+        auto = bool(rs.rand() < 0.75)
+        live = np.array([not e.e.done for e in ob.envs])
+        n_exc += int((nan & live).sum())
+        n_masked += int((~live).sum())
+        got = env.step_results(a, auto_reset=auto)
+        r_ref, d_ref, g_ref = ob.step(a, auto_reset=auto)
+        o_ref, zo_ref = ob.obs()
+        o_ref[~live] = 0                       # an env that was already finished: WaitWrapper's noop_obs (zeros), reward 0
+        zo_ref[~live] = 0
+        assert np.array_equal(got[3], d_ref) and np.array_equal(got[4], g_ref), (case, t)
+        assert np.array_equal(got[2], r_ref.astype(np.float32)), (case, t)
+        assert np.array_equal(got[0], o_ref) and np.array_equal(got[1], zo_ref), (case, t)
+        assert np.isfinite(got[0]).all() and np.isfinite(got[1]).all() and np.isfinite(got[2]).all()
+        if t % 37 == 36:                       # masked reset of a random subset, finished or not
+            m = rs.rand(n) < 0.2
+            env.reset(mask=m)
+            for i in np.flatnonzero(m):
+                ob.envs[i].reset(ob.seeds[i])
+            o_new, zo_new = ob.obs()
+            o_ref[m], zo_ref[m] = o_new[m], zo_new[m]          # the other envs' buffers stay as the last step left them
+            first = env.step_results(None)
+            assert np.array_equal(first[0], o_ref) and np.array_equal(first[1], zo_ref), (case, t, "after masked reset")
+    q, v, steps = ob.state()
+    dbg = env.debug_state()
+    assert np.array_equal(dbg["qpos"], q) and np.array_equal(dbg["qvel"], v) and np.array_equal(dbg["steps"], steps)
+    assert n_masked > 0                         # frozen envs were stepped over
+    env.close()
