@@ -1,8 +1,11 @@
 /* A reference-side binding in plain C: include/zenv.h is all a caller needs (no Python, no torch, no HIP headers).
  *   gcc -std=c99 -Iinclude examples/c_abi_demo.c -o demo -L combinatorial-rl-tasks_amd/lib -lzenv_hip \
  *       -Wl,-rpath,$PWD/combinatorial-rl-tasks_amd/lib
- * Steps 256 PointTSP-v0 envs with zero actions for 40 steps (host actions, auto-reset), then 100 steps with the
- * on-device greedy policy in one persistent launch, and prints sums the test compares with the Python path. */
+ * Steps 256 PointTSP-v0 envs with host actions for 40 steps (auto-reset; each step ONE call: action upload, step
+ * kernel, one download of every result into page-locked memory, one synchronisation -- zenv_step_results), then 100
+ * steps with the on-device greedy policy in one persistent launch, and prints sums the test compares with the Python
+ * path. */
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -34,9 +37,19 @@ int main(void)
     float *obs = (float *)malloc(sizeof(float) * 8 * N);
     float *zone_obs = (float *)malloc(sizeof(float) * Z * F * N);
     float *reward = (float *)malloc(sizeof(float) * N);
+    /* what one `worker` of the reference sends back per step (penv.py:8-12), for all N envs in one slab */
+    int64_t off[ZENV_N_RESULTS];
+    const int64_t slab_bytes = zenv_results_layout(h, off);
+    char *slab = (char *)zenv_host_alloc(slab_bytes);
+    if (!slab) return 3;
+    double host_return = 0.0;
+    int host_dones = 0;
     for (int t = 0; t < 40; ++t) {
         for (int i = 0; i < N; ++i) { actions[2 * i] = 1.0f; actions[2 * i + 1] = (i % 3 - 1) * 0.5f; }
-        CHECK(zenv_step(h, actions, 0, 1));
+        CHECK(zenv_step_results(h, actions, 1, slab));
+        const float *r = (const float *)(slab + off[ZENV_RESULT_REWARD]);
+        const uint8_t *d = (const uint8_t *)(slab + off[ZENV_RESULT_DONE]);
+        for (int i = 0; i < N; ++i) { host_return += r[i]; host_dones += d[i]; }
     }
     float ms = 0.f;
     CHECK(zenv_rollout(h, 100, ZENV_POLICY_GREEDY, 7, 0, 1, 0, 1, &ms, NULL));
@@ -47,7 +60,14 @@ int main(void)
     for (int i = 0; i < 8 * N; ++i) so += obs[i];
     for (int i = 0; i < Z * F * N; ++i) sz += zone_obs[i];
     for (int i = 0; i < N; ++i) sr += reward[i];
-    printf("steps %lld obs_sum %.9f zone_obs_sum %.9f reward_sum %.3f\n", (long long)zenv_step_count(h), so, sz, sr);
+    /* the slab downloaded without stepping holds the same bytes as the field-by-field downloads */
+    CHECK(zenv_step_results(h, NULL, 1, slab));
+    const int slab_ok = memcmp(slab + off[ZENV_RESULT_OBS], obs, sizeof(float) * 8 * N) == 0 &&
+                        memcmp(slab + off[ZENV_RESULT_ZONE_OBS], zone_obs, sizeof(float) * Z * F * N) == 0 &&
+                        memcmp(slab + off[ZENV_RESULT_REWARD], reward, sizeof(float) * N) == 0;
+    printf("steps %lld obs_sum %.9f zone_obs_sum %.9f reward_sum %.3f host_return %.3f host_dones %d slab_ok %d\n",
+           (long long)zenv_step_count(h), so, sz, sr, host_return, host_dones, slab_ok);
+    CHECK(zenv_host_free(slab));
     CHECK(zenv_destroy(h));
     free(actions); free(obs); free(zone_obs); free(reward);
     return 0;

@@ -197,14 +197,18 @@ def test_c_abi_demo_matches_python_path(zenv_mod, tmp_path):
     a = np.zeros((n, 2), np.float32)
     a[:, 0] = 1.0
     a[:, 1] = (np.arange(n) % 3 - 1) * 0.5
+    host_return, host_dones = 0.0, 0
     for _ in range(40):
         env.step(a, auto_reset=True)
+        host_return += float(env.get(Z.F_REWARD).astype(np.float64).sum())
+        host_dones += int(env.get(Z.F_DONE).sum())
     env.rollout(100, Z.POLICY_GREEDY, policy_seed=7)
     o, zo, r, _, _ = env.results()
     assert got["steps"] == 140
     assert abs(got["obs_sum"] - float(o.astype(np.float64).sum())) < 1e-6
     assert abs(got["zone_obs_sum"] - float(zo.astype(np.float64).sum())) < 1e-6
     assert abs(got["reward_sum"] - float(r.astype(np.float64).sum())) < 1e-6
+    assert abs(got["host_return"] - host_return) < 1e-3 and got["host_dones"] == host_dones and got["slab_ok"] == 1
     env.close()
 
 
@@ -247,3 +251,31 @@ def test_plain_seeded_parallel_env_stops_at_the_end_of_its_bank(zenv_mod):
     with pytest.raises(RuntimeError, match="pre-sampled episodes"):
         penv.step(a)
     penv.close()
+
+
+def test_integration_md_ctypes_stub_runs(zenv_mod):
+    """The reference-side binding INTEGRATION.md shows (section 2) is executed as written -- only the library name is
+    replaced by the in-tree path -- and its arrays are checked against the facade on the same calls."""
+    import os
+    import re
+    Z = zenv_mod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes as C, numpy as np.*?)```", text, re.S).group(1)
+    lib_path = os.path.join(root, "combinatorial-rl-tasks_amd", "lib", "libzenv_hip.so")
+    assert 'C.CDLL("libzenv_hip.so")' in code
+    ns = {}
+    exec(compile(code.replace('C.CDLL("libzenv_hip.so")', f'C.CDLL({lib_path!r})'), "INTEGRATION.md", "exec"), ns)
+    n = ns["N"]
+    env = Z.ZoneVecEnv(Z.config_for_id("PointTSP-v0"), n)
+    env.build_bank(1, 100, n_threads=8)
+    env.schedule_fixed_seeds(np.arange(n, dtype=np.uint64) * 10000, 1, 100)
+    env.reset()
+    a = np.zeros((n, 2), np.float32)
+    a[:, 0] = 1.0
+    for _ in range(100):
+        env.step(a, auto_reset=True)
+    o, zo, r, d, _ = env.results()
+    assert np.array_equal(ns["obs"], o) and np.array_equal(ns["zone_obs"], zo)
+    assert np.array_equal(ns["reward"], r) and np.array_equal(ns["done"].astype(bool), d)
+    env.close()

@@ -259,3 +259,18 @@ def test_load_model_state_reads_a_reference_model_dir(tmp_path):
     torch.save({"num_frames": 0}, tmp_path / "status.pt")
     with pytest.raises(KeyError):
         load_model_state(str(tmp_path))
+
+
+def test_integration_md_stub_struct_matches_the_header(zenv_mod):
+    """The ZenvConfig mirror printed in INTEGRATION.md section 2 has the size and field offsets of struct zenv_config
+    (the part of the stub that needs no GPU; tests/test_gpu_edges.py runs the whole stub on the device)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes as C, numpy as np.*?)\ndef check\(rc\):", text, re.S).group(1)
+    lib_path = os.path.join(ROOT, "combinatorial-rl-tasks_amd", "lib", "libzenv_hip.so")
+    ns = {}
+    exec(compile(code.replace('C.CDLL("libzenv_hip.so")', f'C.CDLL({lib_path!r})'), "INTEGRATION.md", "exec"), ns)
+    stub, mine = ns["ZenvConfig"], zenv_mod._native.Config
+    assert C.sizeof(stub) == C.sizeof(mine)
+    offs = {n: getattr(mine, n).offset for n, _ in mine._fields_}
+    for name, _ in stub._fields_:
+        assert getattr(stub, name).offset == offs[name], name
