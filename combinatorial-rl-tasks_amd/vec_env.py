@@ -460,12 +460,20 @@ class ZoneVecEnv:
         per-step result, one synchronisation.  actions None: just the download (after reset()).  Returns
         (obs, zone_obs, reward, done, goal_met, exception); with copy=False the arrays are views of one page-locked
         buffer that the next call overwrites."""
-        slab = self._results_slab()
         a = None
         if actions is not None:
             a = np.ascontiguousarray(actions, np.float32)
             if a.shape != (self.num_envs, 2):
                 raise ValueError(f"actions must have shape ({self.num_envs}, 2)")
+        if copy and self.num_envs * self.num_zones * self.zone_feat * 4 > (8 << 20):
+            # a big batch whose caller wants its own arrays: download each field straight into them (a second pass
+            # over tens of MB through the page-locked image would cost more than the extra synchronisations)
+            if a is not None:
+                self.step(a, auto_reset=auto_reset)
+            return (self.get(nat.F_OBS), self.get(nat.F_ZONE_OBS), self.get(nat.F_REWARD),
+                    self.get(nat.F_DONE).view(bool), self.get(nat.F_GOAL_MET).view(bool),
+                    self.get(nat.F_EXCEPTION).view(bool))
+        slab = self._results_slab()
         check(lib().zenv_step_results(self._h, None if a is None else a.ctypes.data, int(bool(auto_reset)),
                                       slab.ctypes.data))
         return tuple(v.copy() for v in self._slab_views) if copy else self._slab_views
