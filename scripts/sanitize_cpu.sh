@@ -1,0 +1,35 @@
+#!/bin/bash
+# CPU only, two passes in a scratch copy of the tree:
+#  1. the oracle (gcc) rebuilt with AddressSanitizer + UndefinedBehaviorSanitizer, then every CPU test that drives it
+#     (single envs, the OpenMP batch driver, the gloo shards);
+#  2. the product library rebuilt with the HOST side sanitized (hipcc -fsanitize=address,undefined -fno-gpu-sanitize):
+#     layout sampler, seed streams, route heuristic, config validation, packing of the network images -- everything
+#     the C ABI does without a GPU -- through tests/test_host_abi.py and the CPU half of the hard-env tests.  GPU sanitizers are not
+# available on this pool; the kernels mirror the oracle's arithmetic token for token, so an out-of-range shift or a
+# signed overflow there would show here.   usage: scripts/sanitize_cpu.sh
+set -e
+root=$(cd "$(dirname "$0")/.." && pwd)
+tmp=$(mktemp -d /tmp/zenv_san.XXXX)
+(cd "$root" && git archive HEAD) | tar -x -C "$tmp"
+mkdir -p "$tmp/combinatorial-rl-tasks_amd/lib"
+cp "$root/combinatorial-rl-tasks_amd/lib/libzenv_hip.so" "$tmp/combinatorial-rl-tasks_amd/lib/"
+sed -i 's/cmd = \["gcc", "-O2",/cmd = ["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined",/' "$tmp/oracle/oracle.py"
+cd "$tmp"
+LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" \
+ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 \
+python -m pytest tests/test_oracle_cpu.py tests/test_dynamics_independent.py tests/test_hard_env_and_exception.py \
+    tests/test_sharding_gloo.py -x -q -m "not gpu" -p no:cacheprovider
+nm -D oracle/build/libzenv_oracle.so | grep -q __asan && echo "oracle was built with the sanitizers: clean"
+# ---- pass 2: host side of the product library
+git -C "$root" show HEAD:oracle/oracle.py > oracle/oracle.py && rm -rf oracle/build
+csrc=combinatorial-rl-tasks_amd/csrc
+hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -Wno-pass-failed \
+    -mllvm -amdgpu-mfma-vgpr-form -fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan \
+    -o combinatorial-rl-tasks_amd/lib/libzenv_hip.so $csrc/kernels.hip $csrc/mlp_policy.hip $csrc/mlp_f32.hip \
+    $csrc/zenv_api.cpp $csrc/host_sampler.cpp 2> /dev/null
+rt=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+LD_PRELOAD="$rt" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+python -m pytest tests/test_host_abi.py tests/test_hard_env_and_exception.py tests/test_oracle_cpu.py -x -q -m "not gpu" \
+    -p no:cacheprovider
+nm -D combinatorial-rl-tasks_amd/lib/libzenv_hip.so | grep -q __asan && echo "product host code was built with the sanitizers: clean"
+rm -rf "$tmp"
