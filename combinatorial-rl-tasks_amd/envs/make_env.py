@@ -1,4 +1,9 @@
-"""main/envs/make_env.py: make_train_env / make_test_env / make_fixed_env (same signatures)."""
+"""main/envs/make_env.py: make_train_env / make_test_env / make_fixed_env (same signatures).
+
+The reference keeps one id list per factory and per tree (main/envs/make_env.py:14, :32, :49; zone-goals/envs/make_env.py):
+e.g. main's make_train_env does not list PointTSP-v4 / -v5.  Here every factory accepts every id of the merged
+registry -- a superset: whatever the reference constructs is constructed the same way, unknown ids raise the same
+RuntimeError("Unknown environment"), Car / Doggo ids raise NotImplementedError (other robots: out of scope)."""
 from .registry import OUT_OF_SCOPE, REGISTRY, make
 from .wrappers import FixedSeedsWrapper, WaitWrapper, ZoneWrapper
 
