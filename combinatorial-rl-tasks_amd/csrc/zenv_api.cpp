@@ -394,6 +394,15 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
     int rc = validate_config(*cfg);
     if (rc) return rc;
     if (n_env < 1) return fail(ZENV_E_ARG, "n_env must be >= 1");
+    {
+        // the kernels index a handle's arrays with 32-bit element offsets: the largest one, zone_obs [N][Z][F], stays
+        // below 2^29 floats (2 GiB).  That is 3.5 M envs at Z = 25 (tested at 1 M); a bigger batch takes several handles.
+        const int64_t zone_floats = (int64_t)n_env * cfg->num_zones * (cfg->task == ZENV_TASK_TSP ? 6 : 7);
+        if (zone_floats > ((int64_t)1 << 29))
+            return fail(ZENV_E_ARG, "n_env %d x %d zones is beyond one handle's 32-bit indexing (zone_obs would hold %lld "
+                        "floats, the limit is 2^29): split the batch over several handles", n_env, cfg->num_zones,
+                        (long long)zone_floats);
+    }
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev < 1)

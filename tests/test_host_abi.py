@@ -274,3 +274,16 @@ def test_integration_md_stub_struct_matches_the_header(zenv_mod):
     offs = {n: getattr(mine, n).offset for n, _ in mine._fields_}
     for name, _ in stub._fields_:
         assert getattr(stub, name).offset == offs[name], name
+
+
+def test_batch_size_beyond_32_bit_indexing_is_refused(zenv_mod):
+    """zenv_create names the limit of one handle (zone_obs below 2^29 floats) before it looks for a device."""
+    Z = zenv_mod
+    cfg = Z.default_config(0, 25, zones_keepout=0.4)
+    h = C.c_void_p()
+    rc = Z._native.lib().zenv_create(C.byref(cfg), 3_600_000, 0, C.byref(h))
+    assert rc == Z._native.E_ARG and b"32-bit indexing" in Z._native.lib().zenv_last_error()
+    rc = Z._native.lib().zenv_create(C.byref(cfg), 3_500_000, 0, C.byref(h))     # within the limit: only the GPU is missing here
+    assert rc != Z._native.E_ARG or b"32-bit indexing" not in Z._native.lib().zenv_last_error()
+    if rc == 0:
+        Z._native.lib().zenv_destroy(h)
