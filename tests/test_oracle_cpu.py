@@ -496,3 +496,22 @@ def test_solver_ordered_semantics_and_route_heuristic(oracle_mod, zenv_mod):
             j = min(left, key=lambda z: np.hypot(*(zxy[z] - cur)))
             nn.append(j); left.remove(j); cur = zxy[j]
         assert tour_len(order) <= tour_len(np.array(nn)) + 1e-9
+
+
+def test_oracle_regression_vectors(oracle_mod):
+    """The oracle against its own frozen trajectories (tests/golden/oracle_regression.npz: NOT reference output, a pin
+    against silent drift of the checker -- see make_oracle_regression.py)."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_oracle_regression", os.path.join(here, "golden", "make_oracle_regression.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    gold = np.load(os.path.join(here, "golden", "oracle_regression.npz"))
+    now = m.trajectories()
+    assert sorted(now) == sorted(k for k in gold.files if k != "seeds")
+    for k, v in now.items():
+        assert v.dtype == gold[k].dtype and np.array_equal(v, gold[k]), k
+    # the frozen runs contain visits, a TimedTSP episode end and colour changes
+    assert (gold["tsp_greedy_reward"] > 0).sum() > 5 and gold["timed_greedy_flags"].any()
+    assert (gold["colour_greedy_reward"] != 0).any()
