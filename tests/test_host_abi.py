@@ -287,3 +287,24 @@ def test_batch_size_beyond_32_bit_indexing_is_refused(zenv_mod):
     assert rc != Z._native.E_ARG or b"32-bit indexing" not in Z._native.lib().zenv_last_error()
     if rc == 0:
         Z._native.lib().zenv_destroy(h)
+
+
+def test_fixed_seed_stream_property(zenv_mod):
+    """FixedSeedsWrapper's draw (wrappers.py:18-21) for arbitrary rng seeds and ranges, against numpy's Generator: the
+    SeedSequence -> PCG64 initialisation, the buffered 32-bit halves and Lemire's rejection (ranges of one value, powers
+    of two, just below 2^32), negative lower bounds included."""
+    from hypothesis import given, settings, strategies as st
+    Zm = zenv_mod
+
+    @settings(max_examples=150, deadline=None)
+    @given(rng_seed=st.integers(0, 2 ** 64 - 1), lo=st.integers(-2 ** 40, 2 ** 40),
+           span=st.one_of(st.integers(0, 2000), st.sampled_from([2 ** 16 - 1, 2 ** 16, 2 ** 31, 2 ** 32 - 3, 2 ** 32 - 2])),
+           count=st.integers(1, 24))
+    def check_one(rng_seed, lo, span, count):
+        g = np.random.default_rng(rng_seed)
+        want = [int(g.integers(low=lo, high=lo + span + 1, size=1)[0]) for _ in range(count)]
+        assert Zm.fixed_seed_sequence(rng_seed, lo, lo + span, count).tolist() == want
+
+    check_one()
+    with pytest.raises(Zm.ZenvError):
+        Zm.fixed_seed_sequence(1, 0, 2 ** 32, 1)          # wider than one 32-bit draw: refused, not approximated
