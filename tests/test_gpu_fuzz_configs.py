@@ -2,12 +2,15 @@
 other test names -- zone counts 1..30 (compiled-in and runtime-Z kernels), short and long episodes, cooldowns, zone radii,
 reward constants, frameskips other than 10 (the looped substep path), robot constants within validate_config's bounds,
 both scripted policies.  Bit-exact, as everywhere (obs, zone_obs, episode counters, returns, lengths)."""
+import os
+
 import numpy as np
 import pytest
 
 from tests.helpers import oracle_config_from
 
 pytestmark = pytest.mark.gpu
+N_CASES = int(os.environ.get("ZENV_FUZZ_CASES", "24"))        # a longer hunt: ZENV_FUZZ_CASES=400 pytest ... -k random
 
 
 def _draw(rs, Z, case):
@@ -36,7 +39,7 @@ def _draw(rs, Z, case):
     return cfg
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(N_CASES))
 def test_random_configuration_all_modes(zenv_mod, oracle_mod, case):
     Z, O = zenv_mod, oracle_mod
     rs = np.random.RandomState(9000 + case)
