@@ -21,6 +21,7 @@ HIP_STREAM_LEGACY = 1       # hipStreamLegacy: the null stream as an explicit ha
 ROLLOUT_UNFUSED = 1
 ROLLOUT_PER_STEP = 2
 ROLLOUT_CHUNK = 256
+COMM_ID_BYTES = 128
 
 E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE = -1, -2, -3, -4, -5
 
@@ -79,6 +80,9 @@ _H = C.c_void_p
 _PROTOTYPES = {
     "zenv_last_error": (C.c_char_p, []),
     "zenv_version": (C.c_char_p, []),
+    "zenv_device_count": (C.c_int, []),
+    "zenv_build_flags": (C.c_char_p, []),
+    "zenv_rollout_chunk": (C.c_int, []),
     "zenv_config_for_id": (C.c_int, [C.c_char_p, C.POINTER(Config)]),
     "zenv_default_config": (C.c_int, [C.c_int, C.c_int, C.POINTER(Config)]),
     "zenv_zone_feat": (C.c_int, [C.POINTER(Config)]),
@@ -110,6 +114,7 @@ _PROTOTYPES = {
     "zenv_mlp_load": (C.c_int, [_H, C.c_void_p]),
     "zenv_mlp_forward": (C.c_int, [_H]),
     "zenv_get": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int]),
+    "zenv_get_rows": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "zenv_device_ptr": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),
     "zenv_field_bytes": (C.c_int64, [_H, C.c_int]),
     "zenv_sync": (C.c_int, [_H]),
@@ -119,6 +124,15 @@ _PROTOTYPES = {
     "zenv_results_layout": (C.c_int64, [_H, C.POINTER(C.c_int64)]),
     "zenv_step_results": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p]),
     "zenv_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "zenv_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "zenv_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "zenv_comm_destroy": (C.c_int, [_H]),
+    "zenv_comm_info": (C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
+    "zenv_allgather": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int]),
+    "zenv_comm_barrier": (C.c_int, [_H]),
+    "zenv_comm_allreduce_max": (C.c_int, [_H, C.POINTER(C.c_double)]),
+    "zenv_probe_store_stream": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_float)]),
     "zenv_step_count": (C.c_int64, [_H]),
     "zenv_state_bytes": (C.c_int64, [_H]),
     "zenv_get_state": (C.c_int, [_H, C.c_void_p, C.c_int64]),

@@ -29,8 +29,28 @@ def _deps():
     return out
 
 
+FLAGS_STAMP = os.path.join(LIB_DIR, ".build_flags")
+
+
+def extra_flags():
+    """ZENV_EXTRA_FLAGS: diagnostic variants only (e.g. -DZENV_STORE_AUX=16, -DZENV_EXP=1).  The string is compiled into
+    the library (zenv_build_flags()) and stamped beside it, so a variant never passes for the shipped build."""
+    return " ".join(os.environ.get("ZENV_EXTRA_FLAGS", "").split())
+
+
+def _stamped_flags():
+    try:
+        with open(FLAGS_STAMP) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
 def _up_to_date():
-    return os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in _deps())
+    """Newer than every source AND compiled with the flag set asked for now (a diagnostic .so left behind by an
+    experiment is rebuilt by the next plain build, and the other way round)."""
+    return (os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in _deps())
+            and _stamped_flags() == extra_flags())
 
 
 def under_profiler():
@@ -60,14 +80,17 @@ def build_library(force=False, verbose=False):
         try:
             if not force and _up_to_date():          # another rank built it while we waited
                 return LIB_PATH
-            extra = os.environ.get("ZENV_EXTRA_FLAGS", "").split()   # experiments only (e.g. -DZENV_STORE_AUX=16)
+            extra = extra_flags()
             tmp = LIB_PATH + f".tmp{os.getpid()}"
-            cmd = [_hipcc()] + FLAGS + extra + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            cmd = [_hipcc()] + FLAGS + extra.split() + ['-DZENV_BUILD_FLAGS="%s"' % extra.replace('"', "'"),
+                                                        "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
             if verbose:
                 print(" ".join(cmd))
             try:
                 subprocess.run(cmd, check=True)
                 os.replace(tmp, LIB_PATH)
+                with open(FLAGS_STAMP, "w") as f:
+                    f.write(extra)
             finally:
                 if os.path.exists(tmp):
                     os.remove(tmp)

@@ -2360,7 +2360,58 @@ __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t
     p.goal_met[env] = 0;
 }
 
+// =========================================================================== gather prep
+// The send buffer of the job's one collective (zenv_allgather): field [N] -> 4-byte elements, float64 narrowed to
+// float32 ("ncclAllGather of float ep_return[N/G]").
+__global__ __launch_bounds__(256) void k_gather_prep(const void *__restrict__ src, int elem_bytes, uint32_t *__restrict__ dst, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (elem_bytes == 8) dst[i] = __float_as_uint((float)static_cast<const double *>(src)[i]);
+    else dst[i] = static_cast<const uint32_t *>(src)[i];
+}
+
+// =========================================================================== probe: the bare row stream
+// Measurement utility (zenv_probe_store_stream, bench.py's `store_stream_ceiling`): the tile flush of K1 / K1p with
+// everything else taken away -- one wave per tile rewrites its tile's contiguous `tile_bytes` with 1 KiB
+// buffer_store_dwordx4 bursts, `steps` times over, under the cache policy AUX (0 plain, 2 nt, 16 sc1 = write-through).
+// What this reaches at a given footprint is the ceiling of a write-only stream of that shape on this box: the number
+// the step kernels' row stores are held against (the float4-COPY figure of MI355X_MICROARCH.md reads AND writes, so
+// it is not a ceiling for a stream that only writes).
+template <int AUX>
+__global__ __launch_bounds__(kWave) void k_probe_store(float *out, int tile_bytes, int steps)
+{
+    const int lane = threadIdx.x;
+    float *dst = out + (size_t)blockIdx.x * (size_t)(tile_bytes / 4);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, tile_bytes, 0x00020000);
+    v4f_t val = { (float)lane, 1.f, 2.f, 3.f };
+    for (int t = 0; t < steps; ++t) {
+        val.y = (float)t;
+        for (int off = lane * 16; off + 16 <= tile_bytes; off += 1024)
+            __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, off, 0, AUX);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_gather_prep(const void *src, int elem_bytes, void *dst, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gather_prep, dim3((n + 255) / 256), dim3(256), 0, s, src, elem_bytes, static_cast<uint32_t *>(dst), n);
+    return hipGetLastError();
+}
+
+hipError_t launch_probe_store(float *out, long long n_tiles, int tile_bytes, int steps, int aux, hipStream_t s,
+                              hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    const dim3 grid((unsigned)n_tiles), block(kWave);
+    switch (aux) {
+    case 0: hipExtLaunchKernelGGL(k_probe_store<0>, grid, block, 0, s, ev_start, ev_stop, 0, out, tile_bytes, steps); break;
+    case 2: hipExtLaunchKernelGGL(k_probe_store<2>, grid, block, 0, s, ev_start, ev_stop, 0, out, tile_bytes, steps); break;
+    case 16: hipExtLaunchKernelGGL(k_probe_store<16>, grid, block, 0, s, ev_start, ev_stop, 0, out, tile_bytes, steps); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------- launchers
 static inline int n_blocks(int n) { return (n + kWave - 1) / kWave; }

@@ -2,6 +2,9 @@
 // Host-side plumbing only: device memory, the layout bank, launches, copies.  There is no
 // CPU compute path here: without a usable HIP device every compute entry point fails.
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is dlopen()ed by the first zenv_comm_* call
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -99,6 +102,11 @@ struct zenv {
     // experience buffers (zenv_collect)
     ExpBuffers exp{};
     void *exp_mem = nullptr;
+    // the sharded job's communicator (zenv_comm_init): RCCL over xGMI
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    void *comm_send = nullptr, *comm_recv = nullptr;   // [N] and [world * N] 4-byte elements
+    double *comm_scalar = nullptr;                      // device scratch of the barrier / max-reduce
 };
 
 namespace {
@@ -259,7 +267,26 @@ FieldInfo field_info(const zenv *h, int field)
 // ============================================================================ host-only API
 extern "C" const char *zenv_last_error(void) { return g_err.c_str(); }
 
-extern "C" const char *zenv_version(void) { return "zenv-hip 0.1 (gfx950)"; }
+// The -D / -m switches the library was compiled with beyond build.py's fixed set (ZENV_EXTRA_FLAGS: diagnostic
+// variants such as -DZENV_EXP=1, -DZENV_STORE_AUX=16, -DZENV_STAMPS); "" for the shipped build.  build.py passes the
+// string as -DZENV_BUILD_FLAGS, so a variant library names itself and bench.py can refuse to time it unasked.
+#ifndef ZENV_BUILD_FLAGS
+#define ZENV_BUILD_FLAGS ""
+#endif
+extern "C" const char *zenv_build_flags(void) { return ZENV_BUILD_FLAGS; }
+
+extern "C" const char *zenv_version(void)
+{
+    static const std::string v = std::string("zenv-hip 0.3 (gfx950)") +
+                                 (ZENV_BUILD_FLAGS[0] ? std::string(" [variant: ") + ZENV_BUILD_FLAGS + "]" : std::string());
+    return v.c_str();
+}
+
+extern "C" int zenv_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 extern "C" int zenv_zone_feat(const zenv_config *cfg)
 {
@@ -497,6 +524,7 @@ extern "C" int zenv_destroy(zenv_t *h)
     if (!h) return ZENV_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) (void)zenv_comm_destroy(h);
     for (Alloc &a : h->allocs)
         if (*a.slot && a.slab_off < 0) (void)hipFree(*a.slot);
     if (h->results_slab) (void)hipFree(h->results_slab);
@@ -1067,6 +1095,7 @@ static const int kRolloutChunk = [] {
     const int v = e ? std::atoi(e) : 0;
     return v >= 1 && v <= ZENV_ROLLOUT_CHUNK ? v : ZENV_ROLLOUT_CHUNK;
 }();
+extern "C" int zenv_rollout_chunk(void) { return kRolloutChunk; }
 
 // Bring the device copy of the parameter block up to date (it changes with the bank, the schedule, a redirected
 // output buffer ...: rarely, so one comparison per rollout call and a copy only when something did change).
@@ -1195,6 +1224,23 @@ extern "C" int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device)
     return ZENV_OK;
 }
 
+extern "C" int zenv_get_rows(zenv_t *h, int field, int first_env, int count, void *dst)
+{
+    if (!h || !dst) return fail(ZENV_E_ARG, "null argument");
+    const FieldInfo f = field_info(h, field);
+    if (!f.ptr) return fail(ZENV_E_ARG, "unknown field %d", field);
+    if (first_env < 0 || count < 0 || (int64_t)first_env + count > h->n_env)
+        return fail(ZENV_E_ARG, "envs [%d, %d) outside the batch of %d", first_env, first_env + count, h->n_env);
+    if (f.bytes % h->n_env) return fail(ZENV_E_ARG, "field %d is not laid out per env", field);
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int64_t per_env = f.bytes / h->n_env;
+    HIP_TRY(hipMemcpyAsync(dst, static_cast<const char *>(f.ptr) + per_env * first_env, (size_t)(per_env * count),
+                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ZENV_OK;
+}
+
 extern "C" void *zenv_host_alloc(int64_t bytes)
 {
     void *p = nullptr;
@@ -1254,6 +1300,202 @@ extern "C" int zenv_device_ptr(zenv_t *h, int field, void **ptr)
     const FieldInfo f = field_info(h, field);
     if (!f.ptr) return fail(ZENV_E_ARG, "unknown field %d", field);
     *ptr = f.ptr;
+    return ZENV_OK;
+}
+
+// ============================================================================ multi-GPU: the one collective, native RCCL
+// Envs shard trivially over GPUs (one process per GPU, no exchange on the step path); a job's only collective is the
+// all-gather of per-env episodic figures after a rollout.  This replaces the reference's Pipe star
+// (main/src/torch_ac/torch_utils/penv.py:26-40) at N > 1.  librccl is loaded on first use -- a single-GPU caller never
+// maps its half gigabyte -- preferring a copy the process already holds (a torch in the same process brings its own).
+namespace {
+
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    std::string path;
+};
+
+RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.lib ? &api : nullptr;
+    tried = true;
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    void *lib = nullptr;
+    for (const char *n : names)                       // a copy that is already mapped wins (torch's bundled one)
+        if (!lib && (lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) api.path = std::string(n) + " (already loaded)";
+    if (const char *e = std::getenv("ZENV_RCCL_PATH"))
+        if (!lib && (lib = dlopen(e, RTLD_NOW | RTLD_LOCAL))) api.path = e;
+    for (const char *n : names)
+        if (!lib && (lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) api.path = n;
+    if (!lib) return nullptr;
+#define ZENV_SYM(name) api.name = reinterpret_cast<decltype(api.name)>(dlsym(lib, "nccl" #name))
+    ZENV_SYM(GetUniqueId); ZENV_SYM(CommInitRank); ZENV_SYM(CommDestroy); ZENV_SYM(AllGather); ZENV_SYM(AllReduce);
+    ZENV_SYM(GetErrorString); ZENV_SYM(GetVersion);
+#undef ZENV_SYM
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllReduce || !api.GetErrorString)
+        return nullptr;
+    api.lib = lib;
+    return &api;
+}
+
+#define RCCL_TRY(api, expr)                                                                                   \
+    do {                                                                                                      \
+        ncclResult_t _r = (expr);                                                                             \
+        if (_r != ncclSuccess)                                                                                \
+            return fail(ZENV_E_HIP, "%s failed: %s (%s:%d)", #expr, (api)->GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+}  // namespace
+
+extern "C" int zenv_comm_unique_id(void *id_out)
+{
+    if (!id_out) return fail(ZENV_E_ARG, "null argument");
+    static_assert(sizeof(ncclUniqueId) == ZENV_COMM_ID_BYTES, "ZENV_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(ZENV_E_HIP, "librccl not found (%s)", dlerror() ? dlerror() : "no loader message");
+    ncclUniqueId id;
+    RCCL_TRY(api, api->GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof(id));
+    return ZENV_OK;
+}
+
+extern "C" int zenv_comm_init(zenv_t *h, int rank, int world, const void *unique_id)
+{
+    if (!h || !unique_id) return fail(ZENV_E_ARG, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(ZENV_E_ARG, "rank %d outside [0,%d)", rank, world);
+    if (h->comm) return fail(ZENV_E_STATE, "the handle already has a communicator");
+    RcclApi *api = rccl_api();
+    if (!api) return fail(ZENV_E_HIP, "librccl not found");
+    int rc = use_device(h);
+    if (rc) return rc;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    RCCL_TRY(api, api->CommInitRank(&h->comm, world, id, rank));
+    h->comm_rank = rank;
+    h->comm_world = world;
+    const size_t N = (size_t)h->n_env;
+    HIP_TRY(hipMalloc(&h->comm_send, N * 4));
+    HIP_TRY(hipMalloc(&h->comm_recv, N * 4 * (size_t)world));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->comm_scalar), 2 * sizeof(double)));
+    return ZENV_OK;
+}
+
+extern "C" int zenv_comm_destroy(zenv_t *h)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (!h->comm) return ZENV_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    RcclApi *api = rccl_api();
+    if (api) (void)api->CommDestroy(h->comm);
+    h->comm = nullptr;
+    h->comm_world = 0;
+    for (void **m : { &h->comm_send, &h->comm_recv, reinterpret_cast<void **>(&h->comm_scalar) }) {
+        if (*m) (void)hipFree(*m);
+        *m = nullptr;
+    }
+    return ZENV_OK;
+}
+
+extern "C" int zenv_comm_info(const zenv_t *h, int *rank, int *world, const char **library)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (rank) *rank = h->comm_rank;
+    if (world) *world = h->comm_world;
+    if (library) {
+        RcclApi *api = h->comm ? rccl_api() : nullptr;
+        *library = api ? api->path.c_str() : "";
+    }
+    return ZENV_OK;
+}
+
+extern "C" int zenv_allgather(zenv_t *h, int field, void *dst, int dst_on_device)
+{
+    if (!h || !dst) return fail(ZENV_E_ARG, "null argument");
+    if (!h->comm) return fail(ZENV_E_STATE, "zenv_comm_init first");
+    const FieldInfo f = field_info(h, field);
+    const int64_t N = h->n_env;
+    if (!f.ptr || (f.bytes != N * 4 && f.bytes != N * 8))
+        return fail(ZENV_E_ARG, "field %d is not one 4- or 8-byte figure per env", field);
+    RcclApi *api = rccl_api();
+    int rc = use_device(h);
+    if (rc) return rc;
+    const bool is_f32 = f.bytes == N * 8 || field == ZENV_F_REWARD;
+    HIP_TRY(launch_gather_prep(f.ptr, (int)(f.bytes / N), h->comm_send, h->n_env, h->stream));
+    RCCL_TRY(api, api->AllGather(h->comm_send, h->comm_recv, (size_t)N, is_f32 ? ncclFloat32 : ncclInt32, h->comm, h->stream));
+    HIP_TRY(hipMemcpyAsync(dst, h->comm_recv, (size_t)N * 4 * (size_t)h->comm_world,
+                           dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ZENV_OK;
+}
+
+extern "C" int zenv_comm_barrier(zenv_t *h)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (!h->comm) return fail(ZENV_E_STATE, "zenv_comm_init first");
+    RcclApi *api = rccl_api();
+    int rc = use_device(h);
+    if (rc) return rc;
+    // every rank's stream reaches this point, then a one-element sum goes round: nobody leaves before everybody came
+    RCCL_TRY(api, api->AllReduce(h->comm_scalar, h->comm_scalar + 1, 1, ncclFloat64, ncclSum, h->comm, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ZENV_OK;
+}
+
+extern "C" int zenv_comm_allreduce_max(zenv_t *h, double *value)
+{
+    if (!h || !value) return fail(ZENV_E_ARG, "null argument");
+    if (!h->comm) return fail(ZENV_E_STATE, "zenv_comm_init first");
+    RcclApi *api = rccl_api();
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->comm_scalar, value, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RCCL_TRY(api, api->AllReduce(h->comm_scalar, h->comm_scalar + 1, 1, ncclFloat64, ncclMax, h->comm, h->stream));
+    HIP_TRY(hipMemcpyAsync(value, h->comm_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ZENV_OK;
+}
+
+// measurement utility: the attainable rate of a write-only row stream of the step kernels' shape on this device
+extern "C" int zenv_probe_store_stream(int device, int64_t n_tiles, int tile_bytes, int steps, int cache_policy,
+                                       int reps, float *us_per_step)
+{
+    if (!us_per_step) return fail(ZENV_E_ARG, "null argument");
+    if (n_tiles < 1 || n_tiles > (1ll << 24) || tile_bytes < 1024 || tile_bytes % 16 || steps < 1 || reps < 1)
+        return fail(ZENV_E_ARG, "bad probe shape");
+    if (cache_policy != 0 && cache_policy != 2 && cache_policy != 16)
+        return fail(ZENV_E_ARG, "cache_policy is 0 (plain), 2 (nt) or 16 (sc1)");
+    HIP_TRY(hipSetDevice(device));
+    float *buf = nullptr;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), (size_t)n_tiles * (size_t)tile_bytes));
+    hipError_t err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
+    float best = 0.f;
+    for (int r = 0; r <= reps && err == hipSuccess; ++r) {          // r == 0: untimed warm-up
+        err = launch_probe_store(buf, n_tiles, tile_bytes, steps, cache_policy, s, e0, e1);
+        if (err == hipSuccess) err = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+        if (r >= 1 && (r == 1 || ms < best)) best = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (s) (void)hipStreamDestroy(s);
+    (void)hipFree(buf);
+    if (err != hipSuccess) return fail(ZENV_E_HIP, "store-stream probe: %s", hipGetErrorString(err));
+    *us_per_step = best * 1e3f / (float)steps;
     return ZENV_OK;
 }
 

@@ -3,11 +3,93 @@
 The step path has no exchange (every env is independent, like the reference's one-process-
 per-env ``ParallelEnv``, main/src/torch_ac/torch_utils/penv.py:26-40), so ranks never talk
 during a rollout.  The only collective of a job is one all-gather of the per-env episodic
-returns (RCCL over xGMI on GPUs; gloo in the CPU tests).  Global env g = rank*n + i plays map
-seeds seed0 + g, seed0 + g + G, seed0 + g + 2G, ... with G = world*n, so results do not
-depend on how the envs are split over ranks (shard invariance).
+returns: ``ncclAllGather`` over RCCL / xGMI through the C ABI (``zenv_allgather``), no PyTorch.
+Global env g = rank*n + i plays map seeds seed0 + g, seed0 + g + G, seed0 + g + 2G, ... with
+G = world*n, so results do not depend on how the envs are split over ranks (shard invariance).
+
+What the host has to do for that collective is hand RCCL's unique id from rank 0 to the other
+ranks: ``FileRendezvous`` does it through a directory every rank of one node can see (the ranks
+of a launcher are children of one agent process; its pid + start time name the directory).  The
+same object carries the CPU-only fallbacks used by rehearsals on a box with fewer GPUs than
+ranks (RCCL refuses two ranks per device) and by the CPU tests.  ``EnvShard.all_gather`` keeps
+the ``torch.distributed`` form for callers that already run a process group (gloo in tests).
 """
+import os
+import time
+
 import numpy as np
+
+
+class FileRendezvous:
+    """Rank-0-to-all broadcast, all-gather and barrier of small host byte strings through files of one directory.
+
+    Not a data path: it moves the 128-byte RCCL unique id (and, in rehearsals without RCCL, the gathered returns).
+    Every exchange has a name; a name is used once per job."""
+
+    def __init__(self, rank, world, directory=None, timeout=300.0):
+        self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        self.dir = directory or self.default_directory()
+        os.makedirs(self.dir, exist_ok=True)
+
+    @staticmethod
+    def default_directory():
+        """One directory per launch: the launcher agent (the parent of every rank) named by pid and start time."""
+        ppid = os.getppid()
+        start = "0"
+        try:
+            with open(f"/proc/{ppid}/stat") as f:
+                start = f.read().rsplit(")", 1)[1].split()[19]      # starttime, clock ticks since boot
+        except (OSError, IndexError):
+            pass
+        port = os.environ.get("MASTER_PORT", "0")
+        return os.path.join(os.environ.get("ZENV_RDZV_DIR", "/tmp"), f"zenv_rdzv_{ppid}_{start}_{port}")
+
+    def _path(self, name, rank):
+        return os.path.join(self.dir, f"{name}.{rank}")
+
+    def _put(self, name, data):
+        tmp = self._path(name, self.rank) + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, self._path(name, self.rank))        # appears whole or not at all
+
+    def _get(self, name, rank):
+        path, t0 = self._path(name, rank), time.monotonic()
+        while not os.path.exists(path):
+            if time.monotonic() - t0 > self.timeout:
+                raise TimeoutError(f"rendezvous: rank {rank} never wrote {name!r} in {self.dir}")
+            time.sleep(0.002)
+        with open(path, "rb") as f:
+            return f.read()
+
+    def broadcast(self, name, data=None):
+        """rank 0 passes `data` (bytes); every rank returns it."""
+        if self.rank == 0:
+            self._put(name, bytes(data))
+            return bytes(data)
+        return self._get(name, 0)
+
+    def all_gather(self, name, data):
+        self._put(name, bytes(data))
+        return [self._get(name, r) for r in range(self.world)]
+
+    def barrier(self, name):
+        self.all_gather(name, b"1")
+
+    def close(self, name="close"):
+        """Everybody is done with the directory; rank 0 removes it."""
+        self.barrier(name)
+        if self.rank == 0:
+            time.sleep(0.05)                                # let the pollers see the last files
+            for f in os.listdir(self.dir):
+                try:
+                    os.remove(os.path.join(self.dir, f))
+                except OSError:
+                    pass
+            try:
+                os.rmdir(self.dir)
+            except OSError:
+                pass
 
 
 class EnvShard:
@@ -18,6 +100,7 @@ class EnvShard:
         self.seed0 = int(seed0)
         self.env_index0 = self.rank * self.n          # global index of local env 0
         self.seed_stride = self.world * self.n        # G
+        self.host_comm = None                         # FileRendezvous standing in for RCCL (rehearsals)
 
     def first_seeds(self):
         return self.seed0 + self.env_index0 + np.arange(self.n, dtype=np.int64)
@@ -32,9 +115,15 @@ class EnvShard:
         env.schedule_sequential(first=np.arange(self.n, dtype=np.int32), stride=self.n)
 
     # ------------------------------------------------------------------ the one collective
+    def comm_init(self, env, rdzv):
+        """Native RCCL communicator over the job's ranks: rank 0 draws the unique id, the rendezvous hands it round."""
+        from .vec_env import comm_unique_id
+        uid = rdzv.broadcast("rccl_unique_id", comm_unique_id() if self.rank == 0 else None)
+        env.comm_init(self.rank, self.world, uid)
+
     def all_gather(self, local):
         """local: 1-D torch tensor [n] (cuda for nccl, cpu for gloo) -> [world*n] on every rank,
-        ordered by global env index."""
+        ordered by global env index.  (The torch.distributed form, for callers that run a process group.)"""
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -48,15 +137,19 @@ class EnvShard:
         return out
 
     def gather_returns(self, env):
-        """Episodic return of each env's last finished episode, float32, all ranks."""
+        """Episodic return of each env's last finished episode, float32 [world * n] on every rank."""
         from . import _native as nat
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            return env.get(nat.F_LAST_RETURN).astype(np.float32)
-        buf = torch.empty(self.n, dtype=torch.float64, device=f"cuda:{env.device}")
-        env.get_into_device(nat.F_LAST_RETURN, buf.data_ptr())
-        local = buf.to(torch.float32)
-        if dist.get_backend() != "nccl":          # gloo (CPU tests, rehearsals): gather host tensors
-            local = local.cpu()
-        return self.all_gather(local).cpu().numpy()
+        if getattr(env, "comm_world", 0):                       # native RCCL (zenv_allgather)
+            return env.allgather(nat.F_LAST_RETURN)
+        local = env.get(nat.F_LAST_RETURN).astype(np.float32)
+        if self.host_comm is not None:                          # rehearsal: ranks share a GPU, RCCL unavailable
+            parts = self.host_comm.all_gather("returns", local.tobytes())
+            return np.concatenate([np.frombuffer(p, np.float32) for p in parts])
+        try:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                import torch
+                return self.all_gather(torch.from_numpy(local)).numpy()
+        except ImportError:
+            pass
+        return local

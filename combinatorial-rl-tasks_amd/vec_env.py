@@ -92,6 +92,21 @@ def zone_feat(cfg):
     return lib().zenv_zone_feat(C.byref(cfg))
 
 
+def comm_unique_id():
+    """rank 0 of a sharded job: the RCCL unique id (128 bytes) every rank passes to ZoneVecEnv.comm_init."""
+    buf = (C.c_char * nat.COMM_ID_BYTES)()
+    check(lib().zenv_comm_unique_id(buf))
+    return bytes(buf.raw)
+
+
+def probe_store_stream(n_tiles, tile_bytes, steps=64, cache_policy=0, reps=3, device=0):
+    """us per step of a bare write-only row stream of the step kernels' shape (zenv_probe_store_stream)."""
+    us = C.c_float(0)
+    check(lib().zenv_probe_store_stream(int(device), int(n_tiles), int(tile_bytes), int(steps), int(cache_policy),
+                                        int(reps), C.byref(us)))
+    return us.value
+
+
 def sample_layout(cfg, seed):
     """Host half of reset() for ``env.seed(seed); env.reset()``.
 
@@ -362,6 +377,41 @@ class ZoneVecEnv:
     def sync(self):
         check(lib().zenv_sync(self._h))
 
+    # ------------------------------------------------------------------ multi-GPU: the one collective (native RCCL)
+    def comm_init(self, rank, world, unique_id):
+        """Join the job's RCCL communicator (collective: every rank calls it).  unique_id: the 128 bytes rank 0 got
+        from ``comm_unique_id()``, handed over by the host (sharding.FileRendezvous)."""
+        uid = bytes(unique_id)
+        if len(uid) != nat.COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {nat.COMM_ID_BYTES} bytes")
+        check(lib().zenv_comm_init(self._h, int(rank), int(world), uid))
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    @property
+    def comm_library(self):
+        path = C.c_char_p()
+        check(lib().zenv_comm_info(self._h, None, None, C.byref(path)))
+        return (path.value or b"").decode()
+
+    def allgather(self, field):
+        """ncclAllGather of one per-env figure over the job's ranks -> [world * N] on the host, ordered by global env
+        index (float64 fields arrive as float32, int32 fields as int32)."""
+        world = getattr(self, "comm_world", 0)
+        if not world:
+            raise nat.ZenvError(nat.E_STATE, "comm_init first")
+        dt = np.int32 if _FIELD_DTYPES[field] == np.int32 else np.float32
+        out = np.empty(world * self.num_envs, dt)
+        check(lib().zenv_allgather(self._h, int(field), out.ctypes.data, 0))
+        return out
+
+    def comm_barrier(self):
+        check(lib().zenv_comm_barrier(self._h))
+
+    def comm_max(self, value):
+        v = C.c_double(float(value))
+        check(lib().zenv_comm_allreduce_max(self._h, C.byref(v)))
+        return v.value
+
     def set_stream(self, hip_stream=None):
         """Enqueue all further work on the caller's HIP stream (an integer hipStream_t, e.g.
         ``torch.cuda.current_stream().cuda_stream``); None = the handle's own stream again.  0 is the null
@@ -395,6 +445,13 @@ class ZoneVecEnv:
             out = np.empty(self._shape(field), _FIELD_DTYPES[field])
         assert out.nbytes == lib().zenv_field_bytes(self._h, field)
         check(lib().zenv_get(self._h, field, out.ctypes.data, 0))
+        return out
+
+    def get_head(self, field, count, first_env=0):
+        """Rows [first_env, first_env + count) of an env-major field (zenv_get_rows)."""
+        shape = (int(count),) + tuple(self._shape(field)[1:])
+        out = np.empty(shape, _FIELD_DTYPES[field])
+        check(lib().zenv_get_rows(self._h, int(field), int(first_env), int(count), out.ctypes.data))
         return out
 
     def get_into_device(self, field, dst_ptr):

@@ -139,6 +139,13 @@ typedef struct zenv zenv_t;
 /* ---- configuration / introspection (host only; usable without a GPU) ---- */
 const char *zenv_last_error(void);
 const char *zenv_version(void);
+/* Benchmark integrity: the extra compiler switches this library was built with ("" = the shipped build; anything else
+ * is a diagnostic variant, e.g. "-DZENV_EXP=1" compiles the row flush out) and the steps one persistent launch really
+ * covers (ZENV_ROLLOUT_CHUNK unless the diagnostic environment variable ZENV_ROLLOUT_CHUNK_EXP shortened it).  bench.py
+ * prints both and refuses to time a variant unless asked to. */
+int zenv_device_count(void);                  /* usable HIP devices (0 without a GPU); does not create a context */
+const char *zenv_build_flags(void);
+int zenv_rollout_chunk(void);
 /* env_id: "PointTSP-v0", "PointTSP-v1", "PointTSP-v4", "PointTSP-v5" (TSPHardEnv), "PointTTSP-v0", "PointTTSP-v1",
  * "ColourMatch-v0" (envs/__init__.py:88-141); unknown id -> ZENV_E_ARG (make_env.py:18 RuntimeError). */
 int zenv_config_for_id(const char *env_id, zenv_config *out);
@@ -293,6 +300,9 @@ int zenv_collect(zenv_t *h, int frames_per_proc, uint64_t policy_seed, uint64_t 
 
 /* ---- results ---- */
 int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device);
+/* The rows of envs [first_env, first_env + count) of an env-major field (obs, zone_obs, reward, counters ...; not the
+ * time-major ZENV_F_EXP_* buffers) into host memory: what a caller that looks at a few envs of a multi-GB batch uses. */
+int zenv_get_rows(zenv_t *h, int field, int first_env, int count, void *dst);
 int zenv_device_ptr(zenv_t *h, int field, void **ptr);  /* zero-copy for GPU consumers */
 int64_t zenv_field_bytes(const zenv_t *h, int field);
 int zenv_sync(zenv_t *h);
@@ -328,6 +338,36 @@ int zenv_step_results(zenv_t *h, const float *actions, int auto_reset, void *hos
  * stream with the env: step, read the obs buffers of zenv_device_ptr(), compute actions, step. */
 int zenv_set_stream(zenv_t *h, void *hip_stream);
 int64_t zenv_step_count(const zenv_t *h);   /* batched steps executed so far */
+
+/* ---- multi-GPU: env shards and the job's one collective ----
+ * The path shards trivially: one process per GPU, rank r owns global envs [r*N, (r+1)*N), nothing is exchanged on the
+ * step path.  After a rollout the per-env episodic figures are all-gathered over RCCL (xGMI) -- what replaces the
+ * reference's per-env Pipe star, main/src/torch_ac/torch_utils/penv.py:26-40, at N > 1.  No PyTorch involved: librccl is
+ * dlopen()ed by the first of these calls (a copy already in the process wins; ZENV_RCCL_PATH names another).
+ *   zenv_comm_unique_id   rank 0: ncclGetUniqueId into id[ZENV_COMM_ID_BYTES]; the host hands it to every rank
+ *                         (any side channel: a file, the launcher's store)
+ *   zenv_comm_init        ncclCommInitRank on the handle's device; collective: every rank calls it
+ *   zenv_allgather        field = one 4- or 8-byte figure per env (ZENV_F_LAST_RETURN, _EP_RETURN: float64 narrowed to
+ *                         float32; ZENV_F_REWARD float32; ZENV_F_EPISODES, _LAST_LEN, _VISIT_COUNT, _EP_LEN int32) ->
+ *                         dst [world * N] 4-byte elements ordered by global env index, on the handle's stream,
+ *                         synchronised on return
+ *   zenv_comm_barrier     the handle's stream drained on every rank (one-element all-reduce + synchronise)
+ *   zenv_comm_allreduce_max  *value = max over ranks (the bench's max-over-ranks step time) */
+#define ZENV_COMM_ID_BYTES 128
+int zenv_comm_unique_id(void *id_out);
+int zenv_comm_init(zenv_t *h, int rank, int world, const void *unique_id);
+int zenv_comm_destroy(zenv_t *h);
+int zenv_comm_info(const zenv_t *h, int *rank, int *world, const char **library);
+int zenv_allgather(zenv_t *h, int field, void *dst, int dst_on_device);
+int zenv_comm_barrier(zenv_t *h);
+int zenv_comm_allreduce_max(zenv_t *h, double *value);
+
+/* Measurement utility (bench.py `store_stream_ceiling`; not part of the env path): n_tiles waves each rewrite their
+ * own contiguous tile_bytes (a multiple of 16, >= 1024) `steps` times with 1 KiB dwordx4 bursts under cache_policy
+ * (0 plain, 2 non-temporal, 16 sc1 = write-through) -- the row stream of the step kernels with the env taken away.
+ * us_per_step = best of `reps` timed launches (dispatch begin/end events) / steps, after one untimed launch. */
+int zenv_probe_store_stream(int device, int64_t n_tiles, int tile_bytes, int steps, int cache_policy, int reps,
+                            float *us_per_step);
 
 /* ---- state snapshot (tests / checkpointing; the reference never checkpoints env state) ---- */
 int64_t zenv_state_bytes(const zenv_t *h);

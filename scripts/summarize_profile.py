@@ -18,6 +18,8 @@ KERNELS = ("k_rollout_lane", "k_step_lane", "k_policy_lane", "k_reset_lane", "k_
 N_SIMD = 256 * 4
 CHUNK = 256
 SETTLE, WARMUP, STEPS = 6000 - 256, 256, 512      # bench.py --steps 512 --warmup 256 (profile_round.sh)
+BIG_WARMUP, BIG_STEPS = 128, 512                   # the batch-size sweep: --no-settle --warmup 128 --steps 512
+BIG_PS_WARMUP, BIG_PS_STEPS = 16, 64               # ... and its per-step passes
 
 
 def short(name):
@@ -27,11 +29,17 @@ def short(name):
     return name[:40]
 
 
-def launch_steps(no_settle):
+def launch_steps(no_settle, warmup=WARMUP, timed=STEPS):
     seq = []
-    for k in ([] if no_settle else [SETTLE]) + [WARMUP, STEPS]:
+    for k in ([] if no_settle else [SETTLE]) + [warmup, timed]:
         seq += [CHUNK] * (k // CHUNK) + ([k % CHUNK] if k % CHUNK else [])
     return seq
+
+
+def kernel_sources_sha():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return list(bench.KERNEL_SOURCES), bench.kernel_sources_sha()
 
 
 def counter_rows(dirname):
@@ -75,10 +83,13 @@ for sub in ("stats", "stats_per_step"):
 
 workloads = sorted({os.path.basename(d)[len("pmc_fetch_"):].rsplit("_", 1)[0].replace("_per", "")
                     for d in glob.glob(os.path.join(out, "pmc_fetch_*")) if os.path.isdir(d)})
-for w in workloads:
+for w in workloads:                       # "PointTSP-25" (N = 65536) or "PointTSP-25@1048576" (the batch-size sweep)
+    wname, n_env = (w.split("@")[0], int(w.split("@")[1])) if "@" in w else (w, 65536)
+    big = "@" in w
     for mode, kern in (("persistent", "k_rollout_lane"), ("per_step", "k_step_lane")):
-        steps = launch_steps(no_settle=(mode == "per_step")) if mode == "persistent" else None
-        ent = {"kernel": kern, "source": f"profiles/{tag}/summary.json",
+        steps = (launch_steps(True, BIG_WARMUP, BIG_STEPS) if big else launch_steps(no_settle=False)) \
+            if mode == "persistent" else None
+        ent = {"kernel": kern, "source": f"profiles/{tag}/summary.json", "n_env": n_env,
                "method": "rocprofv3 --pmc, one counter group per run; FETCH_SIZE (KiB) x2 per MI355X_MICROARCH.md, "
                          "WRITE_SIZE (KiB) as is; persistent: least-squares fixed + per-step over all dispatches of "
                          "`bench.py --steps 512 --warmup 256`; per_step: mean over all dispatches"}
@@ -135,14 +146,18 @@ for w in workloads:
                 if durs:
                     ent["pmc_run_ns_per_step"] = sum(durs) / len(durs)
                     ent["gpu_clock_ghz"] = round(ent["gpu_cycles_per_step"] / ent["pmc_run_ns_per_step"], 3)
-        traffic.setdefault(f"{w}@65536", {})[mode] = ent
+        traffic.setdefault(f"{wname}@{n_env}", {})[mode] = ent
     # GRBM_GUI_ACTIVE / duration reads high on dispatches far below 0.3 ms (MI355X_MICROARCH.md, DVFS give-back): the
     # per-step kernel's cycles are its measured duration at the clock of the same workload's persistent launches
-    ps, pe = traffic[f"{w}@65536"].get("per_step"), traffic[f"{w}@65536"].get("persistent")
+    ps, pe = traffic[f"{wname}@{n_env}"].get("per_step"), traffic[f"{wname}@{n_env}"].get("persistent")
     if ps and pe and "gpu_clock_ghz" in pe and "pmc_run_ns_per_step" in ps:
         ps["gpu_clock_ghz"] = pe["gpu_clock_ghz"]
         ps["gpu_cycles_per_step"] = ps["pmc_run_ns_per_step"] * pe["gpu_clock_ghz"]
         ps["clock_note"] = "clock of the persistent launches of the same workload (short dispatches read high)"
+names, sha = kernel_sources_sha()
+traffic["_meta"] = {"kernel_sources": names, "kernel_sources_sha256": sha, "measured_in": f"profiles/{tag}",
+                    "note": "bench.py marks the record stale (aux.traffic_stale) and tests/test_bench_contract.py fails "
+                            "when the kernel sources no longer hash to this"}
 summary["pmc"] = traffic
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)

@@ -8,6 +8,7 @@ import pytest
 
 import bench
 
+pytest.importorskip("numpy")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -66,3 +67,74 @@ def test_committed_pmc_record_covers_every_workload_and_mode():
             # ... and a VALU-issue fraction is a fraction
             assert 0.05 < 4 * pmc["valu_insts_per_simd_step"] / pmc["gpu_cycles_per_step"] < 1.0
     assert bench.load_pmc("PointTSP-25", 12345, "persistent") is None
+
+
+def test_committed_pmc_record_was_measured_on_the_kernels_in_the_tree():
+    """profiles/traffic.json names the sha256 of the kernel sources it was measured on: a kernel change without a
+    new PMC pass (scripts/profile_round.sh + summarize_profile.py) fails here instead of silently keeping old bytes."""
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        meta = json.load(f).get("_meta", {})
+    assert meta.get("kernel_sources") == list(bench.KERNEL_SOURCES)
+    assert meta.get("kernel_sources_sha256") == bench.kernel_sources_sha(), \
+        "csrc/ changed since the PMC passes of profiles/traffic.json: re-run scripts/profile_round.sh on the GPU box"
+    assert not bench.traffic_is_stale()
+
+
+def test_beyond_llc_sizes_have_committed_counters():
+    """Every batch of aux.beyond_llc carries PMC bytes measured AT THAT SIZE."""
+    task, zones, _ = bench.WORKLOADS["PointTSP-25"]
+    for n in bench.BEYOND_LLC_SIZES:
+        assert bench.output_bytes_per_step(task, zones, n) > 0.5 * bench.LLC_BYTES
+        for mode in ("persistent", "per_step"):
+            pmc = bench.load_pmc("PointTSP-25", n, mode)
+            assert pmc is not None and pmc.get("hbm_bytes_per_step"), (n, mode)
+            # real traffic per step: at least the row stream, at most 10 % over the algorithmic bytes
+            alg = bench.algorithmic_bytes(task, zones, 256 if mode == "persistent" else 1) * n
+            assert 0.85 * alg < pmc["hbm_bytes_per_step"] < 1.10 * alg, (n, mode, pmc["hbm_bytes_per_step"] / alg)
+    assert bench.output_bytes_per_step(task, zones, bench.BEYOND_LLC_SIZES[-1]) > 4 * bench.LLC_BYTES
+
+
+def test_llc_residency_flag():
+    b = bench.roofline_block(0, 25, 65536, 5.24e-6, 256, True, None)
+    assert b["llc_resident"] and b["output_bytes_per_step"] == 65536 * 637 and b["llc_bytes"] == 256 << 20
+    big = bench.roofline_block(0, 25, 1048576, 88e-6, 256, True, None)
+    assert not big["llc_resident"] and big["output_bytes_per_step"] == 1048576 * 637
+
+
+def test_diagnostic_switches_are_recorded_and_refused(monkeypatch, zenv_mod):
+    """a ZENV_* kernel switch or a variant build must show in the line, and bench.py refuses to
+    time it unless asked (--experiment)."""
+    import argparse
+    nat = zenv_mod._native
+    args = argparse.Namespace(override=[])
+    for k in [k for k in os.environ if k.startswith("ZENV_")]:
+        monkeypatch.delenv(k)
+    clean = bench.experiment_switches(nat, args)
+    assert clean["active"] is False and clean["build_flags"] == "" and clean["rollout_chunk"] == nat.ROLLOUT_CHUNK
+    assert clean["env"] == {}
+    monkeypatch.setenv("ZENV_MLP_F32_VALU", "1")
+    monkeypatch.setenv("ZENV_BENCH_FORCE_DIST", "1")        # harness switch: not an experiment
+    monkeypatch.setenv("ZENV_CPU_THREADS", "4")
+    sw = bench.experiment_switches(nat, args)
+    assert sw["active"] and sw["env"] == {"ZENV_MLP_F32_VALU": "1"}
+    monkeypatch.delenv("ZENV_MLP_F32_VALU")
+    assert bench.experiment_switches(nat, argparse.Namespace(override=["frameskip=1"]))["active"]
+
+
+def test_bench_refuses_an_experiment_without_the_flag(zenv_mod):
+    import subprocess
+    import sys
+    env = dict(os.environ, ZENV_ROLLOUT_CHUNK_EXP="16")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "refusing to time a diagnostic configuration" in (r.stderr + r.stdout)
+    assert "ZENV_ROLLOUT_CHUNK_EXP" in (r.stderr + r.stdout)
+
+
+def test_build_stamp_tracks_the_flag_set(monkeypatch, zenv_mod):
+    """A diagnostic .so (ZENV_EXTRA_FLAGS) does not pass for the shipped build, and the other way round."""
+    import combinatorial_rl_tasks_amd.build as B
+    monkeypatch.delenv("ZENV_EXTRA_FLAGS", raising=False)
+    assert B._up_to_date()                                    # the session fixture built the plain library
+    monkeypatch.setenv("ZENV_EXTRA_FLAGS", "-DZENV_EXP=1")
+    assert B.extra_flags() == "-DZENV_EXP=1" and not B._up_to_date()

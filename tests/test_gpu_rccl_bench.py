@@ -1,7 +1,8 @@
-"""The RCCL branch of the sharded job (sharding.py: init_process_group("nccl") -> get_into_device ->
-all_gather_into_tensor) on the one GPU a test box has: bench.py started as a FRESH child process (never a re-exec of
-the pytest process, which has already initialised the GPU) with a 1-rank process group, checked against the same
-command without a process group.  The N > 1 layout of the gather is covered by tests/test_sharding_gloo.py."""
+"""The RCCL branch of the sharded job (sharding.py: zenv_comm_unique_id -> FileRendezvous.broadcast -> zenv_comm_init ->
+zenv_allgather = ncclAllGather through the C ABI, no PyTorch) on the one GPU a test box has: bench.py started as a
+FRESH child process (never a re-exec of the pytest process, which has already initialised the GPU) with a 1-rank
+communicator, checked against the same command without one.  The N > 1 layout of the gather is covered by
+tests/test_sharding_gloo.py and by the 2-rank launch line below (host rendezvous: RCCL refuses two ranks per device)."""
 import json
 import os
 import subprocess
@@ -18,8 +19,12 @@ def _bench(extra_env, *args):
     env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29641", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
                 "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     env.update(extra_env)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "512", "--warmup", "8", "--workload", "ColourMatch-6",
-           "--no-cpu-baseline", "--no-mlp", "--no-steady", "--no-settle", "--envs-per-gpu", "8192", *args]
+    # `-c` with torch made unimportable: the bench's host side is ctypes over the C ABI, nothing else
+    boot = ("import sys, runpy; sys.modules['torch'] = None; sys.argv = sys.argv[1:]; "
+            "runpy.run_path(sys.argv[0], run_name='__main__')")
+    cmd = [sys.executable, "-c", boot, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "512", "--warmup", "8",
+           "--workload", "ColourMatch-6", "--no-cpu-baseline", "--no-mlp", "--no-steady", "--no-settle", "--no-sweep",
+           "--envs-per-gpu", "8192", *args]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, f"rc {r.returncode}\nstdout: {r.stdout[-2000:]}\nstderr: {r.stderr[-4000:]}"
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -27,11 +32,13 @@ def _bench(extra_env, *args):
     return json.loads(lines[0])
 
 
-def test_one_rank_nccl_gather_matches_the_plain_run(zenv_mod):
+def test_one_rank_native_rccl_gather_matches_the_plain_run(zenv_mod):
     plain = _bench({})
     dist = _bench({"ZENV_BENCH_FORCE_DIST": "1"})
     assert plain["aux"]["collective"] == "none (single process)"
-    assert dist["aux"]["collective"] == "nccl all_gather_into_tensor"
+    assert dist["aux"]["collective"].startswith("rccl ncclAllGather (native)")
+    assert "no PyTorch imported" in plain["aux"]["host_side"] and "no PyTorch imported" in dist["aux"]["host_side"]
+    assert plain["aux"]["env_overrides"]["active"] is False
     assert "all-gather" in dist["config"]["parallelism"]
     assert dist["n_gpus"] == 1 and dist["steps"] == 512
     # same envs, same seeds, same steps: the gathered returns are the local ones
@@ -43,15 +50,16 @@ def test_one_rank_nccl_gather_matches_the_plain_run(zenv_mod):
 
 def test_two_rank_launch_line_on_one_gpu(zenv_mod):
     """The driver's N > 1 command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2`
-    -- on this box's one GPU (ZENV_BENCH_REHEARSAL=gloo: both ranks on cuda:0, the process group over gloo): build lock,
-    rendezvous, per-rank shards, barrier-bracketed timing, MAX over ranks, the gather, one JSON line from rank 0.  Shard
+    -- on this box's one GPU (ZENV_BENCH_REHEARSAL=host: both ranks on device 0, gather / barrier / max over the host
+    rendezvous because RCCL refuses two ranks per device): build lock, rendezvous, per-rank shards, barrier-bracketed
+    timing, MAX over ranks, the gather, one JSON line from rank 0.  Shard
     invariance on the device: 2 ranks x 4096 envs return what one process with 8192 envs returns."""
     env = dict(os.environ)
-    env.update({"HSA_ENABLE_IPC_MODE_LEGACY": "0", "ZENV_BENCH_REHEARSAL": "gloo"})
+    env.update({"HSA_ENABLE_IPC_MODE_LEGACY": "0", "ZENV_BENCH_REHEARSAL": "host"})
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     tail = ["--steps", "512", "--warmup", "8", "--workload", "ColourMatch-6", "--no-cpu-baseline", "--no-mlp", "--no-steady",
-            "--no-settle"]
+            "--no-settle", "--no-sweep"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29643", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs-per-gpu", "4096", *tail]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
@@ -61,8 +69,37 @@ def test_two_rank_launch_line_on_one_gpu(zenv_mod):
     two = json.loads(lines[0])
     one = _bench({}, "--envs-per-gpu", "8192")
     assert two["n_gpus"] == 2 and two["config"]["n_env_total"] == 8192 == one["config"]["n_env_total"]
-    assert two["aux"]["collective"] == "gloo" and two["scaling"] == "weak"
+    assert two["aux"]["collective"].startswith("host rendezvous") and two["scaling"] == "weak"
     assert two["value"] > 0 and two["roofline"]["kernel"] == "k_rollout_lane"
     assert two["cpu_baseline"] is None                      # an N = 1 figure
     assert two["aux"]["mean_last_return_all_ranks"] == one["aux"]["mean_last_return_all_ranks"] != 0.0
     assert two["aux"]["parity_spot_check"] == "bit-identical"
+
+
+def test_native_allgather_through_the_c_abi(zenv_mod):
+    """zenv_comm_unique_id / zenv_comm_init / zenv_allgather / zenv_comm_barrier / zenv_comm_allreduce_max in a fresh
+    child (a 1-rank communicator): the gathered float32 returns and int32 episode counts are the local ones."""
+    code = r"""
+import sys, numpy as np
+sys.modules['torch'] = None
+import __graft_entry__ as g
+g.build()
+import combinatorial_rl_tasks_amd as Z
+from combinatorial_rl_tasks_amd.vec_env import comm_unique_id
+env = Z.ZoneVecEnv("ColourMatch-v0", 1000)
+env.build_bank(1, 1000); env.reset()
+env.rollout(700, Z.POLICY_GREEDY)
+env.comm_init(0, 1, comm_unique_id())
+ret = env.allgather(Z.F_LAST_RETURN); ep = env.allgather(Z.F_EPISODES)
+assert ret.dtype == np.float32 and ep.dtype == np.int32 and ret.shape == (1000,)
+assert np.array_equal(ret, env.get(Z.F_LAST_RETURN).astype(np.float32)) and np.array_equal(ep, env.get(Z.F_EPISODES))
+assert ep.sum() > 0
+env.comm_barrier()
+assert env.comm_max(3.25) == 3.25
+assert 'rccl' in env.comm_library
+env.close()
+print('NATIVE_RCCL_OK')
+"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NATIVE_RCCL_OK" in r.stdout, f"rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"

@@ -61,6 +61,51 @@ def test_two_rank_gloo_shard_invariance(oracle_mod, policy):
     mp.spawn(_worker, args=(2, _free_port(), policy), nprocs=2, join=True)
 
 
+def _rdzv_worker(rank, world, directory, q):
+    from combinatorial_rl_tasks_amd.sharding import EnvShard, FileRendezvous
+    r = FileRendezvous(rank, world, directory=directory, timeout=60)
+    uid = r.broadcast("rccl_unique_id", bytes(range(128)) if rank == 0 else None)
+    r.barrier("fence1")
+    shard = EnvShard(rank, world, 4)
+    shard.host_comm = r
+
+    class FakeEnv:          # the rehearsal path of gather_returns: local returns through the host rendezvous
+        comm_world = 0
+
+        def get(self, field):
+            return np.arange(4, dtype=np.float64) + 10.0 * rank
+    got = shard.gather_returns(FakeEnv())
+    elapsed = max(float(np.frombuffer(b, np.float64)[0]) for b in r.all_gather("elapsed", np.float64(1.0 + rank).tobytes()))
+    q.put((rank, uid, got.tolist(), elapsed))
+    r.close()
+
+
+def test_file_rendezvous_three_ranks(tmp_path):
+    """The torch-free side channel of the sharded job (unique-id broadcast, rehearsal gather, max over ranks)."""
+    import multiprocessing as pmp
+    ctx = pmp.get_context("spawn")
+    q = ctx.Queue()
+    d = str(tmp_path / "rdzv")
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, 3, d, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.concatenate([np.arange(4) + 10.0 * r for r in range(3)]).tolist()
+    for rank, uid, got, elapsed in res:
+        assert uid == bytes(range(128)) and got == want and elapsed == 3.0
+    assert not os.path.exists(d)          # rank 0 removed it
+
+
+def test_rendezvous_directory_is_per_launch(monkeypatch):
+    from combinatorial_rl_tasks_amd.sharding import FileRendezvous
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    d = FileRendezvous.default_directory()
+    assert str(os.getppid()) in d and d.endswith("_29999")
+
+
 def test_single_rank_gather_is_identity():
     from combinatorial_rl_tasks_amd.sharding import EnvShard
     shard = EnvShard(0, 1, 8)
