@@ -422,7 +422,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "aux": {"collective": collective, "host_side": "python + ctypes over the C ABI (no PyTorch imported)"
-                    if "torch" not in sys.modules else "python + ctypes over the C ABI (torch present in the process)",
+                    if sys.modules.get("torch") is None else "python + ctypes over the C ABI (torch present in the process)",
                     "env_overrides": exp, "traffic_stale": traffic_is_stale(),
                     "settle_steps_untimed": args.settle, "hip_event_ms_total": round(ms_total, 3),
                     "bank_build_s": round(t_bank, 2), "episodes_finished_rank0": int(ep.sum()),

@@ -20,6 +20,7 @@ KERNEL_LANE_PER_ENV, KERNEL_WAVE_PER_ENV = 0, 1
 HIP_STREAM_LEGACY = 1       # hipStreamLegacy: the null stream as an explicit handle (hip_runtime_api.h)
 ROLLOUT_UNFUSED = 1
 ROLLOUT_PER_STEP = 2
+ROLLOUT_ASYNC = 4
 ROLLOUT_CHUNK = 256
 COMM_ID_BYTES = 128
 
@@ -98,6 +99,8 @@ _PROTOTYPES = {
     "zenv_bank_build_seeds": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
     "zenv_bank_set": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "zenv_bank_size": (C.c_int, [_H]),
+    "zenv_bank_update": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "zenv_schedule_ring": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "zenv_schedule_sequential": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "zenv_schedule_fixed_seeds": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int64]),
     "zenv_reset": (C.c_int, [_H, C.c_void_p]),
@@ -118,6 +121,7 @@ _PROTOTYPES = {
     "zenv_device_ptr": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p)]),
     "zenv_field_bytes": (C.c_int64, [_H, C.c_int]),
     "zenv_sync": (C.c_int, [_H]),
+    "zenv_query": (C.c_int, [_H]),
     "zenv_host_alloc": (C.c_void_p, [C.c_int64]),
     "zenv_host_free": (C.c_int, [C.c_void_p]),
     "zenv_get_many": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),

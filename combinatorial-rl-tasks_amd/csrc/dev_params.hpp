@@ -86,6 +86,6 @@ struct DevParams {
     const DevParams *self;     // device copy of this block (kept current by the host): cold fields are read through it
 };
 
-enum { SCHED_SEQUENTIAL = 0, SCHED_FIXED_SEEDS = 1 };
+enum { SCHED_SEQUENTIAL = 0, SCHED_FIXED_SEEDS = 1, SCHED_RING = 2 };   // RING: sched_stride = ring depth
 
 }  // namespace zenvk

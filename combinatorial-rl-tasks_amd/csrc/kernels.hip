@@ -113,14 +113,22 @@ __device__ __forceinline__ uint32_t pcg_next32_dev(const P &p, int env)
 
 // Bank slot of env's next episode (and advance the schedule).  episode index / first slot are
 // passed in when the caller has already loaded them.
+// slot of episode k under the two host-laid-out schedules: sequential (first + k * stride, wrapping around the bank)
+// and ring (env i owns the slots first .. first + depth - 1 and walks round them; the host refills a slot with episode
+// k + depth once episode k has been taken from it -- Engine.reset's unbounded _seed += 1 stream, zenv_bank_update)
+template <typename P>
+__device__ __forceinline__ int seq_slot(const P &p, int first, int k)
+{
+    if (p.sched_mode == SCHED_RING) return first + k % p.sched_stride;
+    const long long s = (long long)first + (long long)k * (long long)p.sched_stride;
+    return (int)(s % (long long)p.bank_size);
+}
+
 template <typename P>
 __device__ __forceinline__ int next_bank_slot(const P &p, int env, int k, int first)
 {
     p.episode_idx[env] = k + 1;
-    if (p.sched_mode == SCHED_SEQUENTIAL) {
-        const long long s = (long long)first + (long long)k * (long long)p.sched_stride;
-        return (int)(s % (long long)p.bank_size);
-    }
+    if (p.sched_mode != SCHED_FIXED_SEEDS) return seq_slot(p, first, k);
     // wrappers.py:20-23: rng.integers(min_seed, max_seed + 1) -- Lemire on 32-bit draws
     const uint64_t rng = (uint64_t)(p.seed_max - p.seed_min);
     if (rng == 0) return 0;
@@ -903,11 +911,17 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         const int k = e.steps + 1;   // step index after this call
         const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
         if (valid && was_done) {
-            // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
-            for (int z = 0; z < Z; ++z) my_ents[z] = make_float4(0.f, 0.f, -1.f, 0.f);
-            for (int i = 0; i < 8; ++i) o[i] = 0.f;
-            store_obs8(p, env, o);
-            if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = make_float2(0.f, 0.f);
+            // finished earlier and left alone (step_no_reset): a masked no-op -- WaitWrapper.step's zero obs, reward 0,
+            // done (wrappers.py:34-45).  With auto_reset the worker then does what it does after any done step,
+            // `obs = env.reset()` (penv.py:8-11): the env comes back with its next episode's first obs.
+            if (auto_reset) {
+                need_reset = true;
+            } else {
+                for (int z = 0; z < Z; ++z) my_ents[z] = make_float4(0.f, 0.f, -1.f, 0.f);
+                for (int i = 0; i < 8; ++i) o[i] = 0.f;
+                store_obs8(p, env, o);
+                if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = make_float2(0.f, 0.f);
+            }
         } else if (valid) {
             double rx, ry;               // pre-physics pose: what set_mocaps() sees
             world_pos(e, rx, ry);
@@ -1056,9 +1070,8 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         // (L2 / Infinity Cache) when the cooperative reset of the next launch asks for them,
         // instead of costing it a cold HBM round trip at the end of its critical path.  Nothing
         // is consumed here; the registers are only kept alive until the end of the wave.
-        if (ends_soon && auto_reset && p.sched_mode == SCHED_SEQUENTIAL) {
-            const long long sl = ((long long)slot_first + (long long)epi_idx * (long long)p.sched_stride) %
-                                 (long long)p.bank_size;
+        if (ends_soon && auto_reset && p.sched_mode != SCHED_FIXED_SEEDS) {
+            const long long sl = seq_slot(p, slot_first, epi_idx);
             const int *bz = reinterpret_cast<const int *>(p.bank_zone + 2 * (size_t)sl * Z);
             pf[0] = bz[0];                                   // 128-B lines of the 16*Z-byte zone block
             if (4 * Z > 32) pf[1] = bz[32];
@@ -1156,9 +1169,10 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         }
 
         if (valid) {
-            if (!was_done) {
+            if (!was_done || auto_reset) {
                 p.ep_return[env] = ep_ret;
                 store_counters(p, env, TASK, e);
+                if (was_done) p.done_state[env] = 0;      // revived by the reset above
             }
             xmode[lane] = mode;
             xstep[lane] = e.steps;
@@ -1721,7 +1735,9 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
         ep_ret = ep_ret + r;
         const float rew_out = live ? (float)r : 0.f;                   // a frozen env reports reward 0, done 1
         const uint8_t done_out = (!live || done) ? 1 : 0, goal_out = (live && goal) ? 1 : 0;
-        const bool need_reset = live && done && auto_reset;
+        // (a frozen env -- finished earlier under step_no_reset -- comes back at the first auto-reset step: the worker's
+        // `if done: obs = env.reset()` after WaitWrapper's no-op, penv.py:8-11, wrappers.py:34-45)
+        const bool need_reset = valid && auto_reset && (frozen || done);
         // (an env auto-reset in this step reports the finished episode's count; a frozen one keeps its last)
         vcount = live ? (kColour ? e.goal_dist : (int)__popc(e.vis)) : vcount;
         if (live && done) {
@@ -1857,6 +1873,10 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                     dword = kColour ? colpack : (uint64_t)vis0;   // only the pre-visited zones, step count 0
                     pc.seed[env] = pc.bank_seed[slot];
                     store_obs8(p, env, of);
+                    if (frozen) {
+                        pc.done_state[env] = 0;
+                        frozen = false;
+                    }
                 }
             }
         }
@@ -2025,10 +2045,7 @@ __global__ __launch_bounds__(256) void k_solver_goal(DevParams p, int32_t *__res
 // (:52-75).  Like K6 it runs after the step kernel, on the zone visited in the step and the terminal position.
 __device__ __forceinline__ int current_bank_slot(const DevParams &p, int env)
 {
-    if (p.sched_mode == SCHED_SEQUENTIAL) {
-        const long long s = (long long)p.slot_first[env] + (long long)(p.episode_idx[env] - 1) * (long long)p.sched_stride;
-        return (int)(s % (long long)p.bank_size);
-    }
+    if (p.sched_mode != SCHED_FIXED_SEEDS) return seq_slot(p, p.slot_first[env], p.episode_idx[env] - 1);
     return (int)(p.seed[env] - p.seed_min);
 }
 __device__ __forceinline__ void env_world_pos(const DevParams &p, int env, double &rx, double &ry)
@@ -2140,7 +2157,8 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
     const size_t zi = (size_t)lane * N + env;
     const GlobalRowSink sink{ p.zone_obs + (size_t)env * Z * F };
 
-    if (p.done_state[env]) {
+    const bool revive = p.done_state[env] != 0 && auto_reset;   // frozen env at an auto-reset step: see k_step_lane
+    if (p.done_state[env] && !auto_reset) {
         // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
         if (zl) sink.put<TASK>(lane, make_float4(0.f, 0.f, -1.f, 0.f));
         if (lane == 0) {
@@ -2252,21 +2270,23 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
     }
 
     if (lane == 0) {
-        p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
-        if (p.visit_zone) p.visit_zone[env] = first;
-        p.reward[env] = (float)r;
-        p.done_out[env] = done ? 1 : 0;
-        p.goal_met[env] = goal ? 1 : 0;
-        if (done) {
+        // (revive: the step above ran on the frozen state and counts for nothing -- reward 0, done, then the reset)
+        if (!revive) p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
+        if (p.visit_zone) p.visit_zone[env] = revive ? -1 : first;
+        p.reward[env] = revive ? 0.f : (float)r;
+        p.done_out[env] = (done || revive) ? 1 : 0;
+        p.goal_met[env] = (goal && !revive) ? 1 : 0;
+        if (done && !revive) {
             p.last_return[env] = ep_ret;
             p.last_len[env] = k;
             p.episodes[env] += 1;
             p.exception[env] = exc ? 1 : 0;
             if (!auto_reset) p.done_state[env] = 1;
         }
+        if (revive) p.done_state[env] = 0;
     }
 
-    if (done && auto_reset) {
+    if ((done || revive) && auto_reset) {
         // ---- auto-reset (penv.py:8-11): lane z fetches zone z of the next layout
         if (lane == 0 && p.term_xy) {
             double tx, ty;
@@ -2360,6 +2380,23 @@ __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t
     p.goal_met[env] = 0;
 }
 
+// =========================================================================== bank update
+// zenv_bank_update: `count` freshly sampled layouts, packed one record per layout in a staging buffer
+// ([robot 4 f64 | zone 2Z f64 | seed i64 | aux Z i32, padded to 8 B]), scattered into the bank slots they belong to.
+__global__ __launch_bounds__(64) void k_bank_scatter(DevParams p, const int32_t *__restrict__ slots,
+                                                     const unsigned char *__restrict__ staging, int rec_bytes)
+{
+    const int slot = slots[blockIdx.x], Z = p.Z, lane = threadIdx.x;
+    const unsigned char *rec = staging + (size_t)blockIdx.x * rec_bytes;
+    const double *rd = reinterpret_cast<const double *>(rec);
+    double *bank_robot = const_cast<double *>(p.bank_robot), *bank_zone = const_cast<double *>(p.bank_zone);
+    if (lane < 4) bank_robot[4 * (size_t)slot + lane] = rd[lane];
+    for (int i = lane; i < 2 * Z; i += 64) bank_zone[2 * (size_t)slot * Z + i] = rd[4 + i];
+    if (lane == 0) const_cast<int64_t *>(p.bank_seed)[slot] = reinterpret_cast<const int64_t *>(rd + 4 + 2 * Z)[0];
+    const int32_t *ra = reinterpret_cast<const int32_t *>(rd + 4 + 2 * Z + 1);
+    for (int i = lane; i < Z; i += 64) const_cast<int32_t *>(p.bank_aux)[(size_t)slot * Z + i] = ra[i];
+}
+
 // =========================================================================== gather prep
 // The send buffer of the job's one collective (zenv_allgather): field [N] -> 4-byte elements, float64 narrowed to
 // float32 ("ncclAllGather of float ep_return[N/G]").
@@ -2393,6 +2430,14 @@ __global__ __launch_bounds__(kWave) void k_probe_store(float *out, int tile_byte
 }
 
 }  // namespace
+
+hipError_t launch_bank_scatter(const DevParams &p, const int32_t *slots, const void *staging, int rec_bytes, int count,
+                               hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bank_scatter, dim3(count), dim3(64), 0, s, p, slots, static_cast<const unsigned char *>(staging),
+                       rec_bytes);
+    return hipGetLastError();
+}
 
 hipError_t launch_gather_prep(const void *src, int elem_bytes, void *dst, int n, hipStream_t s)
 {

@@ -39,6 +39,9 @@ hipError_t launch_solver_goal(const DevParams &p, int32_t *out, hipStream_t s);
 hipError_t launch_order_reset(const DevParams &p, const uint8_t *mask, hipStream_t s);
 hipError_t launch_order_step(const DevParams &p, hipStream_t s);
 hipError_t launch_policy(const DevParams &p, const StepPolicy &pol, hipStream_t s);
+// zenv_bank_update: scatter `count` packed layout records (rec_bytes each) into the bank slots slots[count]
+hipError_t launch_bank_scatter(const DevParams &p, const int32_t *slots, const void *staging, int rec_bytes, int count,
+                               hipStream_t s);
 // send buffer of zenv_allgather: n elements of 4 (copied) or 8 bytes (float64 -> float32) into 4-byte slots
 hipError_t launch_gather_prep(const void *src, int elem_bytes, void *dst, int n, hipStream_t s);
 // measurement utility: n_tiles waves each rewrite their contiguous tile_bytes `steps` times (aux: 0 plain, 2 nt, 16 sc1)

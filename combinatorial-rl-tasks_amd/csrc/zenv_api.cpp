@@ -102,6 +102,11 @@ struct zenv {
     // experience buffers (zenv_collect)
     ExpBuffers exp{};
     void *exp_mem = nullptr;
+    // staging of zenv_bank_update (page-locked host image + its device copy)
+    void *refill_host = nullptr, *refill_dev = nullptr;
+    size_t refill_cap = 0;
+    hipEvent_t refill_done = nullptr;
+    bool refill_busy = false;
     // the sharded job's communicator (zenv_comm_init): RCCL over xGMI
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 0;
@@ -532,6 +537,9 @@ extern "C" int zenv_destroy(zenv_t *h)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_self) (void)hipFree(h->d_self);
+    if (h->refill_host) (void)hipHostFree(h->refill_host);
+    if (h->refill_dev) (void)hipFree(h->refill_dev);
+    if (h->refill_done) (void)hipEventDestroy(h->refill_done);
     for (void *m : { h->mlp_mem, h->mlp_f32_mem, (void *)h->mlp_value_sigma, h->mlp_pooled, (void *)h->mlp_mu,
                      (void *)h->mlp_std, (void *)h->mlp_value,
                      (void *)h->p.visit_zone, (void *)h->p.term_xy, (void *)h->p.goal, (void *)h->p.goal_last,
@@ -603,24 +611,25 @@ static int upload_bank(zenv *h, const std::vector<double> &robot4, const std::ve
     return ZENV_OK;
 }
 
-extern "C" int zenv_bank_build_seeds(zenv_t *h, const int64_t *seed_list, int count, int n_threads)
+// Engine.reset's random half for a list of env seeds, on n_threads host threads: robot (x, y, quat w, quat z), zone
+// centres, the task's aux column (tmax / colours / route ranks) per seed.
+static int sample_bank_rows(const zenv *h, const int64_t *seed_list, size_t S, int n_threads, std::vector<double> &robot4,
+                            std::vector<double> &zone, std::vector<int32_t> &aux)
 {
-    if (!h || !seed_list) return fail(ZENV_E_ARG, "null argument");
-    if (count < 1) return fail(ZENV_E_ARG, "count must be >= 1");
     const int Z = h->cfg.num_zones;
-    const size_t S = count;
     for (size_t i = 0; i < S; ++i)
         if (seed_list[i] < 0 || seed_list[i] + 1 > 0xFFFFFFFFll)
             return fail(ZENV_E_ARG, "Seed must be between 0 and 2**32 - 1");
-    std::vector<double> robot4(S * 4), zone(S * Z * 2);
-    std::vector<int32_t> aux(S * Z);
-    std::vector<int64_t> seeds(seed_list, seed_list + S);
+    robot4.assign(S * 4, 0.0);
+    zone.assign(S * Z * 2, 0.0);
+    aux.assign(S * Z, 0);
     std::vector<int> status(S, 0);
     n_threads = std::max(1, std::min(n_threads, 256));
+    if ((size_t)n_threads > S) n_threads = (int)S;
     auto work = [&](int tid) {
         for (size_t i = tid; i < S; i += n_threads) {
             Layout L;
-            status[i] = sample_layout(h->cfg, seeds[i], L);
+            status[i] = sample_layout(h->cfg, seed_list[i], L);
             double s, c;
             det_sincos(L.robot_rot / 2, s, c);   // world.py rot2quat: [cos(rot/2), 0, 0, sin(rot/2)]
             robot4[4 * i + 0] = L.robot_x;
@@ -645,8 +654,72 @@ extern "C" int zenv_bank_build_seeds(zenv_t *h, const int64_t *seed_list, int co
     }
     for (size_t i = 0; i < S; ++i)
         if (status[i])
-            return fail(ZENV_E_LAYOUT, "Failed to sample layout of objects (seed %lld)", (long long)seeds[i]);
+            return fail(ZENV_E_LAYOUT, "Failed to sample layout of objects (seed %lld)", (long long)seed_list[i]);
+    return ZENV_OK;
+}
+
+extern "C" int zenv_bank_build_seeds(zenv_t *h, const int64_t *seed_list, int count, int n_threads)
+{
+    if (!h || !seed_list) return fail(ZENV_E_ARG, "null argument");
+    if (count < 1) return fail(ZENV_E_ARG, "count must be >= 1");
+    std::vector<double> robot4, zone;
+    std::vector<int32_t> aux;
+    std::vector<int64_t> seeds(seed_list, seed_list + count);
+    int rc = sample_bank_rows(h, seed_list, (size_t)count, n_threads, robot4, zone, aux);
+    if (rc) return rc;
     return upload_bank(h, robot4, zone, aux, seeds);
+}
+
+// Refill bank slots in place, stream-ordered: the layouts of `seeds` are sampled on the host, staged in page-locked
+// memory, copied once and scattered by a small kernel -- behind every step already enqueued, before every later one.
+extern "C" int zenv_bank_update(zenv_t *h, const int32_t *slots, const int64_t *seed_list, int count, int n_threads)
+{
+    if (!h || !slots || !seed_list) return fail(ZENV_E_ARG, "null argument");
+    if (!h->bank_ready) return fail(ZENV_E_STATE, "build or set the layout bank first");
+    if (count < 0) return fail(ZENV_E_ARG, "count must be >= 0");
+    if (count == 0) return ZENV_OK;
+    for (int i = 0; i < count; ++i)
+        if (slots[i] < 0 || slots[i] >= h->p.bank_size)
+            return fail(ZENV_E_ARG, "slot %d outside the bank [0,%d)", slots[i], h->p.bank_size);
+    int rc = use_device(h);
+    if (rc) return rc;
+    std::vector<double> robot4, zone;
+    std::vector<int32_t> aux;
+    rc = sample_bank_rows(h, seed_list, (size_t)count, n_threads, robot4, zone, aux);
+    if (rc) return rc;
+    const size_t Z = (size_t)h->cfg.num_zones;
+    const size_t rec = (4 + 2 * Z + 1) * 8 + ((Z * 4 + 7) / 8) * 8;
+    const size_t need = (size_t)count * (rec + sizeof(int32_t));
+    if (h->refill_cap < need) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->refill_host) (void)hipHostFree(h->refill_host);
+        if (h->refill_dev) (void)hipFree(h->refill_dev);
+        h->refill_host = h->refill_dev = nullptr;
+        h->refill_cap = 0;
+        const size_t cap = std::max(need * 2, (size_t)1 << 16);
+        HIP_TRY(hipHostMalloc(&h->refill_host, cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&h->refill_dev, cap));
+        h->refill_cap = cap;
+    } else if (h->refill_busy) {
+        HIP_TRY(hipEventSynchronize(h->refill_done));      // the previous refill still reads the staging buffer
+    }
+    char *hb = static_cast<char *>(h->refill_host);
+    for (int i = 0; i < count; ++i) {
+        double *rd = reinterpret_cast<double *>(hb + (size_t)i * rec);
+        std::memcpy(rd, &robot4[4 * (size_t)i], 32);
+        std::memcpy(rd + 4, &zone[2 * Z * (size_t)i], 16 * Z);
+        std::memcpy(rd + 4 + 2 * Z, &seed_list[i], 8);
+        std::memcpy(rd + 4 + 2 * Z + 1, &aux[Z * (size_t)i], 4 * Z);
+    }
+    std::memcpy(hb + (size_t)count * rec, slots, (size_t)count * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(h->refill_dev, h->refill_host, need, hipMemcpyHostToDevice, h->stream));
+    const char *db = static_cast<const char *>(h->refill_dev);
+    HIP_TRY(launch_bank_scatter(h->p, reinterpret_cast<const int32_t *>(db + (size_t)count * rec), db, (int)rec, count,
+                                h->stream));
+    if (!h->refill_done) HIP_TRY(hipEventCreateWithFlags(&h->refill_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->refill_done, h->stream));
+    h->refill_busy = true;
+    return ZENV_OK;
 }
 
 extern "C" int zenv_bank_build(zenv_t *h, int64_t seed_first, int count, int n_threads)
@@ -725,6 +798,26 @@ extern "C" int zenv_schedule_sequential(zenv_t *h, const int32_t *first, int32_t
     HIP_TRY(hipMemset(h->p.episode_idx, 0, h->n_env * sizeof(int32_t)));
     h->p.sched_mode = SCHED_SEQUENTIAL;
     h->p.sched_stride = stride % S;
+    h->sched_ready = true;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_schedule_ring(zenv_t *h, const int32_t *first, int32_t depth)
+{
+    if (!h || !first) return fail(ZENV_E_ARG, "null argument");
+    if (!h->bank_ready) return fail(ZENV_E_STATE, "build or set the layout bank first");
+    if (depth < 1) return fail(ZENV_E_ARG, "ring depth must be >= 1");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int S = h->p.bank_size;
+    for (int i = 0; i < h->n_env; ++i)
+        if (first[i] < 0 || (int64_t)first[i] + depth > S)
+            return fail(ZENV_E_ARG, "ring of env %d, slots [%d, %d), leaves the bank [0,%d)", i, first[i], first[i] + depth, S);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->p.slot_first, first, (size_t)h->n_env * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->p.episode_idx, 0, h->n_env * sizeof(int32_t)));
+    h->p.sched_mode = SCHED_RING;
+    h->p.sched_stride = depth;
     h->sched_ready = true;
     return ZENV_OK;
 }
@@ -1189,6 +1282,13 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
         h->act_tag.index0 = env_index0;
         h->act_tag.step = h->step_count;
     }
+    if (flags & ZENV_ROLLOUT_ASYNC) {
+        // enqueue only: the caller overlaps host work (bank refills, a PPO update) with the launches and collects with
+        // zenv_query() / zenv_sync(); no times are reported
+        if (ms_total) *ms_total = -1.f;
+        if (ms_step_kernel_avg) *ms_step_kernel_avg = -1.f;
+        return ZENV_OK;
+    }
     hipEvent_t ev_first = own_bracket ? h->events[0] : h->events[2];
     hipEvent_t ev_last = own_bracket ? h->events[1] : h->events[3 + 2 * (n_sampled - 1)];
     HIP_TRY(hipEventSynchronize(ev_last));
@@ -1520,6 +1620,20 @@ extern "C" int zenv_sync(zenv_t *h)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return ZENV_OK;
+}
+
+extern "C" int zenv_query(zenv_t *h)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const hipError_t e = hipStreamQuery(h->stream);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();      // not an error: clear the sticky code
+        return 0;
+    }
+    return fail(ZENV_E_HIP, "hipStreamQuery: %s", hipGetErrorString(e));
 }
 
 extern "C" int64_t zenv_step_count(const zenv_t *h) { return h ? h->step_count : 0; }

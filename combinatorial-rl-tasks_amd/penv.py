@@ -15,7 +15,7 @@ from .envs.wrappers import FixedSeedsWrapper, WaitWrapper, ZoneWrapper
 from .envs.zone_envs import ColourMatchNextCityEnv, TSPNextCityEnv, ZoneEnvBase
 from .vec_env import ZoneVecEnv
 
-_PLAIN_EPISODES = 256   # default bank depth for envs that are not behind a FixedSeedsWrapper
+_RING_DEPTH = 4   # default ring of pre-sampled maps per env for envs that are not behind a FixedSeedsWrapper
 
 
 def _unwrap(env):
@@ -32,10 +32,12 @@ def _unwrap(env):
 class ParallelEnv:
     """A batch of zone envs stepped by one MI355X kernel launch."""
 
-    def __init__(self, envs, device=0, episodes_per_env=_PLAIN_EPISODES):
-        """episodes_per_env: only for plain seeded envs (no FixedSeedsWrapper) -- how many episodes of env i
-        (Engine.reset's seeds _seed, _seed + 1, ...) are sampled ahead into the device bank.  Stepping past the last
-        one raises instead of silently replaying another env's maps."""
+    def __init__(self, envs, device=0, episodes_per_env=_RING_DEPTH):
+        """episodes_per_env: only for plain seeded envs (no FixedSeedsWrapper, e.g. make_test_env, make_env.py:20-35) --
+        the depth of the ring of maps kept ahead of each env on the device.  Env i plays Engine.reset's unbounded
+        stream _seed, _seed + 1, ... ([not vendored] Engine.reset: `_seed += 1` at every reset): every reset -- an
+        explicit reset() or the auto-reset inside step() -- takes the next map from the env's ring and the host puts
+        the map `depth` episodes further on into the slot it came from (zenv_bank_update), so the stream never ends."""
         assert len(envs) >= 1, "No environment given."
         self._plain_depth = None
         self.envs = envs
@@ -60,15 +62,18 @@ class ParallelEnv:
             self._vec.schedule_fixed_seeds(np.array([f.rng_seed for f in fixed], np.uint64), int(lo), int(hi))
         elif all(f is None for f in fixed):
             # Engine semantics: reset k of env i plays seed _seed_i + k (reset() does _seed += 1)
+            depth = max(1, int(episodes_per_env))
             seeds = []
             for b in bases:
                 if b._seed is None:
                     b.seed(None)
-                seeds.append(int(b._seed) + np.arange(int(episodes_per_env), dtype=np.int64))
+                seeds.append(int(b._seed) + np.arange(depth, dtype=np.int64))
+            self._seed0 = np.array([s[0] for s in seeds], np.int64)     # seed of env i's episode 0
             self._vec.build_bank_seeds(np.concatenate(seeds))
-            self._vec.schedule_sequential(first=np.arange(self.num_envs, dtype=np.int32) * int(episodes_per_env),
-                                          stride=1)
-            self._plain_depth = int(episodes_per_env)
+            self._ring_first = np.arange(self.num_envs, dtype=np.int32) * depth
+            self._vec.schedule_ring(self._ring_first, depth)
+            self._consumed = np.zeros(self.num_envs, np.int64)           # maps env i has taken from its ring
+            self._plain_depth = depth
         else:
             raise ValueError("mixing seeded and FixedSeedsWrapper envs is not supported")
         self._goals = all(isinstance(b, (TSPNextCityEnv, ColourMatchNextCityEnv)) for b in bases)
@@ -79,7 +84,18 @@ class ParallelEnv:
     def reset(self):
         self._vec.reset()
         self._finished = None
+        if self._plain_depth is not None:
+            self._refill(np.arange(self.num_envs))
         return self._obs_list()
+
+    def _refill(self, envs_idx):
+        """envs_idx just took a map each (episode k = _consumed[i]) from their rings: put episode k + depth into the
+        slot it came from.  The device never runs dry: a step ends at most one episode per env, and this runs before
+        the next step is enqueued."""
+        k = self._consumed[envs_idx]
+        slots = self._ring_first[envs_idx] + (k % self._plain_depth)
+        self._vec.update_bank(slots, self._seed0[envs_idx] + k + self._plain_depth)
+        self._consumed[envs_idx] = k + 1
 
     def step(self, actions):
         return self._step(actions, True)
@@ -118,8 +134,11 @@ class ParallelEnv:
     # ------------------------------------------------------------------ array surface
     def step_arrays(self, actions, auto_reset=True):
         """(obs (P,8), zone_obs (P,Z,F), reward (P,), done (P,), goal_met (P,)) float32/bool."""
-        return self._vec.step_results(np.asarray(actions, np.float32).reshape(self.num_envs, 2),
-                                      auto_reset=auto_reset)[:5]
+        res = self._vec.step_results(np.asarray(actions, np.float32).reshape(self.num_envs, 2),
+                                     auto_reset=auto_reset)[:5]
+        if self._plain_depth is not None and auto_reset and res[3].any():
+            self._refill(np.flatnonzero(res[3]))
+        return res
 
     @property
     def vec(self):
@@ -142,11 +161,9 @@ class ParallelEnv:
         was_finished = getattr(self, "_finished", None)
         any_done = bool(d.any())
         if self._plain_depth is not None and auto_reset and any_done:
-            # episode k of env i sits in slot i * depth + k: the reset that follows the depth-th episode end would
-            # take env i + 1's first map (Engine.reset would play seed _seed + depth)
-            if int(self._vec.get(nat.F_EPISODES).max()) >= self._plain_depth:
-                raise RuntimeError(f"ParallelEnv: an env finished its {self._plain_depth} pre-sampled episodes; build "
-                                   "it with a larger episodes_per_env, or wrap the envs in FixedSeedsWrapper")
+            # every env that reports done was reset inside the step (also one left finished by step_no_reset: the
+            # worker resets it after WaitWrapper's no-op, penv.py:8-11): each took a map from its ring
+            self._refill(np.flatnonzero(d))
         # info dicts: {'cost': 0} for everybody, then the few envs with something to say
         infos = [{"cost": 0} for _ in range(P)]
         if was_finished is not None and was_finished.any():

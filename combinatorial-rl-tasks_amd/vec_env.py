@@ -207,6 +207,22 @@ class ZoneVecEnv:
             raise ValueError("first must have shape (num_envs,)")
         check(lib().zenv_schedule_sequential(self._h, None if f is None else f.ctypes.data, int(stride)))
 
+    def schedule_ring(self, first, depth):
+        """Env i walks round the slots first[i] .. first[i] + depth - 1 (zenv_schedule_ring); ``update_bank`` keeps
+        the ring ahead of it."""
+        f = np.ascontiguousarray(first, np.int32)
+        if f.shape != (self.num_envs,):
+            raise ValueError("first must have shape (num_envs,)")
+        check(lib().zenv_schedule_ring(self._h, f.ctypes.data, int(depth)))
+
+    def update_bank(self, slots, seeds, n_threads=4):
+        """Refill bank slots in place with the layouts of `seeds` (zenv_bank_update; stream-ordered)."""
+        sl = np.ascontiguousarray(slots, np.int32).reshape(-1)
+        sd = np.ascontiguousarray(seeds, np.int64).reshape(-1)
+        if sl.shape != sd.shape:
+            raise ValueError("one seed per slot")
+        check(lib().zenv_bank_update(self._h, sl.ctypes.data, sd.ctypes.data, sl.size, int(n_threads)))
+
     def schedule_fixed_seeds(self, rng_seeds, min_seed, max_seed):
         s = np.ascontiguousarray(rng_seeds, np.uint64)
         if s.shape != (self.num_envs,):
@@ -241,7 +257,7 @@ class ZoneVecEnv:
                                 None if dst_ptr is None else C.c_void_p(int(dst_ptr))))
 
     def rollout(self, steps, policy, policy_seed=0x5EED, env_index0=0, auto_reset=True,
-                time_step_kernel=False, fused=True, event_stride=1, mode=None):
+                time_step_kernel=False, fused=True, event_stride=1, mode=None, wait=True):
         """K closed-loop steps a_t = policy(obs_t, t); step(a_t) on the handle's stream.
 
         mode "persistent" (default): one launch advances every env by up to 256 steps, state in
@@ -254,6 +270,8 @@ class ZoneVecEnv:
         if mode is None:
             mode = "persistent" if fused else "unfused"
         flags = {"persistent": 0, "per_step": nat.ROLLOUT_PER_STEP, "unfused": nat.ROLLOUT_UNFUSED}[mode]
+        if not wait:            # enqueue only (ZENV_ROLLOUT_ASYNC): collect with done() / sync(); no times
+            flags |= nat.ROLLOUT_ASYNC
         total = C.c_float(0)
         kern = C.c_float(0)
         check(lib().zenv_rollout(self._h, int(steps), int(policy), int(policy_seed),
@@ -376,6 +394,13 @@ class ZoneVecEnv:
 
     def sync(self):
         check(lib().zenv_sync(self._h))
+
+    def done(self):
+        """Non-blocking: has everything enqueued on the handle's stream finished (zenv_query)?"""
+        rc = lib().zenv_query(self._h)
+        if rc < 0:
+            check(rc)
+        return rc == 1
 
     # ------------------------------------------------------------------ multi-GPU: the one collective (native RCCL)
     def comm_init(self, rank, world, unique_id):

@@ -12,8 +12,9 @@
  * 0 on success or a negative ZENV_E_* code (text from zenv_last_error()); no exception
  * crosses the boundary.  The caller owns every buffer it passes; the library owns the
  * handle and its device memory until zenv_destroy().  A handle is bound to one device and
- * one HIP stream and is not thread-safe.  zenv_step()/zenv_reset()/zenv_policy() are
- * asynchronous on the handle's stream; zenv_get() and zenv_sync() synchronise.
+ * one HIP stream and is not thread-safe.  zenv_step()/zenv_reset()/zenv_policy()/zenv_bank_update() are
+ * asynchronous on the handle's stream; zenv_get*(), zenv_sync() and -- unless ZENV_ROLLOUT_ASYNC is set --
+ * zenv_rollout() synchronise.
  *
  * There is no CPU fallback: every compute entry point fails with ZENV_E_HIP when no
  * gfx950 device is usable.
@@ -182,10 +183,19 @@ int zenv_bank_build_seeds(zenv_t *h, const int64_t *seeds, int count, int n_thre
 int zenv_bank_set(zenv_t *h, const double *robot_xyrot, const double *zone_xy,
                   const int32_t *aux, const int64_t *seeds, int count);
 int zenv_bank_size(const zenv_t *h);
+/* Refill bank slots in place: slot slots[j] <- the layout of env seed seeds[j] (sampled here, on n_threads host
+ * threads).  Stream-ordered: it lands behind every step already enqueued and before every later one.  With
+ * zenv_schedule_ring this is Engine.reset's unbounded seed stream (_seed += 1 at every reset, [not vendored]
+ * Engine.reset; make_env.py:20-35 make_test_env never runs out of maps): once env i has taken episode k from its ring,
+ * the host puts episode k + depth into the slot that held it. */
+int zenv_bank_update(zenv_t *h, const int32_t *slots, const int64_t *seeds, int count, int n_threads);
 
 /* ---- episode schedule: which bank slot env i uses for its k-th episode ---- */
 /* slot = (first[i] + k*stride) mod S; first == NULL -> i mod S. */
 int zenv_schedule_sequential(zenv_t *h, const int32_t *first, int32_t stride);
+/* Ring: env i owns the slots first[i] .. first[i] + depth - 1 and takes slot first[i] + (k mod depth) for its k-th
+ * episode; the host keeps the ring ahead of the env with zenv_bank_update. */
+int zenv_schedule_ring(zenv_t *h, const int32_t *first, int32_t depth);
 /* FixedSeedsWrapper semantics on device: env i draws seeds from its own PCG64 stream
  * default_rng(rng_seeds[i]).integers(min_seed, max_seed+1); the bank must hold
  * min_seed..max_seed in order (make_env.py:3-18,37-51). */
@@ -199,7 +209,10 @@ int zenv_reset(zenv_t *h, const uint8_t *mask);
  * (NULL = internal action buffer written by zenv_policy); auto_reset != 0 resets finished
  * envs in the same launch and returns the new episode's first observation with the terminal
  * reward/done/goal_met (penv.py:8-11).  With auto_reset == 0 a finished env is a masked
- * no-op: zero obs, reward 0, done 1 (WaitWrapper, wrappers.py:34-45).
+ * no-op: zero obs, reward 0, done 1 (WaitWrapper, wrappers.py:34-45); the first auto_reset != 0 step after that
+ * brings it back -- reward 0, done 1 and the next episode's first observation -- as the worker's
+ * `if done: obs = env.reset()` does after WaitWrapper's no-op (the fixed-length-skill loop,
+ * torch_ac/algos/hier_base.py:179-183: skill_len - 1 step_no_reset calls, then one step).
  * Exception path ([not vendored] Engine.step: `except MujocoException: done = True; reward = reward_exception;
  * info['exception'] = True`): mujoco-py raises it when MuJoCo warns that qacc / qpos / qvel hold a NaN, an Inf or a
  * value beyond 1e10 (mj_checkAcc -> mjWARN_BADQACC, after which MuJoCo has reset the data to qpos0, qvel = 0).  With
@@ -220,8 +233,13 @@ int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0
  * on the stream); ms_step_kernel_avg (may be NULL): kernel time per step -- persistent: begin/end
  * events of every launch, summed, / steps; otherwise the mean over every event_stride-th
  * step-kernel dispatch. */
+/* zenv_rollout() is SYNCHRONOUS by default: it returns when its last launch has finished (it reports their times).
+ * ZENV_ROLLOUT_ASYNC: enqueue and return at once (ms_* come back as -1); the host overlaps its own work -- refilling
+ * bank slots (zenv_bank_update), a policy update -- and collects with zenv_query() (1 = the stream is idle, 0 = still
+ * running, < 0 error) or zenv_sync(). */
 #define ZENV_ROLLOUT_UNFUSED 1
 #define ZENV_ROLLOUT_PER_STEP 2
+#define ZENV_ROLLOUT_ASYNC 4
 #define ZENV_ROLLOUT_CHUNK 256   /* most steps one persistent launch covers */
 int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
                  int auto_reset, int flags, int event_stride, float *ms_total,
@@ -306,6 +324,7 @@ int zenv_get_rows(zenv_t *h, int field, int first_env, int count, void *dst);
 int zenv_device_ptr(zenv_t *h, int field, void **ptr);  /* zero-copy for GPU consumers */
 int64_t zenv_field_bytes(const zenv_t *h, int field);
 int zenv_sync(zenv_t *h);
+int zenv_query(zenv_t *h);   /* non-blocking: 1 = everything enqueued on the handle's stream has finished, 0 = not yet */
 /* Host-policy surface (a CPU-resident policy: actions up, observations down, every step): page-locked host
  * memory for the caller's buffers, so that zenv_step()'s action upload and zenv_get()'s downloads run as DMA
  * at PCIe rate instead of through a pageable bounce buffer.  zenv_get_many() enqueues several downloads and

@@ -69,7 +69,11 @@ class OracleBatch:
         g = np.zeros(n, bool)
         for i, e in enumerate(self.envs):
             if e.e.done:
-                d[i] = True      # masked no-op, like the device batch
+                # finished earlier under step_no_reset: WaitWrapper's no-op (zero obs, reward 0, done, wrappers.py:34-45);
+                # under `step` the worker then resets it like after any done step (penv.py:8-11)
+                d[i] = True
+                if auto_reset:
+                    e.reset(self.seeds[i])
                 continue
             r[i], d[i], g[i] = e.step(actions[i])
             if d[i] and auto_reset:

@@ -305,3 +305,93 @@ def test_step_results_is_step_plus_every_download(zenv_mod):
             a_env.step_results(np.zeros((n + 1, 2), np.float32))
         a_env.close()
         b_env.close()
+
+
+def test_plain_seeded_parallel_env_never_runs_out_of_maps(zenv_mod, oracle_mod):
+    """[not vendored] Engine.reset: `_seed += 1` at every reset, for ever -- make_test_env (make_env.py:20-35) envs in a
+    ParallelEnv play seed, seed + 1, seed + 2, ...  16 PointTSP-v1 envs, >= 1000 episodes EACH (a ring of 3 maps per env
+    on the device, refilled by the host sampler behind every reset: zenv_schedule_ring + zenv_bank_update), every obs /
+    reward / done in lock-step with the oracle playing the same seed stream; two explicit reset() calls in between
+    consume a seed each, as Engine.reset does."""
+    Zm, O = zenv_mod, oracle_mod
+    from combinatorial_rl_tasks_amd.envs import make_test_env
+    from combinatorial_rl_tasks_amd.penv import ParallelEnv
+    P, base = 16, 4000
+    penv = ParallelEnv([make_test_env("PointTSP-v1", seed=base + 100000 * i) for i in range(P)], episodes_per_env=3)
+    cfg = oracle_config_from(O, Zm.config_for_id("PointTSP-v1"))
+    refs = [O.OracleEnv(cfg) for _ in range(P)]
+    nxt = [base + 100000 * i for i in range(P)]           # the seed the next reset of env i plays
+
+    def ref_reset(i):
+        out = refs[i].reset(nxt[i])
+        nxt[i] += 1
+        return out
+    penv.reset()
+    ref_obs = [ref_reset(i) for i in range(P)]
+    episodes = np.zeros(P, np.int64)
+    t = 0
+    while episodes.min() < 1000:
+        if t in (5000, 5001):                               # Engine.reset consumes a seed whenever it is called
+            obs = penv.reset()
+            ref_obs = [ref_reset(i) for i in range(P)]
+            for i in range(P):
+                assert np.array_equal(obs[i]["obs"].astype(np.float32), ref_obs[i][0]), (t, i)
+        acts = np.stack([refs[i].policy(O.POLICY_GREEDY, ref_obs[i][0], ref_obs[i][1], i, t) for i in range(P)])
+        o, zo, r, d, g = penv.step_arrays(acts)
+        for i in range(P):
+            rr, dd, gg = refs[i].step(acts[i])
+            assert np.float32(rr) == r[i] and dd == d[i] and gg == g[i], (t, i)
+            if dd:
+                ref_obs[i] = ref_reset(i)
+                episodes[i] += 1
+            else:
+                ref_obs[i] = refs[i].obs()
+            if dd or t % 64 == 0:                           # every episode boundary + a sample of ordinary steps
+                assert np.array_equal(o[i], ref_obs[i][0]) and np.array_equal(zo[i], ref_obs[i][1]), (t, i, episodes[i])
+        t += 1
+        assert t < 2_000_000
+    assert episodes.min() >= 1000 and np.array_equal(penv.vec.get(Zm.F_EPISODES), episodes)
+    assert np.array_equal(penv.vec.get(Zm.F_SEED), np.array(nxt) - 1)      # each env is on the last seed it drew
+    penv.close()
+
+
+def test_skill_boundary_step_resets_envs_left_finished(zenv_mod, oracle_mod):
+    """The fixed-length-skill loop (torch_ac/algos/hier_base.py:179-183): skill_len - 1 `step_no_reset` calls, then one
+    `step`, on make_train_env(hier=True) envs (WaitWrapper(ZoneWrapper(FixedSeedsWrapper)), make_env.py:12-14).  An env
+    that finished inside the skill idles as WaitWrapper's no-op (zero obs, reward 0, done, info {}) and the boundary
+    `step` brings it back: the worker's `if done: obs = env.reset()` (penv.py:8-11) returns the next episode's first obs
+    -- a freshly drawn seed -- with reward 0 and done."""
+    Zm, O = zenv_mod, oracle_mod
+    from combinatorial_rl_tasks_amd.envs import make_train_env
+    from combinatorial_rl_tasks_amd.penv import ParallelEnv
+    P, skill_len, tasks = 8, 25, 20
+    penv = ParallelEnv([make_train_env("PointTSP-v1", hier=True, num_training_tasks=tasks, rng_seed=3 + 10000 * i)
+                        for i in range(P)])
+    cfg = oracle_config_from(O, Zm.config_for_id("PointTSP-v1"))
+    refs = [O.OracleEnv(cfg) for _ in range(P)]
+    rngs = [np.random.default_rng(3 + 10000 * i) for i in range(P)]
+    draw = lambda i: int(rngs[i].integers(low=1, high=tasks + 1, size=1)[0])   # noqa: E731
+    obs = penv.reset()
+    ref_obs = [refs[i].reset(draw(i)) for i in range(P)]
+    revived = 0
+    for t in range(1500):
+        acts = np.stack([refs[i].policy(O.POLICY_GREEDY, ref_obs[i][0], ref_obs[i][1], i, t) for i in range(P)])
+        boundary = (t + 1) % skill_len == 0
+        obs, rew, done, info = (penv.step if boundary else penv.step_no_reset)(acts)
+        for i in range(P):
+            if refs[i].e.done:                              # WaitWrapper: the inner env is already done
+                assert rew[i] == 0.0 and done[i] and info[i] == {}, (t, i)
+                if boundary:
+                    ref_obs[i] = refs[i].reset(draw(i))
+                    revived += 1
+                else:
+                    ref_obs[i] = (np.zeros(8, np.float32), np.zeros_like(ref_obs[i][1]))
+            else:
+                r, d, g = refs[i].step(acts[i])
+                assert abs(rew[i] - r) <= 1e-5 and done[i] == d and info[i].get("goal_met", False) == g, (t, i)
+                # the terminal step's own obs under step_no_reset, the next episode's first obs under step
+                ref_obs[i] = refs[i].reset(draw(i)) if (d and boundary) else refs[i].obs()
+            assert np.array_equal(obs[i]["obs"].astype(np.float32), ref_obs[i][0]), (t, i)
+            assert np.array_equal(obs[i]["zone_obs"].astype(np.float32), ref_obs[i][1]), (t, i)
+    assert revived >= P
+    penv.close()

@@ -110,8 +110,9 @@ def test_lockstep_with_adversarial_actions_and_reset_patterns(zenv_mod, oracle_m
         got = env.step_results(a, auto_reset=auto)
         r_ref, d_ref, g_ref = ob.step(a, auto_reset=auto)
         o_ref, zo_ref = ob.obs()
-        o_ref[~live] = 0                       # an env that was already finished: WaitWrapper's noop_obs (zeros), reward 0
-        zo_ref[~live] = 0
+        if not auto:                           # an env that was already finished: WaitWrapper's noop_obs (zeros), reward 0;
+            o_ref[~live] = 0                   # under auto-reset the worker resets it and returns the new first obs
+            zo_ref[~live] = 0
         assert np.array_equal(got[3], d_ref) and np.array_equal(got[4], g_ref), (case, t)
         assert np.array_equal(got[2], r_ref.astype(np.float32)), (case, t)
         assert np.array_equal(got[0], o_ref) and np.array_equal(got[1], zo_ref), (case, t)
