@@ -233,9 +233,13 @@ def test_state_blob_with_a_nan_is_refused(zenv_mod):
     env.close()
 
 
-def test_plain_seeded_parallel_env_stops_at_the_end_of_its_bank(zenv_mod):
-    """A ParallelEnv over seeded envs without FixedSeedsWrapper pre-samples episodes_per_env maps per env
-    (Engine.reset: _seed += 1) and raises when one env has played them all, instead of drifting into another env's."""
+@pytest.mark.parametrize("depth", [1, 2])
+def test_plain_seeded_parallel_env_with_an_episode_ending_at_every_step(zenv_mod, depth):
+    """The hardest case for the ring of pre-sampled maps (penv.py, zenv_schedule_ring + zenv_bank_update): every step
+    ends every env's episode (a NaN action: Engine.step's exception branch), so every step takes a map from every ring
+    and the host refills it before the next step -- with a ring of ONE map too.  Env i keeps playing Engine.reset's
+    seed stream s_i, s_i + 1, s_i + 2, ...; explicit reset() calls consume a seed each as well."""
+    Z = zenv_mod
     from combinatorial_rl_tasks_amd import envs
     from combinatorial_rl_tasks_amd.penv import ParallelEnv
     es = []
@@ -243,13 +247,22 @@ def test_plain_seeded_parallel_env_stops_at_the_end_of_its_bank(zenv_mod):
         e = envs.make("PointTSP-v1")
         e.seed(100 * i)
         es.append(envs.ZoneWrapper(e))
-    penv = ParallelEnv(es, episodes_per_env=2)
-    penv.reset()
+    penv = ParallelEnv(es, episodes_per_env=depth)
+    cfg = Z.config_for_id("PointTSP-v1")
     a = np.full((3, 2), np.nan, np.float32)            # a NaN action ends the episode at once (exception branch)
-    _, r, d, info = penv.step(a)
-    assert all(d) and r == (-10.0,) * 3 and all(i == {"exception": True} for i in info)
-    with pytest.raises(RuntimeError, match="pre-sampled episodes"):
-        penv.step(a)
+    k = 0                                              # resets so far: env i is on seed 100 i + k - 1
+    for rnd in range(3):
+        obs = penv.reset()
+        k += 1
+        for t in range(40):
+            if t:
+                obs, r, d, info = penv.step(a)
+                k += 1
+                assert all(d) and r == (-10.0,) * 3 and all(i == {"exception": True} for i in info)
+            assert np.array_equal(penv.vec.get(Z.F_SEED), 100 * np.arange(3) + k - 1), (rnd, t)
+            for i in range(3):                         # the first obs of that seed's map: zone rows = its layout / 3
+                _, zones, _, _ = Z.sample_layout(cfg, 100 * i + k - 1)
+                assert np.array_equal(obs[i]["zone_obs"][:, :2].astype(np.float32), (zones / 3.0).astype(np.float32))
     penv.close()
 
 
