@@ -206,6 +206,8 @@ def main():
                     help="skip the 8192-step steady-state side measurement of the same kernel (aux.steady_state)")
     ap.add_argument("--no-mlp", action="store_true",
                     help="skip the side measurement with the reference's actor network as the on-device policy")
+    ap.add_argument("--no-per-step", action="store_true",
+                    help="skip the per-step-kernel side measurement (aux.per_step_launch_mode)")
     ap.add_argument("--no-sweep", action="store_true",
                     help="skip aux.workloads (the other BASELINE configs) and aux.beyond_llc (the batch-size sweep)")
     ap.add_argument("--event-stride", type=int, default=16,
@@ -374,7 +376,7 @@ def main():
         steady = None if (args.no_steady or args.override) else \
             steady_state(env, task, zones, policy, shard.env_index0, args.mode, pmc, lib_chunk)
         per_step = per_step_rate(env, task, zones, policy, shard.env_index0, args.workload) \
-            if (args.mode == "persistent" and side) else None
+            if (args.mode == "persistent" and side and not args.no_per_step) else None
         mlp = None if (args.no_mlp or not side) else mlp_policy_rate(env, zones)
         host_rt = None if (args.no_mlp or not side) else host_roundtrip_rate(env)
         sweep = side and not args.no_sweep and args.workload == "PointTSP-25" and n_env == 65536 and \

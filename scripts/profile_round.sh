@@ -13,13 +13,13 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python -c 'import __graft_entry__ as g; g.build()' || exit 1
 python bench.py > $out/bench.json 2> $out/bench.err
 tail -c 600 $out/bench.json; echo
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --no-cpu-baseline --no-mlp > $out/stats_bench.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_per_step -- python bench.py --no-cpu-baseline --no-mlp --no-steady --mode per_step --steps 2000 --warmup 2000 > $out/stats_per_step_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --no-cpu-baseline --no-mlp --no-sweep > $out/stats_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_per_step -- python bench.py --no-cpu-baseline --no-mlp --no-steady --no-sweep --mode per_step --steps 2000 --warmup 2000 > $out/stats_per_step_bench.json 2>/dev/null
 echo "stats done"
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 for w in $workloads; do
   for mode in persistent per_step; do
-    common="--workload $w --mode $mode --steps 512 --warmup 256 --no-cpu-baseline --no-kernel-events --no-mlp --no-steady"
+    common="--workload $w --mode $mode --steps 512 --warmup 256 --no-cpu-baseline --no-kernel-events --no-mlp --no-steady --no-sweep --no-per-step"
     [ $mode = per_step ] && common="$common --no-settle"
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_${w}_$mode -- python bench.py $common > /dev/null 2>&1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_${w}_$mode -- python bench.py $common > /dev/null 2>&1
@@ -30,7 +30,7 @@ done
 # the batch-size sweep of aux.beyond_llc: HBM bytes of both kernels AT each size (per-step output 0.6x .. 7x the LLC)
 for n in ${SWEEP_SIZES:-262144 1048576 3145728}; do
   w="PointTSP-25@$n"
-  base="--workload PointTSP-25 --envs-per-gpu $n --bank-maps 262144 --no-settle --no-cpu-baseline --no-kernel-events --no-mlp --no-steady --no-sweep"
+  base="--workload PointTSP-25 --envs-per-gpu $n --bank-maps 262144 --no-settle --no-cpu-baseline --no-kernel-events --no-mlp --no-steady --no-sweep --no-per-step"
   for mode in persistent per_step; do
     [ $mode = persistent ] && common="$base --mode persistent --warmup 128 --steps 512" || common="$base --mode per_step --warmup 16 --steps 64"
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_${w}_$mode -- python bench.py $common > /dev/null 2>&1
