@@ -71,6 +71,7 @@ struct DevParams {
     int64_t *seed;
     // schedule
     int32_t *slot_first, *episode_idx;
+    int32_t *reset_hint;  // [N] bank slot an env may reset into at the next step (-1: none): prefetch hint, not state
     uint64_t *pcg;        // [N][4] state_hi,state_lo,inc_hi,inc_lo
     uint32_t *pcg_buf;    // [N][2] has_u32,u32
     // bank
@@ -78,6 +79,7 @@ struct DevParams {
     const double *bank_zone;    // [S][Z][2]
     const int32_t *bank_aux;    // [S][Z]
     const int64_t *bank_seed;   // [S]
+    const float4 *bank_first;   // [S][3] derived: first obs (8 floats), the greedy policy's first action (2), pad
     // outputs
     float *obs, *zone_obs, *reward, *actions;
     uint8_t *done_out, *goal_met;

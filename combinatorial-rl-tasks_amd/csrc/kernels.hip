@@ -53,9 +53,48 @@ constexpr int kWave = 64;
 // Rows per flush chunk of the 6-float rows (RPC * 6 floats must be whole float4: 2 or 4).  4 halves the number of
 // expand -> slab -> store iterations of a 25-zone tile (13 -> 7), which is what made PointTSP-25 flush slower per byte
 // than TimedTSP-25's 7-float rows.
+// experiment switch (round 3): the zone wave's small per-env stores behind the row flush instead of before the
+// rendezvous -- measured slower (the pointers stay live across the flush: more SGPR spill code), so 0
+#ifndef ZENV_STORES_AFTER_FLUSH
+#define ZENV_STORES_AFTER_FLUSH 0
+#endif
 #ifndef ZENV_RPC6
 #define ZENV_RPC6 4
 #endif
+
+// Every wave of a launch starts by reading the same ~700 bytes of kernel arguments (DevParams by value).  Left to the
+// compiler those reads come as a dozen scalar loads spread through the prologue and the rare branches, re-issued
+// wherever SGPR pressure dropped a value, each followed by its own s_waitcnt: on the zone wave's path to "pose known"
+// that was eight to ten SERIALISED scalar-cache misses at the moment all 2 048 waves of the grid miss on the same
+// lines (round 3 stamps: pose ready 2.3 us after the first wave of the grid started, for 0.4 us in the wave that
+// needs four fields).  This touches every 64-byte line of the argument block at once -- all misses in flight
+// together, one wait -- so that the compiler's own loads behind it are scalar-cache hits.  (The loaded values are
+// thrown away; one asm statement, so the destination registers are dead only after its s_waitcnt.)
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+template <int BYTES>
+__device__ __forceinline__ void warm_kernarg()
+{
+#ifndef ZENV_NO_KERNARG_WARM
+    const auto k = __builtin_amdgcn_kernarg_segment_ptr();   // constant address space: an SGPR pair
+    v16i_t t;
+    static_assert(BYTES <= 12 * 64, "extend the list");
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\t"
+                 "s_load_dwordx16 %0, %1, 0x40\n\t"
+                 "s_load_dwordx16 %0, %1, 0x80\n\t"
+                 "s_load_dwordx16 %0, %1, 0xc0\n\t"
+                 "s_load_dwordx16 %0, %1, 0x100\n\t"
+                 "s_load_dwordx16 %0, %1, 0x140\n\t"
+                 "s_load_dwordx16 %0, %1, 0x180\n\t"
+                 "s_load_dwordx16 %0, %1, 0x1c0\n\t"
+                 "s_load_dwordx16 %0, %1, 0x200\n\t"
+                 "s_load_dwordx16 %0, %1, 0x240\n\t"
+                 "s_load_dwordx16 %0, %1, 0x280\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(t)
+                 : "s"(k)
+                 : "memory");
+#endif
+}
 
 template <int TASK>
 struct TaskTraits {
@@ -309,6 +348,17 @@ struct GlobalRowSink {
         for (int f = 0; f < TaskTraits<TASK>::F; ++f) rows[z * TaskTraits<TASK>::F + f] = r[f];
     }
 };
+
+// Derived bank rows (k_bank_derive): [slot][3] float4 = first obs (8 floats), first greedy action (2 floats), pad.
+template <typename P>
+__device__ __forceinline__ float4 load_bank_first(const P &p, int slot, float *of)
+{
+    const float4 *bf = p.bank_first + 3 * (size_t)slot;     // same address in every lane
+    const float4 f0 = bf[0], f1 = bf[1], f2 = bf[2];
+    of[0] = f0.x; of[1] = f0.y; of[2] = f0.z; of[3] = f0.w;
+    of[4] = f1.x; of[5] = f1.y; of[6] = f1.z; of[7] = f1.w;
+    return f2;
+}
 
 // Engine.reset for one env from bank slot `slot`: writes the zone arrays, the lane's registers
 // and the env's zone rows / entries.
@@ -831,6 +881,7 @@ __global__ __launch_bounds__(kStepThreads) __attribute__((amdgpu_waves_per_eu(2,
 void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset, StepPolicy pol)
 {
     extern __shared__ __align__(16) float4 lds4[];
+    warm_kernarg<sizeof(DevParams) + 8 + 8 + sizeof(StepPolicy)>();
     constexpr int F = TaskTraits<TASK>::F;
     constexpr int G = TaskTraits<TASK>::G;
     constexpr int ZR = ZT > 0 ? ZT : 1;
@@ -849,8 +900,14 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
 
     EnvRegs e;
     e.steps = 0;
+    // zone wave: what its epilogue (behind the flush) stores
+    bool z_valid = false, z_was_done = false, z_need_reset = false;
+    int z_hint = -1, z_first = -1;
+    double z_ep_ret = 0.0;
+    float z_rew = 0.f;
+    uint8_t z_done = 0, z_goal = 0;
     float o[8];   // physics wave: this step's obs
-    int pf[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // zone wave: reset prefetch, one dword per cache line
+    int pf[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };   // physics wave: reset prefetch, one dword per cache line
 
     if (role == 0) {
         // =================================================================== zone wave
@@ -1065,27 +1122,14 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         }
 
         ZSTAMP(6);
-        // ---- reset prefetch, one step ahead.  For the few envs that can terminate at the next
-        // step, request every cache line of their next episode's bank rows now: they are on chip
-        // (L2 / Infinity Cache) when the cooperative reset of the next launch asks for them,
-        // instead of costing it a cold HBM round trip at the end of its critical path.  Nothing
-        // is consumed here; the registers are only kept alive until the end of the wave.
-        if (ends_soon && auto_reset && p.sched_mode != SCHED_FIXED_SEEDS) {
-            const long long sl = seq_slot(p, slot_first, epi_idx);
-            const int *bz = reinterpret_cast<const int *>(p.bank_zone + 2 * (size_t)sl * Z);
-            pf[0] = bz[0];                                   // 128-B lines of the 16*Z-byte zone block
-            if (4 * Z > 32) pf[1] = bz[32];
-            if (4 * Z > 64) pf[2] = bz[64];
-            if (4 * Z > 96) pf[3] = bz[96];
-            pf[4] = bz[4 * Z - 1];
-            pf[5] = reinterpret_cast<const int *>(p.bank_robot + 4 * (size_t)sl)[0];
-            if (TASK != ZENV_TASK_TSP) {
-                const int *ba = p.bank_aux + (size_t)sl * Z;
-                pf[6] = ba[0];
-                pf[7] = ba[Z - 1];
-            }
-            pf[8] = (int)p.bank_seed[sl];
-        }
+        // ---- reset hint, one step ahead.  An env that can terminate at the NEXT step leaves the bank slot of its next
+        // episode behind; the physics wave of the next launch -- whose own loads land first and which then has time to
+        // spare -- touches that slot's cache lines right at its start, so that they are in this XCD's L2 when the
+        // cooperative reset asks for them ~2.5 us later instead of costing it a 1.6 us round trip to HBM at the end
+        // of the launch's critical path (round 3 stamps; a prefetch at the END of the previous launch, as rounds 1-2
+        // had it, only reaches the Infinity Cache: the L2s are invalidated between launches).
+        int hint = -1;
+        if (ends_soon && auto_reset && p.sched_mode != SCHED_FIXED_SEEDS) hint = seq_slot(p, slot_first, epi_idx);
 
         ZSTAMP(15);
         // ---- auto-reset (penv.py:8-11), wave-cooperative: for each finished env of the tile,
@@ -1136,9 +1180,6 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                     const unsigned long long m1 = __ballot(lane < Z && (code & 2));
                     colpack = spread_even_bits((uint32_t)m0) | (spread_even_bits((uint32_t)m1) << 1);
                 }
-                // The fresh episode's state is wave-uniform: every lane builds the first obs and
-                // the wave evaluates the scripted policy together (lane z <-> zone z), so the
-                // reset adds a few hundred ns to this wave instead of a serial Z-long scan.
                 EnvRegs fresh;
                 fresh.x0 = b0; fresh.y0 = b1; fresh.bq0 = b2; fresh.bq3 = b3;
                 fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
@@ -1147,13 +1188,13 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 fresh.colpack = colpack;
                 fresh.goal_dist = (TASK == ZENV_TASK_COLOUR_MATCH) ? hamming_to_goal(colpack, Z) : 0;
                 fresh.steps = 0;
+                // the first obs of the next episode and the greedy policy's first action: derived once per bank row
+                // (k_bank_derive, same arithmetic), so a reset is one round of loads and a handful of stores
                 float of[8];
-                emit_obs8(p, fresh, of);   // the first obs of the next episode
-                float2 next_act = make_float2(0.f, 0.f);
+                const float4 f2 = load_bank_first(p, slot, of);
+                float2 next_act = make_float2(f2.x, f2.y);
                 if (pol.policy == ZENV_POLICY_UNIFORM)
                     next_act = uniform_action(pol.env_index0 + (uint64_t)env_j, pol.step_index, pol.seed);
-                else if (pol.policy == ZENV_POLICY_GREEDY)
-                    next_act = greedy_action_coop<TASK>(lane, Z, en.x, en.y, code, en.w, of[1], of[2], of[3], of[4]);
                 if (lane == j) {
                     e = fresh;
                     ep_ret = 0.0;
@@ -1169,18 +1210,27 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         }
 
         if (valid) {
-            if (!was_done || auto_reset) {
-                p.ep_return[env] = ep_ret;
-                store_counters(p, env, TASK, e);
-                if (was_done) p.done_state[env] = 0;      // revived by the reset above
-            }
             xmode[lane] = mode;
             xstep[lane] = e.steps;
-            if (p.visit_zone) p.visit_zone[env] = first;
-            p.reward[env] = rew_out;
-            p.done_out[env] = done_out;
-            p.goal_met[env] = goal_out;
         }
+        // the env's small per-step results and counters go out BEHIND the row stream (after the rendezvous, below): a
+        // dozen store instructions that nothing waits for no longer sit between the zone pass and the start of the flush
+        z_valid = valid; z_was_done = was_done != 0; z_need_reset = need_reset; z_hint = hint; z_first = first;
+        z_ep_ret = ep_ret; z_rew = rew_out; z_done = done_out; z_goal = goal_out;
+#if !ZENV_STORES_AFTER_FLUSH
+        if (z_valid) {
+            if (!z_was_done || auto_reset) {
+                p.ep_return[env] = z_ep_ret;
+                store_counters(p, env, TASK, e);
+                if (z_was_done) p.done_state[env] = 0;      // revived by the reset
+            }
+            p.reset_hint[env] = z_need_reset ? -1 : z_hint;
+            if (p.visit_zone) p.visit_zone[env] = z_first;
+            p.reward[env] = z_rew;
+            p.done_out[env] = z_done;
+            p.goal_met[env] = z_goal;
+        }
+#endif
         ZSTAMP(2);
     } else {
         // =================================================================== physics wave
@@ -1194,6 +1244,25 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
             }
             const float2 act = reinterpret_cast<const float2 *>(actions)[env];
+            // the previous launch's reset hint (see the zone wave): touch every cache line of that bank slot now
+            const int hint = auto_reset ? p.reset_hint[env] : -1;
+            if (hint >= 0 && hint < p.bank_size) {
+                const int *bz = reinterpret_cast<const int *>(p.bank_zone + 2 * (size_t)hint * Z);
+                pf[0] = bz[0];                                   // 128-B lines of the 16*Z-byte zone block
+                if (4 * Z > 32) pf[1] = bz[32];
+                if (4 * Z > 64) pf[2] = bz[64];
+                if (4 * Z > 96) pf[3] = bz[96];
+                pf[4] = bz[4 * Z - 1];
+                pf[5] = reinterpret_cast<const int *>(p.bank_robot + 4 * (size_t)hint)[0];
+                if (TASK != ZENV_TASK_TSP) {
+                    const int *ba = p.bank_aux + (size_t)hint * Z;
+                    pf[6] = ba[0];
+                    pf[7] = ba[Z - 1];
+                }
+                pf[8] = (int)p.bank_seed[hint];
+                pf[9] = reinterpret_cast<const int *>(p.bank_first + 3 * (size_t)hint)[0];
+                pf[10] = reinterpret_cast<const int *>(p.bank_first + 3 * (size_t)hint)[11];
+            }
             // Engine.step: ctrl = clip(action, ctrlrange); frameskip x mj_step
             const double c0 = det_clamp((double)act.x, -1.0, 1.0);
             const double c1 = det_clamp((double)act.y, -1.0, 1.0);
@@ -1223,8 +1292,20 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 1)   // diagnostic builds only: ZENV_EXP bit 0 drops the flush
         flush_entries<TASK, StorePolicy<ZT * F>::kStep>(ents, stage, p.zone_obs + (size_t)env0 * Z * F, n_blk * Z, lane);
 #endif
-        asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]),
-                     "v"(pf[7]), "v"(pf[8]));
+#if ZENV_STORES_AFTER_FLUSH
+        if (z_valid) {
+            if (!z_was_done || auto_reset) {
+                p.ep_return[env] = z_ep_ret;
+                store_counters(p, env, TASK, e);
+                if (z_was_done) p.done_state[env] = 0;      // revived by the reset
+            }
+            p.reset_hint[env] = z_need_reset ? -1 : z_hint;
+            if (p.visit_zone) p.visit_zone[env] = z_first;
+            p.reward[env] = z_rew;
+            p.done_out[env] = z_done;
+            p.goal_met[env] = z_goal;
+        }
+#endif
         ZSTAMP(3);
     } else if (env < N) {
         if (xmode[lane] == 0) {
@@ -1241,6 +1322,9 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             world_pos(e, tx, ty);           // where the finished episode ended (TSP_next_city_env.py:63-66)
             p.term_xy[env] = make_double2(tx, ty);
         }
+        // (nothing of the prefetch is consumed: the registers are only kept alive until the end of the wave)
+        asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]),
+                     "v"(pf[7]), "v"(pf[8]), "v"(pf[9]), "v"(pf[10]));
         ZSTAMP(13);
     }
 }
@@ -1839,13 +1923,11 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
                 fresh.colpack = colpack;
                 fresh.goal_dist = kColour ? hamming_to_goal(colpack, Z) : 0;
                 fresh.steps = 0;
-                float of[8];
-                emit_obs8(p, fresh, of);   // the first obs of the next episode
-                float2 next_act = make_float2(0.f, 0.f);
+                float of[8];                    // first obs + first greedy action of the episode: derived bank rows
+                const float4 f2 = load_bank_first(pc, slot, of);
+                float2 next_act = make_float2(f2.x, f2.y);
                 if (pol.policy == ZENV_POLICY_UNIFORM)
                     next_act = uniform_action(polt.env_index0 + (uint64_t)env_j, polt.step_index, polt.seed);
-                else if (pol.policy == ZENV_POLICY_GREEDY)
-                    next_act = greedy_action_coop<TASK>(lane, Z, en.x, en.y, code, en.w, of[1], of[2], of[3], of[4]);
                 wave_lds_fence();   // lane j reads back what its neighbours wrote
 #pragma unroll
                 for (int h = 0; h < ZH; ++h) {
@@ -2380,6 +2462,44 @@ __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t
     p.goal_met[env] = 0;
 }
 
+// =========================================================================== bank derive
+// What an episode's first step needs that is a pure function of its bank row: the first observation (ZoneEnvBase.obs
+// of the freshly reset env: qpos = qvel = 0, steps = 0) and the scripted greedy policy's first action.  One wave per
+// bank slot, lane z <-> zone z; computed once when the bank is uploaded or a slot is refilled, with the same device
+// functions the step kernels use, so that the auto-reset inside a step (penv.py:8-11) only copies.
+template <int TASK>
+__global__ __launch_bounds__(kWave) void k_bank_derive(DevParams p, const int32_t *__restrict__ slots)
+{
+    const int lane = threadIdx.x, Z = p.Z;
+    const int slot = slots ? slots[blockIdx.x] : (int)blockIdx.x;
+    const double *br = p.bank_robot + 4 * (size_t)slot;
+    int code = (TASK == ZENV_TASK_COLOUR_MATCH) ? 0 : (int)((p.vis0 >> (lane & 31)) & 1u);
+    float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < Z) {
+        const size_t bi = (size_t)slot * Z + lane;
+        const double2 zz = reinterpret_cast<const double2 *>(p.bank_zone)[bi];
+        int aux = 0;
+        if (TASK == ZENV_TASK_TIMED_TSP) aux = p.bank_aux[bi];
+        if (TASK == ZENV_TASK_COLOUR_MATCH) code = p.bank_aux[bi];
+        en = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
+    }
+    EnvRegs fresh;
+    fresh.x0 = br[0]; fresh.y0 = br[1]; fresh.bq0 = br[2]; fresh.bq3 = br[3];
+    fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
+    fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
+    fresh.vis = 0u; fresh.colpack = 0ull; fresh.goal_dist = 0;
+    fresh.steps = 0;
+    float of[8];
+    emit_obs8(p, fresh, of);
+    const float2 a = greedy_action_coop<TASK>(lane, Z, en.x, en.y, code, en.w, of[1], of[2], of[3], of[4]);
+    if (lane == 0) {
+        float4 *bf = const_cast<float4 *>(p.bank_first) + 3 * (size_t)slot;
+        bf[0] = make_float4(of[0], of[1], of[2], of[3]);
+        bf[1] = make_float4(of[4], of[5], of[6], of[7]);
+        bf[2] = make_float4(a.x, a.y, 0.f, 0.f);
+    }
+}
+
 // =========================================================================== bank update
 // zenv_bank_update: `count` freshly sampled layouts, packed one record per layout in a staging buffer
 // ([robot 4 f64 | zone 2Z f64 | seed i64 | aux Z i32, padded to 8 B]), scattered into the bank slots they belong to.
@@ -2430,6 +2550,17 @@ __global__ __launch_bounds__(kWave) void k_probe_store(float *out, int tile_byte
 }
 
 }  // namespace
+
+hipError_t launch_bank_derive(const DevParams &p, const int32_t *slots, int count, hipStream_t s)
+{
+    const dim3 grid(count), block(kWave);
+    switch (p.task) {
+    case ZENV_TASK_TSP: hipLaunchKernelGGL(k_bank_derive<ZENV_TASK_TSP>, grid, block, 0, s, p, slots); break;
+    case ZENV_TASK_TIMED_TSP: hipLaunchKernelGGL(k_bank_derive<ZENV_TASK_TIMED_TSP>, grid, block, 0, s, p, slots); break;
+    default: hipLaunchKernelGGL(k_bank_derive<ZENV_TASK_COLOUR_MATCH>, grid, block, 0, s, p, slots); break;
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_bank_scatter(const DevParams &p, const int32_t *slots, const void *staging, int rec_bytes, int count,
                                hipStream_t s)

@@ -39,6 +39,8 @@ hipError_t launch_solver_goal(const DevParams &p, int32_t *out, hipStream_t s);
 hipError_t launch_order_reset(const DevParams &p, const uint8_t *mask, hipStream_t s);
 hipError_t launch_order_step(const DevParams &p, hipStream_t s);
 hipError_t launch_policy(const DevParams &p, const StepPolicy &pol, hipStream_t s);
+// first obs + first greedy action of every bank slot (slots == null: all `count` = bank_size slots) -> p.bank_first
+hipError_t launch_bank_derive(const DevParams &p, const int32_t *slots, int count, hipStream_t s);
 // zenv_bank_update: scatter `count` packed layout records (rec_bytes each) into the bank slots slots[count]
 hipError_t launch_bank_scatter(const DevParams &p, const int32_t *slots, const void *staging, int rec_bytes, int count,
                                hipStream_t s);

@@ -72,7 +72,7 @@ struct zenv {
     void *results_slab = nullptr;
     int64_t results_off[ZENV_N_RESULTS] = {};
     int64_t results_bytes = 0;
-    void *bank_mem[4] = { nullptr, nullptr, nullptr, nullptr };
+    void *bank_mem[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // robot, zone, aux, seed, derived first rows
     uint8_t *d_mask = nullptr;
     bool bank_ready = false;
     bool sched_ready = false;
@@ -487,6 +487,7 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
         h->results_bytes = off;
     }
     want(h, p.dbg, 16 * ((N + 63) / 64), false);
+    want(h, p.reset_hint, N, false);       // zero-filled = "slot 0": a prefetch hint only, any value is harmless
 
     hipError_t err = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     h->stream = h->own_stream;
@@ -582,29 +583,31 @@ static int upload_bank(zenv *h, const std::vector<double> &robot4, const std::ve
     // allocate and fill the new bank first; the handle switches to it only when all of it is on the device (a failure
     // half way leaves the old bank -- and bank_ready -- exactly as they were)
     const size_t S = seeds.size();
-    const size_t bytes[4] = { robot4.size() * sizeof(double), zone.size() * sizeof(double), aux.size() * sizeof(int32_t),
-                              S * sizeof(int64_t) };
-    const void *src[4] = { robot4.data(), zone.data(), aux.data(), seeds.data() };
-    void *fresh[4] = { nullptr, nullptr, nullptr, nullptr };
+    const size_t bytes[5] = { robot4.size() * sizeof(double), zone.size() * sizeof(double), aux.size() * sizeof(int32_t),
+                              S * sizeof(int64_t), S * 3 * sizeof(float4) };
+    const void *src[5] = { robot4.data(), zone.data(), aux.data(), seeds.data(), nullptr };
+    void *fresh[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     hipError_t err = hipSuccess;
-    for (int i = 0; i < 4 && err == hipSuccess; ++i) {
+    for (int i = 0; i < 5 && err == hipSuccess; ++i) {
         err = hipMalloc(&fresh[i], bytes[i]);
-        if (err == hipSuccess) err = hipMemcpy(fresh[i], src[i], bytes[i], hipMemcpyHostToDevice);
+        if (err == hipSuccess && src[i]) err = hipMemcpy(fresh[i], src[i], bytes[i], hipMemcpyHostToDevice);
     }
     if (err != hipSuccess) {
         for (void *m : fresh)
             if (m) (void)hipFree(m);
         return fail(ZENV_E_HIP, "uploading the layout bank: %s", hipGetErrorString(err));
     }
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         if (h->bank_mem[i]) (void)hipFree(h->bank_mem[i]);
         h->bank_mem[i] = fresh[i];
     }
+    h->p.bank_first = static_cast<const float4 *>(h->bank_mem[4]);
     h->p.bank_robot = static_cast<const double *>(h->bank_mem[0]);
     h->p.bank_zone = static_cast<const double *>(h->bank_mem[1]);
     h->p.bank_aux = static_cast<const int32_t *>(h->bank_mem[2]);
     h->p.bank_seed = static_cast<const int64_t *>(h->bank_mem[3]);
     h->p.bank_size = static_cast<int32_t>(S);
+    HIP_TRY(launch_bank_derive(h->p, nullptr, (int)S, h->stream));     // first obs + first greedy action per slot
     h->bank_ready = true;
     if (h->p.sched_mode == SCHED_FIXED_SEEDS && h->p.seed_max - h->p.seed_min + 1 != (int64_t)S)
         h->sched_ready = false;  // that schedule draws slots of the bank it was made for: the next reset starts a default one
@@ -716,6 +719,7 @@ extern "C" int zenv_bank_update(zenv_t *h, const int32_t *slots, const int64_t *
     const char *db = static_cast<const char *>(h->refill_dev);
     HIP_TRY(launch_bank_scatter(h->p, reinterpret_cast<const int32_t *>(db + (size_t)count * rec), db, (int)rec, count,
                                 h->stream));
+    HIP_TRY(launch_bank_derive(h->p, reinterpret_cast<const int32_t *>(db + (size_t)count * rec), count, h->stream));
     if (!h->refill_done) HIP_TRY(hipEventCreateWithFlags(&h->refill_done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(h->refill_done, h->stream));
     h->refill_busy = true;
@@ -795,7 +799,7 @@ extern "C" int zenv_schedule_sequential(zenv_t *h, const int32_t *first, int32_t
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(h->p.slot_first, f.data(), f.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(h->p.episode_idx, 0, h->n_env * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(h->p.episode_idx, 0, h->n_env * sizeof(int32_t), h->stream));   // on the handle's stream: the null stream does not order with it
     h->p.sched_mode = SCHED_SEQUENTIAL;
     h->p.sched_stride = stride % S;
     h->sched_ready = true;
@@ -815,7 +819,7 @@ extern "C" int zenv_schedule_ring(zenv_t *h, const int32_t *first, int32_t depth
             return fail(ZENV_E_ARG, "ring of env %d, slots [%d, %d), leaves the bank [0,%d)", i, first[i], first[i] + depth, S);
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(h->p.slot_first, first, (size_t)h->n_env * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(h->p.episode_idx, 0, h->n_env * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(h->p.episode_idx, 0, h->n_env * sizeof(int32_t), h->stream));   // on the handle's stream: the null stream does not order with it
     h->p.sched_mode = SCHED_RING;
     h->p.sched_stride = depth;
     h->sched_ready = true;
@@ -840,8 +844,8 @@ extern "C" int zenv_schedule_fixed_seeds(zenv_t *h, const uint64_t *rng_seeds, i
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(h->p.pcg, st.data(), st.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(h->p.pcg_buf, 0, 2 * (size_t)h->n_env * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(h->p.episode_idx, 0, h->n_env * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(h->p.pcg_buf, 0, 2 * (size_t)h->n_env * sizeof(uint32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->p.episode_idx, 0, h->n_env * sizeof(int32_t), h->stream));   // on the handle's stream: the null stream does not order with it
     h->p.sched_mode = SCHED_FIXED_SEEDS;
     h->p.seed_min = min_seed;
     h->p.seed_max = max_seed;
@@ -1609,7 +1613,7 @@ extern "C" int zenv_debug_stamps(zenv_t *h, unsigned long long *dst, int64_t cou
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(dst, h->p.dbg, have * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(h->p.dbg, 0, have * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(h->p.dbg, 0, have * sizeof(unsigned long long), h->stream));
     return ZENV_OK;
 }
 

@@ -1,28 +1,28 @@
-"""Diagnostic: which arrays of the state blob differ between two rollout modes (auto-reset on)?"""
+"""Diagnostic: which per-env fields / state arrays differ between two rollout modes (auto-reset on)?
+usage: python scripts/diff_modes.py [modeA modeB] [n=65536] [task=1] [zones=25] [steps=150]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import combinatorial_rl_tasks_amd as Z
-n = 4096
-Zn, F, ZH = 25, 7, 13
-cfg = Z.default_config(1, Zn, zones_keepout=0.40)
-modes = sys.argv[1:3] if len(sys.argv) > 2 else ("persistent", "unfused")
-blobs = []
-for mode in modes:
-    env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n); env.reset()
-    env.rollout(150, Z.POLICY_GREEDY, mode=mode)
-    blobs.append(np.frombuffer(env.get_state(), np.uint8).copy()); env.close()
-a, b = blobs
-d = np.nonzero(a != b)[0]
-print(modes, "blob bytes", a.size, "differing", d.size)
-sizes = [("qa",16),("qb",16),("qc",16),("fa",16),("fb",16),("zxy",16*Zn),("zpf",16*ZH),("vis",4),("tmax",4*Zn),("colpack",8),
- ("cooldown",Zn),("goal_dist",4),("steps",4),("done_state",1),("ep_return",8),("last_return",8),("last_len",4),("episodes",4),
- ("visit_count",4),("seed",8),("slot_first",4),("episode_idx",4),("pcg",32),("pcg_buf",8),("obs",32),("zone_obs",4*Zn*F),
- ("reward",4),("actions",8),("done_out",1),("goal_met",1)]
-off = 16
-for name, per in sizes:
-    sz = per * n
-    k = ((d >= off) & (d < off + sz)).sum()
-    if k: print(name, "differs in", k, "bytes")
-    off += sz
-print("end offset", off, "(blob", a.size, ")")
+kw = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+modes = [a for a in sys.argv[1:] if "=" not in a] or ["persistent", "per_step"]
+n, task, Zn, steps = int(kw.get("n", 65536)), int(kw.get("task", 1)), int(kw.get("zones", 25)), int(kw.get("steps", 150))
+cfg = Z.default_config(task, Zn, zones_keepout=0.40 if Zn > 15 else 0.55)
+fields = {k: getattr(Z, k) for k in ("F_OBS", "F_ZONE_OBS", "F_REWARD", "F_DONE", "F_GOAL_MET", "F_EP_RETURN", "F_EP_LEN",
+                                      "F_LAST_RETURN", "F_LAST_LEN", "F_EPISODES", "F_VISIT_COUNT", "F_SEED", "F_ACTIONS")}
+runs = []
+for mode in modes[:2]:
+    env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n, n_threads=16); env.reset()
+    env.rollout(steps, Z.POLICY_GREEDY, mode=mode)
+    got = {k: env.get(f) for k, f in fields.items()}
+    got.update({"dbg_" + k: v for k, v in env.debug_state().items()})
+    got["blob"] = np.frombuffer(env.get_state(), np.uint8).copy()
+    runs.append(got); env.close()
+a, b = runs
+for k in a:
+    if not np.array_equal(a[k], b[k], equal_nan=True):
+        bad = np.flatnonzero((a[k] != b[k]).reshape(len(a[k]), -1).any(1)) if k != "blob" else np.flatnonzero(a[k] != b[k])
+        print(k, "differs at", bad.size, "envs/bytes; first", bad[:8], "episodes there", a["F_EPISODES"][bad[:8]] if k != "blob" else "")
+        if k == "F_ACTIONS":
+            print("  ", a[k][bad[:4]], b[k][bad[:4]], "ep_len", a["F_EP_LEN"][bad[:4]])
+print(modes, "n", n, "compared", len(a), "arrays")

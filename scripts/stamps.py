@@ -8,9 +8,10 @@ import combinatorial_rl_tasks_amd.build as B
 if B.under_profiler():
     raise SystemExit("this script compiles a variant library: run it without rocprofv3, or build the variant first "
                      "(scripts/build_variant.py) and profile a script that loads it through ZENV_LIB_PATH")
-so = os.path.join(ROOT, "gpurun_out", "libzenv_stamps.so")
+so = os.path.join(B.LIB_DIR, "variants", "libzenv_stamps.so")      # travels to the GPU box when built here (cross-compiled)
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.run([B._hipcc()] + B.FLAGS + ["-DZENV_STAMPS"] + os.environ.get("ZENV_EXTRA_FLAGS", "").split() + ["-o", so] + [os.path.join(B.CSRC, s) for s in B.SOURCES], check=True)
+if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(os.path.join(B.CSRC, f)) for f in os.listdir(B.CSRC)):
+    subprocess.run([B._hipcc()] + B.FLAGS + ["-DZENV_STAMPS"] + os.environ.get("ZENV_EXTRA_FLAGS", "").split() + ["-o", so] + [os.path.join(B.CSRC, s) for s in B.SOURCES], check=True)
 import combinatorial_rl_tasks_amd._native as nat
 nat.LIB_PATH = so
 import combinatorial_rl_tasks_amd as Z
@@ -21,11 +22,13 @@ cfg = Z.default_config(task, zones, zones_keepout=keep)
 env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n); env.reset()
 warm = int([a for a in sys.argv if a.startswith('warm=')][0][5:]) if any(a.startswith('warm=') for a in sys.argv) else 30
 env.build_bank_seeds(np.concatenate([1 + np.arange(n) + k * n for k in range(3)])); env.schedule_sequential(first=np.arange(n, dtype=np.int32), stride=n); env.reset()
-env.rollout(warm, Z.POLICY_GREEDY, fused=fused)
+mode = "per_step" if fused else "unfused"      # K1 either way: with its fused action source, or behind a K3 launch
+env.rollout(warm, Z.POLICY_GREEDY, mode=mode)
 L = nat.lib(); L.zenv_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
-acc = []
+acc, kus = [], []
 for it in range(20):
-    env.rollout(1, Z.POLICY_GREEDY, fused=fused)
+    _, k_ms = env.rollout(1, Z.POLICY_GREEDY, mode=mode, time_step_kernel=True)
+    kus.append(k_ms * 1e3)
     buf = np.zeros((n // 64, 16), np.uint64)
     nat.check(L.zenv_debug_stamps(env._h, buf.ctypes.data, buf.size))
     acc.append(buf.astype(np.int64))
@@ -37,6 +40,9 @@ names = {0: "Z start", 1: "Z pose ready", 14: "Z zone loop done", 6: "Z finalize
          12: "P obs8 stored", 13: "P end"}
 print(sys.argv[1:], "fused" if fused else "unfused", "episodes so far", int(env.get(Z.F_EPISODES).sum()))
 ends = np.maximum(rel[:, :, 3], rel[:, :, 13])
+span = (a[:, :, [2, 3, 4, 10, 11, 12, 13]].max(axis=(1, 2)) - a[:, :, [0, 8]].min(axis=(1, 2))) * 0.01
+print("dispatch (begin/end events) median %.2f us | first stamp -> last stamp median %.2f us | difference (launch ramp before the "
+      "first wave + drain after the last) %.2f us" % (np.median(kus), np.median(span), np.median(np.array(kus) - span)))
 print("block end: median %.2f p90 %.2f p99 %.2f max %.2f" % (np.median(ends), np.percentile(ends, 90), np.percentile(ends, 99), ends.max()))
 slow = ends > np.percentile(ends, 99)
 rs = a[:, :, 5] > 0
