@@ -55,6 +55,7 @@ WORKLOADS = {
 
 SETTLE_STEPS = 6000     # untimed steps (settle + warmup) before the timed region, ~40 ms of GPU time
 EPISODES_PER_ENV = 4    # depth of the map bank per env; the schedule wraps around it (the oracle too)
+DEFAULT_SLICE = 65536   # envs per persistent launch (zenv_set_rollout_slice's default): one env wave per SIMD
 BEYOND_LLC_SIZES = (262144, 1048576, 3145728)   # 160 MB, 640 MB, 1.9 GB of outputs per step (LLC = 268 MB)
 BEYOND_LLC_BANK = 262144                        # maps of the sweep: env i replays map 1 + (i mod this)
 
@@ -188,6 +189,9 @@ def main():
                     help="0 (default): env g plays map seeds 1+g, 1+g+G, ... from a 4-episode-deep bank.  M > 0: env i "
                          "replays map 1 + (i mod M) in every episode -- the batch-size sweep's setting, where a bank of "
                          "4 x 3 M layouts would only cost host time")
+    ap.add_argument("--rollout-slice", type=int, default=None,
+                    help="envs one persistent launch covers (zenv_set_rollout_slice; library default 65536, 0 = the whole "
+                         "batch in one launch -- the setting in which every step's outputs really stream to HBM)")
     ap.add_argument("--workload", default="PointTSP-25", choices=sorted(WORKLOADS))
     ap.add_argument("--policy", default="greedy", choices=["greedy", "uniform"])
     ap.add_argument("--override", action="append", default=[],
@@ -265,6 +269,9 @@ def main():
 
     # env g (global index) plays map seeds 1+g, 1+g+G, 1+g+2G, ... (G = global env count)
     env = Z.ZoneVecEnv(cfg, n_env, device=local_rank)
+    slice_envs = DEFAULT_SLICE if args.rollout_slice is None else args.rollout_slice
+    if args.rollout_slice is not None:
+        env.set_rollout_slice(args.rollout_slice)
     rdzv = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -357,7 +364,7 @@ def main():
                 k_step_s = ms_kernel / 1e3
             else:
                 k_step_s = loop_s
-            roofline = roofline_block(task, zones, n_env, k_step_s, chunk if persistent else 1, persistent, pmc)
+            roofline = roofline_block(task, zones, n_env, k_step_s, chunk if persistent else 1, persistent, pmc, slice_envs)
             roofline.update({
                 "kernel_launches_timed": n_launches if not args.unfused else
                 (args.steps + args.event_stride - 1) // args.event_stride,
@@ -374,7 +381,7 @@ def main():
                                  args.settle + args.warmup + args.steps, policy, spot_period)
         side = not distributed and not args.override
         steady = None if (args.no_steady or args.override) else \
-            steady_state(env, task, zones, policy, shard.env_index0, args.mode, pmc, lib_chunk)
+            steady_state(env, task, zones, policy, shard.env_index0, args.mode, pmc, lib_chunk, slice_envs=slice_envs)
         per_step = per_step_rate(env, task, zones, policy, shard.env_index0, args.workload) \
             if (args.mode == "persistent" and side and not args.no_per_step) else None
         mlp = None if (args.no_mlp or not side) else mlp_policy_rate(env, zones)
@@ -401,7 +408,8 @@ def main():
                 b = big[-1]
                 roofline["frac_hbm_resident"] = b["persistent"]["frac"]
                 roofline["hbm_resident_case"] = {
-                    "n_env": b["n_env"], "output_bytes_per_step": b["persistent"]["output_bytes_per_step"],
+                    "n_env": b["n_env"], "launch": "one launch over the whole batch (rollout slice 0)",
+                    "output_bytes_per_step": b["persistent"]["output_bytes_per_step"],
                     "achieved": b["persistent"]["achieved"], "kernel_us_per_step": b["persistent"]["kernel_us_per_step"],
                     "us_per_65536_envs": b["persistent"].get("us_per_65536_envs"), "traffic": b["persistent"]["traffic"],
                     "store_stream_GBps": (b.get("store_stream") or {}).get("best_GBps")}
@@ -418,7 +426,8 @@ def main():
             "config": {"workload": f"{args.workload}, N_env={n_env} per GPU, num_steps=2000, "
                                    f"zones_keepout={keepout}, policy=pi_{args.policy} (on-device, "
                                    f"launch mode {args.mode}), auto-reset on" +
-                                   (f", env i replays map 1 + (i mod {args.bank_maps})" if args.bank_maps else "") + tag,
+                                   (f", env i replays map 1 + (i mod {args.bank_maps})" if args.bank_maps else "") +
+                                   (f", rollout slice {args.rollout_slice}" if args.rollout_slice is not None else "") + tag,
                        "n_env_total": world * n_env, "zones": zones,
                        "parallelism": f"env-shard x{world}, all-gather(ep_return) after rollout"},
             "roofline": roofline,
@@ -456,10 +465,10 @@ def compact(b):
     return None if not isinstance(b, dict) else {
         k: b.get(k) for k in ("kernel", "steps_per_launch", "kernel_us_per_step", "kernel_avg_us", "achieved",
                               "frac", "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch",
-                              "traffic", "llc_resident", "steps", "launches", "env_steps_per_s")}
+                              "traffic", "llc_resident", "envs_per_launch", "steps", "launches", "env_steps_per_s")}
 
 
-def roofline_block(task, zones, n_env, k_step_s, steps_per_launch, persistent, pmc):
+def roofline_block(task, zones, n_env, k_step_s, steps_per_launch, persistent, pmc, envs_per_launch=None):
     """`roofline` of the bench line for a kernel that takes k_step_s per step in launches of steps_per_launch.
 
     Two byte bases, both algorithmic: `outputs_only` -- what a launch of K steps must move when the
@@ -475,6 +484,10 @@ def roofline_block(task, zones, n_env, k_step_s, steps_per_launch, persistent, p
     achieved1 = alg1 * n_env / k_step_s / 1e9
     traffic = traffic_for_launch(pmc, steps_per_launch)
     out_bytes = output_bytes_per_step(task, zones, n_env)
+    # what is rewritten in place while a launch runs: the outputs of the envs ONE launch covers (a persistent launch
+    # covers a slice of the batch, a per-step launch all of it -- but then every step is a new launch over everything)
+    per_launch = n_env if (not persistent or not envs_per_launch) else min(n_env, envs_per_launch)
+    launch_out_bytes = output_bytes_per_step(task, zones, per_launch) if persistent else out_bytes
     return {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -482,7 +495,8 @@ def roofline_block(task, zones, n_env, k_step_s, steps_per_launch, persistent, p
         "traffic_note": (None if traffic is None else
                          f"committed PMC bytes (FETCH_SIZE x2 + WRITE_SIZE) scaled to this launch of "
                          f"{steps_per_launch} step(s); {pmc.get('source')}"),
-        "llc_resident": bool(out_bytes <= LLC_BYTES), "output_bytes_per_step": int(out_bytes), "llc_bytes": LLC_BYTES,
+        "llc_resident": bool(launch_out_bytes <= LLC_BYTES), "output_bytes_per_step": int(out_bytes),
+        "envs_per_launch": int(per_launch), "output_bytes_per_step_per_launch": int(launch_out_bytes), "llc_bytes": LLC_BYTES,
         "kernel": "k_rollout_lane" if persistent else "k_step_lane",
         "kernel_avg_us": round(k_step_s * 1e6 * steps_per_launch, 2),
         "steps_per_launch": steps_per_launch,
@@ -526,7 +540,8 @@ def store_stream_ceiling(Z, task, zones, n_env, device, steps=64):
         return f"error: {ex}"
 
 
-def steady_state(env, task, zones, policy, env_index0, mode, pmc, lib_chunk, steps=8192, settle=SETTLE_STEPS):
+def steady_state(env, task, zones, policy, env_index0, mode, pmc, lib_chunk, steps=8192, settle=SETTLE_STEPS,
+                 slice_envs=DEFAULT_SLICE):
     """Side measurement (never `value`): the SAME kernel, same envs, right after the timed region, over enough
     steps that launch overheads and the clock transient are out of the picture -- every dispatch timed with its
     own begin/end HIP events.  This is the figure to compare rounds by."""
@@ -537,8 +552,9 @@ def steady_state(env, task, zones, policy, env_index0, mode, pmc, lib_chunk, ste
                                time_step_kernel=persistent)
         chunk = min(lib_chunk, steps) if persistent else 1
         k_step_s = (ms_k if persistent else ms / steps) / 1e3
-        blk = roofline_block(task, zones, env.num_envs, k_step_s, chunk, persistent, pmc)
-        blk.update({"steps": steps, "launches": (steps + chunk - 1) // chunk,
+        blk = roofline_block(task, zones, env.num_envs, k_step_s, chunk, persistent, pmc, slice_envs)
+        n_slices = 1 if (not persistent or not slice_envs) else -(-env.num_envs // slice_envs)
+        blk.update({"steps": steps, "launches": n_slices * ((steps + chunk - 1) // chunk),
                     "env_steps_per_s": round(env.num_envs * steps / (ms * 1e-3), 1),
                     "loop_us_per_step": round(ms / steps * 1e3, 3)})
         return blk
@@ -634,7 +650,10 @@ def beyond_llc(Z, policy, lib_chunk, device, sizes=BEYOND_LLC_SIZES):
     Infinity Cache -- nothing a step writes is still on chip when the next step rewrites it, so the stores do reach
     HBM.  Per size: the persistent kernel (512 steps, every dispatch timed) and the per-step kernel, each with the
     committed PMC bytes of THAT size (profiles/traffic.json, `PointTSP-25@N`), the bare store stream of the same
-    footprint on this box, and the oracle spot check.  env i replays map 1 + (i mod 262144)."""
+    footprint on this box, and the oracle spot check.  env i replays map 1 + (i mod 262144).
+    `persistent` is ONE launch over the whole batch (zenv_set_rollout_slice 0): the HBM-streaming case the PMC bytes
+    belong to; `persistent_sliced` is the library's default for such a batch -- launches over 65 536 envs each, whose
+    outputs stay in the Infinity Cache while they are rewritten."""
     task, zones, keepout = WORKLOADS["PointTSP-25"]
     out = []
     for n in sizes:
@@ -645,15 +664,19 @@ def beyond_llc(Z, policy, lib_chunk, device, sizes=BEYOND_LLC_SIZES):
             env.reset()
             scale = n / 65536.0
             settle = max(64, int(SETTLE_STEPS / scale))
+            env.set_rollout_slice(0)           # ONE launch over the whole batch: every step's outputs stream to HBM
             steady = steady_state(env, task, zones, policy, 0, "persistent", load_pmc("PointTSP-25", n, "persistent"),
-                                  lib_chunk, steps=512, settle=settle)
+                                  lib_chunk, steps=512, settle=settle, slice_envs=0)
+            env.set_rollout_slice(DEFAULT_SLICE)   # the library's default: slices of 65 536 envs (a slice's outputs stay on chip)
+            sliced = steady_state(env, task, zones, policy, 0, "persistent", None, lib_chunk, steps=512, settle=64,
+                                  slice_envs=DEFAULT_SLICE)
             per = per_step_rate(env, task, zones, policy, 0, "PointTSP-25", steps=200, warm=50)
-            total = settle + 512 + 50 + 200
+            total = settle + 512 + 64 + 512 + 50 + 200
             spot = parity_spot_check(env, cfg, seeds, stride, 0, total, policy, period)
             env.close()
             ent = {"n_env": n, "parity_spot_check": spot, "steps_checked": total,
                    "store_stream": store_stream_ceiling(Z, task, zones, n, device)}
-            for key, blk in (("persistent", steady), ("per_step", per)):
+            for key, blk in (("persistent", steady), ("persistent_sliced", sliced), ("per_step", per)):
                 if isinstance(blk, dict):
                     c = compact(blk)
                     c["output_bytes_per_step"] = blk["output_bytes_per_step"]

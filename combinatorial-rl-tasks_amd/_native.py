@@ -108,6 +108,7 @@ _PROTOTYPES = {
     "zenv_policy": (C.c_int, [_H, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "zenv_rollout": (C.c_int, [_H, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "zenv_set_rollout_slice": (C.c_int, [_H, C.c_int]),
     "zenv_collect": (C.c_int, [_H, C.c_int, C.c_uint64, C.c_uint64, C.c_float, C.c_float]),
     "zenv_order_enable": (C.c_int, [_H]),
     "zenv_route_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

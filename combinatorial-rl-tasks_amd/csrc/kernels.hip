@@ -1399,22 +1399,30 @@ template <int ZT> struct RowDiv {
 // its static entry + the env's per-step word; same values as make_entry() + expand_entry().
 // MAY_ZERO = false: the env wave has told the stream wave that no env of the tile is frozen this
 // step (always the case with auto-reset on), so the all-zero-row selects drop out.
+// ColourMatch rows in the persistent kernel: the colour's (R, G, B, A) and the cooldown feature cd / max_cd take a
+// handful of values, so the stream wave looks them up in two small LDS tables filled once per launch with the same
+// expressions (rt.col[colour 0..2, 3 = all-zero row], rt.cd[0..255]) instead of re-deriving them for every row of every
+// step (three compare-select pairs and a three-instruction float64 division per row: ~100 of the stream wave's ~200
+// vector instructions per step at Z = 6).
+struct RowTables {
+    const float4 *col;
+    const float *cd;
+};
 template <int TASK, int ZT, bool MAY_ZERO>
 __device__ __forceinline__ void expand_row(const DevParams &p, const typename StaticEnt<TASK>::type s, uint64_t d,
-                                           const uint8_t *cd_env, int z, float *row)
+                                           const uint8_t *cd_env, int z, float *row, const RowTables &rt)
 {
     const bool zero = MAY_ZERO && (d & kDynZero) != 0ull;
     row[0] = zero ? 0.f : s.x;
     row[1] = zero ? 0.f : s.y;
-    row[5] = zero ? 0.f : 0.25f;
     if constexpr (TASK == ZENV_TASK_COLOUR_MATCH) {
         const int col = zero ? 3 : (int)((d >> (2 * z)) & 3ull);
-        row[2] = col == 2 ? 1.f : 0.f;
-        row[3] = col == 1 ? 1.f : 0.f;
-        row[4] = col == 0 ? 1.f : 0.f;
+        const float4 c = rt.col[col];
+        row[2] = c.x; row[3] = c.y; row[4] = c.z; row[5] = c.w;
         const int cd = zero ? 0 : (int)cd_env[z];
-        row[6] = (float)div_const((double)(float)cd, p.d_maxcd, p.inv_maxcd);
+        row[6] = rt.cd[cd];
     } else {
+        row[5] = zero ? 0.f : 0.25f;
         const bool vis = (((uint32_t)d >> z) & 1u) != 0u;
         row[2] = vis ? 1.f : 0.f;
         row[3] = zero ? 0.f : 1.f;
@@ -1432,7 +1440,7 @@ __device__ __forceinline__ void expand_row(const DevParams &p, const typename St
 template <int TASK, int ZT, bool MAY_ZERO>
 __device__ __forceinline__ void flush_static(const DevParams &p, const typename StaticEnt<TASK>::type *sent,
                                              const uint64_t *dynw, const uint8_t *cdb, float4 *stage, float *dst,
-                                             int n_rows, int lane)
+                                             int n_rows, int lane, const RowTables &rt)
 {
     constexpr int F = TaskTraits<TASK>::F, RPC = TaskTraits<TASK>::RPC, G = TaskTraits<TASK>::G;
     constexpr int ZB = (ZT + 3) & ~3;
@@ -1445,7 +1453,7 @@ __device__ __forceinline__ void flush_static(const DevParams &p, const typename 
         for (int j = 0; j < RPC; ++j) {
             const int r = c * RPC + j;
             const int el = RowDiv<ZT>::div(r);
-            expand_row<TASK, ZT, MAY_ZERO>(p, sent[r], dynw[el], cdb + el * ZB, r - el * ZT, v + j * F);
+            expand_row<TASK, ZT, MAY_ZERO>(p, sent[r], dynw[el], cdb + el * ZB, r - el * ZT, v + j * F, rt);
         }
     };
     // Full iterations (64 chunks = 64*G float4 each), software-pipelined: while the staged rows of
@@ -1499,7 +1507,7 @@ __device__ __forceinline__ void flush_static(const DevParams &p, const typename 
     if (r < n_rows) {
         float v[F];
         const int el = RowDiv<ZT>::div(r);
-        expand_row<TASK, ZT, MAY_ZERO>(p, sent[r], dynw[el], cdb + el * ZB, r - el * ZT, v);
+        expand_row<TASK, ZT, MAY_ZERO>(p, sent[r], dynw[el], cdb + el * ZB, r - el * ZT, v, rt);
         for (int f = 0; f < F; ++f) dst[(size_t)r * F + f] = v[f];
     }
 }
@@ -1602,7 +1610,7 @@ __device__ __forceinline__ float2 greedy_action_regs(const float4 *zp, const int
 
 template <int TASK, int ZT>
 __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
+void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, int tile0)
 {
     static_assert(ZT > 0 && ZT <= 30, "zone arrays live in registers; bit 31 / 63 of the step word are flags");
     using SE = typename StaticEnt<TASK>::type;
@@ -1625,7 +1633,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
 #endif
     const int lane = threadIdx.x & (kWave - 1);
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
-    const int env0 = blockIdx.x * kWave;
+    const int env0 = ((int)blockIdx.x + tile0) * kWave;   // tile0: first tile of this launch's slice of the batch
     const int env = env0 + lane;
     const int N = p.N;
     const bool valid = env < N;
@@ -1635,6 +1643,17 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
     uint32_t *cdw = reinterpret_cast<uint32_t *>(dynw + 2 * kWave);      // [2][64][ZB/4] cooldown bytes
     // [0] published, [1] flushed, [2 + b] "step word buffer b holds an all-zero env"
     int *ctr = reinterpret_cast<int *>(cdw + (kColour ? 2 * kWave * (ZB / 4) : 0));
+    float4 *coltab = reinterpret_cast<float4 *>(ctr + 4);               // ColourMatch: [4] (R, G, B, A) by colour code
+    float *cdtab = reinterpret_cast<float *>(coltab + 4);                // ColourMatch: [256] cooldown / max_cd
+    const RowTables rt{ coltab, cdtab };
+    if (kColour) {                                                       // both waves fill, before the launch's barrier
+        for (int i = threadIdx.x; i < 256; i += 2 * kWave)
+            cdtab[i] = (float)div_const((double)(float)i, p.d_maxcd, p.inv_maxcd);
+        if (threadIdx.x < 4) {
+            const int c = threadIdx.x;                                   // 0 Blue, 1 Green, 2 Red, 3 = an all-zero row
+            coltab[c] = make_float4(c == 2 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, c == 0 ? 1.f : 0.f, c == 3 ? 0.f : 0.25f);
+        }
+    }
     const uint32_t full = (1u << Z) - 1u;
     const int n_blk = min(kWave, N - env0);
     const int n_rows = n_blk * Z;
@@ -1652,9 +1671,9 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol)
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 1)   // diagnostic builds only: ZENV_EXP bit 0 drops the flush
             const uint8_t *cdb = reinterpret_cast<const uint8_t *>(cdw + b * kWave * (ZB / 4));
             if (__builtin_amdgcn_readfirstlane(*(lds_vint *)(ctr + 2 + b)))   // some env of the tile is frozen
-                flush_static<TASK, ZT, true>(p, sent, dynw + b * kWave, cdb, stage, tile_dst, n_rows, lane);
+                flush_static<TASK, ZT, true>(p, sent, dynw + b * kWave, cdb, stage, tile_dst, n_rows, lane, rt);
             else
-                flush_static<TASK, ZT, false>(p, sent, dynw + b * kWave, cdb, stage, tile_dst, n_rows, lane);
+                flush_static<TASK, ZT, false>(p, sent, dynw + b * kWave, cdb, stage, tile_dst, n_rows, lane, rt);
 #endif
             lds_ctr_set(ctr + 1, t + 1);                  // flushed(t)
             if (t == (n_steps >> 1) - 1) ZSTAMP(11);
@@ -2655,7 +2674,8 @@ static inline size_t rollout_lds_bytes(const DevParams &p)
     return (size_t)kWave * p.Z * ent + (size_t)kWave * G * sizeof(float4)         // static entries, flush slab
            + 2 * kWave * sizeof(uint64_t)                                          // per-step words
            + (p.task == ZENV_TASK_COLOUR_MATCH ? 2 * (size_t)kWave * ZB : 0)       // cooldown bytes
-           + 4 * sizeof(int);                                                      // counters
+           + 4 * sizeof(int)                                                       // counters
+           + (p.task == ZENV_TASK_COLOUR_MATCH ? 4 * sizeof(float4) + 256 * sizeof(float) : 0);   // row tables
 }
 
 bool rollout_kernel_available(const DevParams &p)
@@ -2665,13 +2685,13 @@ bool rollout_kernel_available(const DevParams &p)
 
 template <int TASK>
 static void launch_rollout_task(const DevParams &p, int n_steps, int auto_reset, const StepPolicy &pol, hipStream_t s,
-                                hipEvent_t ev_start, hipEvent_t ev_stop)
+                                hipEvent_t ev_start, hipEvent_t ev_stop, int tile0, int n_tiles)
 {
-    const dim3 grid(n_blocks(p.N)), block(2 * kWave);
+    const dim3 grid(n_tiles), block(2 * kWave);
     const size_t lds = rollout_lds_bytes(p);
 #define ZENV_LAUNCH(ZT)                                                                                       \
     hipExtLaunchKernelGGL((k_rollout_lane<TASK, ZT>), grid, block, lds, s, ev_start, ev_stop, 0, p, n_steps, \
-                          auto_reset, pol)
+                          auto_reset, pol, tile0)
     switch (p.Z) {
     case 5: ZENV_LAUNCH(5); break;
     case 6: ZENV_LAUNCH(6); break;
@@ -2683,14 +2703,18 @@ static void launch_rollout_task(const DevParams &p, int n_steps, int auto_reset,
 #undef ZENV_LAUNCH
 }
 
+int rollout_tiles(const DevParams &p) { return n_blocks(p.N); }
+
 hipError_t launch_rollout(const DevParams &p, int n_steps, int auto_reset, const StepPolicy &pol, hipStream_t s,
-                          hipEvent_t ev_start, hipEvent_t ev_stop)
+                          hipEvent_t ev_start, hipEvent_t ev_stop, int tile0, int n_tiles)
 {
     if (!rollout_kernel_available(p)) return hipErrorInvalidValue;
+    if (n_tiles < 0) n_tiles = n_blocks(p.N) - tile0;
+    if (tile0 < 0 || n_tiles < 1 || tile0 + n_tiles > n_blocks(p.N)) return hipErrorInvalidValue;
     switch (p.task) {
-    case ZENV_TASK_TSP: launch_rollout_task<ZENV_TASK_TSP>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop); break;
-    case ZENV_TASK_TIMED_TSP: launch_rollout_task<ZENV_TASK_TIMED_TSP>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop); break;
-    default: launch_rollout_task<ZENV_TASK_COLOUR_MATCH>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop); break;
+    case ZENV_TASK_TSP: launch_rollout_task<ZENV_TASK_TSP>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop, tile0, n_tiles); break;
+    case ZENV_TASK_TIMED_TSP: launch_rollout_task<ZENV_TASK_TIMED_TSP>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop, tile0, n_tiles); break;
+    default: launch_rollout_task<ZENV_TASK_COLOUR_MATCH>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop, tile0, n_tiles); break;
     }
     return hipGetLastError();
 }

@@ -26,8 +26,10 @@ hipError_t launch_step(const DevParams &p, const float *actions, int auto_reset,
 // K closed-loop steps in one launch (persistent kernel); a_0 must be in p.actions, a_K is left there.
 // pol.step_index = index of the FIRST action the launch computes (= step count before + 1).
 bool rollout_kernel_available(const DevParams &p);
+// tile0 / n_tiles: the slice of the batch's 64-env tiles this launch covers (n_tiles < 0: all from tile0 on)
+int rollout_tiles(const DevParams &p);
 hipError_t launch_rollout(const DevParams &p, int n_steps, int auto_reset, const StepPolicy &pol, hipStream_t s,
-                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int tile0 = 0, int n_tiles = -1);
 hipError_t launch_reset(const DevParams &p, const uint8_t *mask, hipStream_t s);
 // goal-conditioned variant: set goals (new_goal[N], -1 = keep; *bad counts rejected ones) / per-step shaping
 hipError_t launch_goal_set(const DevParams &p, const int32_t *new_goal, int32_t *bad, hipStream_t s);

@@ -87,6 +87,7 @@ struct zenv {
         int64_t step = -1;
     } act_tag;
     std::vector<hipEvent_t> events;
+    int rollout_slice_tiles = 1024;   // 64-env tiles per persistent launch (zenv_set_rollout_slice): one per wave slot pair
     // actor network (zenv_mlp_load)
     void *mlp_mem = nullptr;
     MlpImages mlp{};
@@ -1226,8 +1227,15 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     const bool per_kernel = ms_step_kernel_avg != nullptr && steps > 0;
     if (event_stride < 1) event_stride = 1;
     // persistent: one launch covers up to kRolloutChunk steps and every launch is timed
+    // ... in slices of the batch (zenv_set_rollout_slice): a launch of more workgroups than the chip holds at once runs
+    // its later workgroups wherever a slot frees up, and the placement "one env wave + one stream wave per SIMD" that
+    // the first 1 024 tiles get is lost (measured: one launch over 131 072 envs takes 6.9 us per 65 536 env-steps, two
+    // launches over 65 536 each 5.3)
+    const int all_tiles = rollout_tiles(h->p);
+    const int slice = h->rollout_slice_tiles > 0 ? std::min(h->rollout_slice_tiles, all_tiles) : all_tiles;
+    const int n_slices = (all_tiles + slice - 1) / slice;
     const int n_sampled = !per_kernel ? 0
-                          : persistent ? (steps + kRolloutChunk - 1) / kRolloutChunk
+                          : persistent ? n_slices * ((steps + kRolloutChunk - 1) / kRolloutChunk)
                                        : (steps + event_stride - 1) / event_stride;
     const size_t need = 2 + 2 * (size_t)n_sampled;
     while (h->events.size() < need) {
@@ -1250,12 +1258,14 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     if (persistent && steps > 0) {
         StepPolicy pol{ policy, (uint32_t)h->step_count, policy_seed, env_index0, h->p.actions };
         if (!have_a0) HIP_TRY(launch_policy(h->p, pol, h->stream));   // a_0; every launch leaves the next action behind
-        for (int t = 0, c = 0; t < steps; t += kRolloutChunk, ++c) {
+        for (int t = 0, c = 0; t < steps; t += kRolloutChunk) {
             const int k = std::min(kRolloutChunk, steps - t);
             pol.step_index = (uint32_t)(h->step_count + 1);
-            hipEvent_t e0 = per_kernel ? h->events[2 + 2 * c] : nullptr;
-            hipEvent_t e1 = per_kernel ? h->events[3 + 2 * c] : nullptr;
-            HIP_TRY(launch_rollout(h->p, k, auto_reset, pol, h->stream, e0, e1));
+            for (int tile0 = 0; tile0 < all_tiles; tile0 += slice, ++c) {
+                hipEvent_t e0 = per_kernel ? h->events[2 + 2 * c] : nullptr;
+                hipEvent_t e1 = per_kernel ? h->events[3 + 2 * c] : nullptr;
+                HIP_TRY(launch_rollout(h->p, k, auto_reset, pol, h->stream, e0, e1, tile0, std::min(slice, all_tiles - tile0)));
+            }
             h->step_count += k;
         }
     }
@@ -1623,6 +1633,14 @@ extern "C" int zenv_sync(zenv_t *h)
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return ZENV_OK;
+}
+
+extern "C" int zenv_set_rollout_slice(zenv_t *h, int envs_per_launch)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (envs_per_launch < 0) return fail(ZENV_E_ARG, "envs_per_launch must be >= 0 (0: the whole batch in one launch)");
+    h->rollout_slice_tiles = (envs_per_launch + 63) / 64;
     return ZENV_OK;
 }
 

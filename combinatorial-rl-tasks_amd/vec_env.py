@@ -280,6 +280,10 @@ class ZoneVecEnv:
                                  C.byref(kern) if time_step_kernel else None))
         return total.value, (kern.value if time_step_kernel else None)
 
+    def set_rollout_slice(self, envs_per_launch):
+        """Envs one persistent launch covers (default 65 536; 0 = the whole batch in one launch): zenv_set_rollout_slice."""
+        check(lib().zenv_set_rollout_slice(self._h, int(envs_per_launch)))
+
     # ------------------------------------------------------------------ solver-ordered variant (8(f) row 3)
     def enable_order(self):
         """TSPOrderEnv semantics (TSP_order_env.py:13-113); call before build_bank / set_bank -- an episode's

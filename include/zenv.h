@@ -244,6 +244,13 @@ int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0
 int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
                  int auto_reset, int flags, int event_stride, float *ms_total,
                  float *ms_step_kernel_avg);
+/* How many envs ONE persistent launch covers (default 65 536 = 1 024 tiles: the chip's 1 024 SIMDs each hold one env
+ * wave and one stream wave; a larger batch is stepped slice by slice, every slice ZENV_ROLLOUT_CHUNK steps at a time).
+ * A launch over more workgroups than are resident at once loses that placement -- one launch over 131 072 envs takes
+ * 6.9 us per 65 536 env-steps against 5.3 for two launches over 65 536 each -- and a slice's per-step output (42 MB at
+ * Z = 25) stays in the Infinity Cache while it is rewritten.  0: the whole batch in one launch.  Results do not
+ * depend on it. */
+int zenv_set_rollout_slice(zenv_t *h, int envs_per_launch);
 
 /* ---- goal-conditioned variant: TSPNextCityEnv, main/envs/zone_envs/
  * TSP_next_city_env.py:41-109, and TimedTSPNextCityEnv, zone-goals/envs/TTSP_next_city_env.py:40-51, as the

@@ -30,7 +30,7 @@ done
 # the batch-size sweep of aux.beyond_llc: HBM bytes of both kernels AT each size (per-step output 0.6x .. 7x the LLC)
 for n in ${SWEEP_SIZES:-262144 1048576 3145728}; do
   w="PointTSP-25@$n"
-  base="--workload PointTSP-25 --envs-per-gpu $n --bank-maps 262144 --no-settle --no-cpu-baseline --no-kernel-events --no-mlp --no-steady --no-sweep --no-per-step"
+  base="--workload PointTSP-25 --envs-per-gpu $n --bank-maps 262144 --rollout-slice 0 --no-settle --no-cpu-baseline --no-kernel-events --no-mlp --no-steady --no-sweep --no-per-step"
   for mode in persistent per_step; do
     [ $mode = persistent ] && common="$base --mode persistent --warmup 128 --steps 512" || common="$base --mode per_step --warmup 16 --steps 64"
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_${w}_$mode -- python bench.py $common > /dev/null 2>&1

@@ -492,3 +492,32 @@ def test_solver_ordered_variant_lockstep(zenv_mod, oracle_mod):
     with pytest.raises(Z.ZenvError):
         env.enable_order()                                    # routes ride in the bank: enable first
     env.close()
+
+
+@pytest.mark.parametrize("task,zones", [(0, 25), (1, 15), (2, 6)])
+def test_persistent_launch_slices_do_not_change_results(zenv_mod, task, zones):
+    """zenv_set_rollout_slice: a batch stepped in launches over 64, 128 or 200 of its envs, or in one launch over all of
+    them (0), ends in the same state bit for bit (ragged last slice and ragged last tile included)."""
+    Z = zenv_mod
+    n, T = 333, 300
+    blobs = []
+    for sl in (0, 64, 128, 200, 65536):
+        cfg = Z.default_config(task, zones, zones_keepout=0.40 if zones == 25 else 0.55, num_steps=120)
+        env = Z.ZoneVecEnv(cfg, n)
+        env.build_bank(5, 6 * n)
+        env.schedule_sequential(stride=n)
+        env.reset()
+        env.set_rollout_slice(sl)
+        env.rollout(T, Z.POLICY_GREEDY, policy_seed=9)
+        env.rollout(70, Z.POLICY_UNIFORM, policy_seed=9, env_index0=17)
+        blobs.append(env.get_state())
+        assert env.get(Z.F_EPISODES).sum() > n
+        env.close()
+    for b in blobs[1:]:
+        assert np.array_equal(b, blobs[0])
+    with pytest.raises(Z.ZenvError):
+        env = Z.ZoneVecEnv(Z.default_config(0, 5), 8)
+        try:
+            env.set_rollout_slice(-1)
+        finally:
+            env.close()
