@@ -7,7 +7,7 @@
 //   zones    zxy[Z][N] double2          float64   zone centres (x,y), zone-major
 // (pairs so that every access is 16 B per lane = 1 KiB per wave instruction)
 //   TSP/TTSP vis[N] u32 bitmask; tmax[Z][N] i32 (TimedTSP)
-//   Colour   colpack[N] u64 (2 bits/zone), cooldown[Z][N] u8, goal_dist[N] i32
+//   Colour   colpack[N] u64 (2 bits/zone), cooldown u64 [ceil(Z/8)][N] (a byte per zone), goal_dist[N] i32
 //   counters steps[N] i32, done_state[N] u8, ep_return[N] f64, episodes/last_len[N] i32 ...
 // Outputs are row-major exactly as the reference consumer reads them
 // (main/src/utils/format.py:25-29): obs [N][8] f32, zone_obs [N][Z][F] f32.
@@ -48,7 +48,7 @@ struct DevParams {
     uint32_t *vis;
     int32_t *tmax;
     uint64_t *colpack;
-    uint8_t *cooldown;
+    uint8_t *cooldown;       // ColourMatch: one byte per zone, eight zones of an env per 64-bit word: u64 [ceil(Z/8)][N]
     int32_t *goal_dist;
     int32_t *steps;
     uint8_t *done_state;

@@ -116,6 +116,27 @@ __device__ __forceinline__ int hamming_to_goal(uint64_t colpack, int Z)
     return min(to_blue, min(to_green, to_red));
 }
 
+// ColourMatch cooldowns: one byte per zone, EIGHT zones of one env per 64-bit word, words [ceil(Z/8)][N] -- an env's
+// cooldowns are one 8-byte load and one 8-byte store per step (Z <= 8) instead of Z byte-wide read-modify-writes of
+// half-empty cache lines (round 2: u8 [Z][N], PMC traffic 1.28x the algorithmic bytes on ColourMatch-6).
+template <typename P>
+__device__ __forceinline__ uint8_t *cd_byte(const P &p, int z, int env)
+{
+    return p.cooldown + (((size_t)(z >> 3) * p.N + env) << 3) + (z & 7);
+}
+template <typename P>
+__device__ __forceinline__ uint64_t *cd_word(const P &p, int w, int env)
+{
+    return reinterpret_cast<uint64_t *>(p.cooldown) + (size_t)w * p.N + env;
+}
+// every non-zero byte of w minus one (colour_match_env.py:98-100 for eight zones at once; no borrow crosses a byte)
+__device__ __forceinline__ uint64_t cd_decrement(uint64_t w)
+{
+    const uint64_t lo7 = 0x7F7F7F7F7F7F7F7Full;
+    const uint64_t nz = (((w & lo7) + lo7) | w) & 0x8080808080808080ull;
+    return w - (nz >> 7);
+}
+
 // PCG64 (numpy default_rng) step/output on device, for the FixedSeedsWrapper schedule
 __device__ __forceinline__ void pcg_step_dev(uint64_t &hi, uint64_t &lo, uint64_t ihi, uint64_t ilo)
 {
@@ -388,7 +409,7 @@ __device__ __forceinline__ void reset_env(const DevParams &p, int env, int slot,
         } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
             code = ba[z];
             e.colpack |= (uint64_t)code << (2 * z);
-            p.cooldown[zi] = 0;
+            *cd_byte(p, z, env) = 0;
         }
         const float4 en = make_entry<TASK>(p, zx, zy, code, aux, 0);
         sink.template put<TASK>(z, en);
@@ -917,45 +938,54 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         double ep_ret = 0.0;
         float4 zp[ZH];      // float32 zone positions (x/3, y/3), two zones per 16-byte load
         int auxr[ZR];
+        constexpr int ZW = ZT > 0 ? (ZT + 7) / 8 : 1;
+        uint64_t cdw[ZW];   // ColourMatch: the env's cooldown bytes, eight zones per word
         int epi_idx = 0, slot_first = 0;
         float2 act = make_float2(0.f, 0.f);
-        if (valid) {
-            // ---- issue every load of this env first
-            was_done = p.done_state[env];
-            act = reinterpret_cast<const float2 *>(actions)[env];   // only its NaN-ness matters here (exception path)
+        {
+            // ---- issue every load of this env first.  No branch around them: a lane beyond the batch (the last tile
+            // of a ragged batch) loads the last env's state and ignores it -- inside an `if (valid)` the loaded values
+            // reach the code below through copies at the end of the block, and those copies made the wave wait for
+            // EVERY zone load before it could look at the pose (round 3: s_waitcnt vmcnt right behind the issue)
+            const int envl = valid ? env : N - 1;
+            was_done = p.done_state[envl];
+            act = reinterpret_cast<const float2 *>(actions)[envl];   // only its NaN-ness matters here (exception path)
             {
-                const double2 qa = p.qa[env], fa = p.fa[env], fb = p.fb[env];
+                const double2 qa = p.qa[envl], fa = p.fa[envl], fb = p.fb[envl];
                 e.q0 = qa.x; e.q1 = qa.y;
                 e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
             }
-            e.steps = p.steps[env];
+            e.steps = p.steps[envl];
             e.vis = 0u; e.colpack = 0ull; e.goal_dist = 0;
             if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                e.colpack = p.colpack[env];
-                e.goal_dist = p.goal_dist[env];
+                e.colpack = p.colpack[envl];
+                e.goal_dist = p.goal_dist[envl];
             } else {
-                e.vis = p.vis[env];
+                e.vis = p.vis[envl];
             }
-            ep_ret = p.ep_return[env];
+            ep_ret = p.ep_return[envl];
             if (ZT > 0) {
                 // issue order = consumption order: pose first, then zone pairs 0, 1, ... so the
                 // in-order vmcnt waits of the zone pass release one pair at a time
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int h = 0; h < ZH; ++h) zp[h] = p.zpf[(size_t)h * N + env];   // 1 KiB per wave
+                for (int h = 0; h < ZH; ++h) zp[h] = p.zpf[(size_t)h * N + envl];   // 1 KiB per wave
 #pragma unroll
                 for (int z = 0; z < ZR; ++z) {
-                    const size_t zi = (size_t)z * N + env;
+                    const size_t zi = (size_t)z * N + envl;
                     auxr[z] = 0;
                     if (TASK == ZENV_TASK_TIMED_TSP) auxr[z] = p.tmax[zi];
-                    if (TASK == ZENV_TASK_COLOUR_MATCH) auxr[z] = p.cooldown[zi];
+                }
+                if (TASK == ZENV_TASK_COLOUR_MATCH) {
+#pragma unroll
+                    for (int w = 0; w < ZW; ++w) cdw[w] = *cd_word(p, w, envl);
                 }
                 // nothing below may be scheduled above this point, nor any load below it
                 __builtin_amdgcn_sched_barrier(0);
             }
             // only needed at the very end (reset / prefetch): requested behind the zone loads
-            epi_idx = p.episode_idx[env];     // the bank slot of a reset is known before it happens
-            slot_first = p.slot_first[env];
+            epi_idx = p.episode_idx[envl];     // the bank slot of a reset is known before it happens
+            slot_first = p.slot_first[envl];
         }
 
         float rew_out = 0.f;
@@ -993,6 +1023,10 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             // decides.  Everything is collected in bit masks; the lowest set bit wins.
             const float rxf = (float)rx, ryf = (float)ry;
             uint32_t in_mask = 0u, amb_mask = 0u, elig_mask = 0u, expired = 0u, expiring = 0u;
+            if (TASK == ZENV_TASK_COLOUR_MATCH && ZT > 0) {
+#pragma unroll
+                for (int w = 0; w < ZW; ++w) cdw[w] = cd_decrement(cdw[w]);   // colour_match_env.py:98-100, all zones
+            }
 #pragma unroll
             for (int z = 0; z < (ZT > 0 ? ZT : Z); ++z) {
                 const size_t zi = (size_t)z * N + env;
@@ -1001,10 +1035,12 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 if (ZT > 0) {
                     pr = zp[z >> 1];
                     aux = auxr[z];
+                    // (the words were decremented above the loop: this is the cooldown AFTER this step's decrement)
+                    if (TASK == ZENV_TASK_COLOUR_MATCH) aux = (int)((cdw[z >> 3] >> (8 * (z & 7))) & 0xFFull);
                 } else {
                     pr = p.zpf[(size_t)(z >> 1) * N + env];
                     if (TASK == ZENV_TASK_TIMED_TSP) aux = p.tmax[zi];
-                    if (TASK == ZENV_TASK_COLOUR_MATCH) aux = p.cooldown[zi];
+                    if (TASK == ZENV_TASK_COLOUR_MATCH) aux = *cd_byte(p, z, env);
                 }
                 const float x3 = (z & 1) ? pr.z : pr.x, y3 = (z & 1) ? pr.w : pr.y;
                 const float dxf = __builtin_fmaf(3.f, x3, -rxf), dyf = __builtin_fmaf(3.f, y3, -ryf);
@@ -1015,9 +1051,11 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 float4 en = make_float4(x3, y3, 0.f, 0.f);
                 if (TASK == ZENV_TASK_COLOUR_MATCH) {
                     int cd = aux;
-                    if (cd > 0) cd -= 1;                        // colour_match_env.py:98-100
+                    if (ZT == 0) {
+                        if (cd > 0) cd -= 1;                    // colour_match_env.py:98-100
+                        *cd_byte(p, z, env) = (uint8_t)cd;
+                    }
                     elig_mask |= (cd == 0 ? 1u : 0u) << z;
-                    p.cooldown[zi] = (uint8_t)cd;
                     en.z = (float)(int)((e.colpack >> (2 * z)) & 3ull);
                     en.w = (float)div_const((double)(float)cd, p.d_maxcd, p.inv_maxcd);
                 } else {
@@ -1050,7 +1088,14 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                     int col = (int)((e.colpack >> (2 * first)) & 3ull);
                     col = (col == 2) ? 0 : col + 1;                  // Blue->Green->Red->Blue
                     e.colpack = (e.colpack & ~(3ull << (2 * first))) | ((uint64_t)col << (2 * first));
-                    p.cooldown[(size_t)first * N + env] = (uint8_t)p.max_cd;
+                    if (ZT > 0) {
+#pragma unroll
+                        for (int w = 0; w < ZW; ++w)
+                            if ((first >> 3) == w)
+                                cdw[w] = (cdw[w] & ~(0xFFull << (8 * (first & 7)))) | ((uint64_t)p.max_cd << (8 * (first & 7)));
+                    } else {
+                        *cd_byte(p, first, env) = (uint8_t)p.max_cd;
+                    }
                     float *slot = reinterpret_cast<float *>(my_ents + first);
                     slot[2] = (float)col;
                     slot[3] = (float)div_const((double)(float)p.max_cd, p.d_maxcd, p.inv_maxcd);
@@ -1064,6 +1109,10 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             if (TASK == ZENV_TASK_TIMED_TSP) {
                 timed_out = (expired & ~e.vis & full) != 0u;
                 ends_soon = (expiring & ~e.vis & full) != 0u;
+            }
+            if (TASK == ZENV_TASK_COLOUR_MATCH && ZT > 0) {
+#pragma unroll
+                for (int w = 0; w < ZW; ++w) *cd_word(p, w, env) = cdw[w];
             }
         }
 
@@ -1161,7 +1210,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                         p.tmax[zi] = aux;
                     } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
                         code = p.bank_aux[bi];
-                        p.cooldown[zi] = 0;
+                        *cd_byte(p, lane, env_j) = 0;
                     }
                     en = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
                     ents[j * Z + lane] = en;
@@ -1734,7 +1783,15 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         for (int z = 0; z < ZT; ++z) {
             const size_t zi = (size_t)z * N + env;
             if (TASK == ZENV_TASK_TIMED_TSP) auxr[z] = p.tmax[zi];
-            if (kColour) auxr[z] = p.cooldown[zi];
+        }
+        if (kColour) {
+#pragma unroll
+            for (int w = 0; w < (ZT + 7) / 8; ++w) {
+                const uint64_t cw = *cd_word(p, w, env);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (8 * w + i < ZT) auxr[8 * w + i] = (int)((cw >> (8 * i)) & 0xFFull);
+            }
         }
     }
 #pragma unroll
@@ -1752,7 +1809,13 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         pc.ep_return[env] = ret;
         if (kColour) {
 #pragma unroll
-            for (int z = 0; z < ZT; ++z) pc.cooldown[(size_t)z * N + env] = (uint8_t)auxr[z];
+            for (int w = 0; w < (ZT + 7) / 8; ++w) {
+                uint64_t cw = 0ull;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (8 * w + i < ZT) cw |= (uint64_t)((uint32_t)auxr[8 * w + i] & 0xFFu) << (8 * i);
+                *cd_word(pc, w, env) = cw;
+            }
         }
     };
     // A step is written so that its common case has no divergent branch: every lane of the wave runs the zone pass,
@@ -2301,7 +2364,7 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
     if (zl) {
         zz = p.zxy[zi];
         if (TASK == ZENV_TASK_TIMED_TSP) aux = p.tmax[zi];
-        if (TASK == ZENV_TASK_COLOUR_MATCH) aux = p.cooldown[zi];
+        if (TASK == ZENV_TASK_COLOUR_MATCH) aux = *cd_byte(p, lane, env);
     }
     const double dx = zz.x - rx, dy = zz.y - ry;
     const bool inside = zl && (dx * dx + dy * dy <= p.hit_d2);
@@ -2324,7 +2387,7 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
             e.vis |= 1u << first;
         }
     }
-    if (TASK == ZENV_TASK_COLOUR_MATCH && zl) p.cooldown[zi] = (uint8_t)aux;
+    if (TASK == ZENV_TASK_COLOUR_MATCH && zl) *cd_byte(p, lane, env) = (uint8_t)aux;
     const bool visited = (e.vis >> lane) & 1u;
     bool timed_out = false;
     if (TASK == ZENV_TASK_TIMED_TSP) timed_out = __ballot(zl && !visited && (aux - k) <= 0) != 0ull;   // TTSP_env.py:67
@@ -2410,7 +2473,7 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
                 p.tmax[zi] = a;
             } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
                 code = p.bank_aux[bi];
-                p.cooldown[zi] = 0;
+                *cd_byte(p, lane, env) = 0;
             }
             en = make_entry<TASK>(p, zz.x, zz.y, code, a, 0);
             sink.put<TASK>(lane, en);

@@ -466,7 +466,7 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
     want(h, p.vis, N, true);
     want(h, p.tmax, Z * N, true);
     want(h, p.colpack, N, true);
-    want(h, p.cooldown, Z * N, true);
+    want(h, p.cooldown, ((Z + 7) / 8) * 8 * N, true);      // one byte per zone, eight zones of an env per 64-bit word
     want(h, p.goal_dist, N, true);
     want(h, p.steps, N, true);
     want(h, p.done_state, N, true);
@@ -1712,6 +1712,14 @@ extern "C" int zenv_set_state(zenv_t *h, const void *src, int64_t bytes)
                 const double *d = reinterpret_cast<const double *>(scan);
                 for (size_t i = 0; i < a.bytes / sizeof(double); ++i)
                     if (!std::isfinite(d[i])) return fail(ZENV_E_ARG, "state blob holds a non-finite joint state");
+                // the kernels turn sin / cos of the hinge angle by h * omega per substep with Taylor kernels that
+                // validate_config keeps below 0.05 rad for every state the model can REACH; a blob can hold any
+                // finite velocity, so the same bound is applied to it (qc = (v1, v2): omega is the second double)
+                if (s0 == (void **)&h->p.qc)
+                    for (size_t i = 1; i < a.bytes / sizeof(double); i += 2)
+                        if (!(h->cfg.timestep * std::fabs(d[i]) < 0.05))
+                            return fail(ZENV_E_ARG, "state blob: env %zu turns %.3g rad per substep, beyond the small-angle "
+                                        "update (0.05)", i / 2, h->cfg.timestep * std::fabs(d[i]));
             }
             scan += a.bytes;
         }
@@ -1760,10 +1768,11 @@ extern "C" int zenv_debug_state(zenv_t *h, double *qpos, double *qvel, int32_t *
         }
     }
     if (cooldown) {
-        std::vector<uint8_t> cd(N * Z);
-        HIP_TRY(hipMemcpy(cd.data(), p.cooldown, N * Z, hipMemcpyDeviceToHost));
+        const size_t ZW = (Z + 7) / 8;
+        std::vector<uint8_t> cd(ZW * 8 * N);
+        HIP_TRY(hipMemcpy(cd.data(), p.cooldown, cd.size(), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < N; ++i)
-            for (size_t z = 0; z < Z; ++z) cooldown[i * Z + z] = cd[z * N + i];
+            for (size_t z = 0; z < Z; ++z) cooldown[i * Z + z] = cd[((z >> 3) * N + i) * 8 + (z & 7)];
     }
     if (steps) HIP_TRY(hipMemcpy(steps, p.steps, N * 4, hipMemcpyDeviceToHost));
     return ZENV_OK;

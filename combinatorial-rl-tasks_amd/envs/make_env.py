@@ -2,8 +2,11 @@
 
 The reference keeps one id list per factory and per tree (main/envs/make_env.py:14, :32, :49; zone-goals/envs/make_env.py):
 e.g. main's make_train_env does not list PointTSP-v4 / -v5.  Here every factory accepts every id of the merged
-registry -- a superset: whatever the reference constructs is constructed the same way, unknown ids raise the same
-RuntimeError("Unknown environment"), Car / Doggo ids raise NotImplementedError (other robots: out of scope)."""
+registry -- a superset: whatever main/ constructs is constructed the same way, unknown ids raise the same
+RuntimeError("Unknown environment"), Car / Doggo ids raise NotImplementedError (other robots: out of scope).
+One id pair is registered on different classes by different trees: PointTSP-v4 / -v5 are TSPHardEnv(TSPEnv) in main/
+(TSP_hard_env.py:11) and TSPHardEnv(TSPNextCityEnv) in zone-goals/ (zone-goals/envs/TSP_hard_env.py:11); the factories
+here follow main/, `registry.make(id, tree="zone-goals")` builds the goal-conditioned variant (TSPHardNextCityEnv)."""
 from .registry import OUT_OF_SCOPE, REGISTRY, make
 from .wrappers import FixedSeedsWrapper, WaitWrapper, ZoneWrapper
 

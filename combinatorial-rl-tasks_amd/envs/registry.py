@@ -1,6 +1,7 @@
 """The gym registry of main/envs/__init__.py:7-141 for the ids on the MI355X hot path."""
 from .zone_envs import (ColourMatchEnv, ColourMatchNextCityEnv, ColourMatchSolverEnv, TimedTSPEnv,
-                        TimedTSPNextCityEnv, TSPEnv, TSPHardEnv, TSPNextCityEnv, TSPOrderEnv, TSPOrderTestEnv)
+                        TimedTSPNextCityEnv, TSPEnv, TSPHardEnv, TSPHardNextCityEnv, TSPNextCityEnv, TSPOrderEnv,
+                        TSPOrderTestEnv)
 
 config_point = {                      # __init__.py:7-14
     "robot_base": "xmls/point.xml", "num_cities": 15, "walled": False,
@@ -46,12 +47,29 @@ REGISTRY = {
     "PointTSP-v21": (TSPOrderTestEnv, config_point),                   # zone-goals/envs/__init__.py:102-104
 }
 
+# Ids that the reference's trees register on DIFFERENT classes.  REGISTRY above follows main/envs/__init__.py; the
+# zone-goals tree (zone-goals/envs/__init__.py:112-119, TSP_hard_env.py:11) builds PointTSP-v4 / -v5 on the
+# goal-conditioned TSPNextCityEnv: `make(id, tree="zone-goals")` selects that registration.
+TREE_OVERRIDES = {
+    "zone-goals": {
+        "PointTSP-v4": (TSPHardNextCityEnv, config_zone_fixed_1),
+        "PointTSP-v5": (TSPHardNextCityEnv, config_zone_fixed_2),
+    },
+}
+
 # registered by the reference but outside this build (other robots)
 OUT_OF_SCOPE = ("CarTSP-v0", "DoggoTSP-v0")
 
 
-def make(env_id, **kwargs):
-    """gym.make for the registered zone envs."""
+def make(env_id, tree="main", **kwargs):
+    """gym.make for the registered zone envs.  tree: which of the reference's source trees' registrations to follow
+    where they differ ("main", or "zone-goals" for the goal-conditioned hard instances)."""
+    if tree != "main":
+        if tree not in TREE_OVERRIDES:
+            raise ValueError(f"unknown tree {tree!r}")
+        if env_id in TREE_OVERRIDES[tree]:
+            cls, config = TREE_OVERRIDES[tree][env_id]
+            return cls(config, **kwargs)
     if env_id in REGISTRY:
         cls, config = REGISTRY[env_id]
         return cls(config, **kwargs)

@@ -256,6 +256,16 @@ class TSPNextCityEnv(TSPEnv):
         return np.array([(mask >> i) & 1 for i in range(self.num_cities)], bool)
 
 
+class TSPHardNextCityEnv(TSPHardEnv, TSPNextCityEnv):
+    """PointTSP-v4 / -v5 as the zone-goals tree registers them (zone-goals/envs/TSP_hard_env.py:11-34: TSPHardEnv derives
+    from TSPNextCityEnv there): the hard instances -- fixed placements, cities that start visited -- with the
+    goal-conditioned surface (set_goal / get_goal / get_available_goals, info['shaped_reward'], info['need_next_goal']).
+    The cities that start visited are not available goals."""
+
+    def __init__(self, config, **kw):
+        TSPHardEnv.__init__(self, config, **kw)       # -> ... -> TSPNextCityEnv.__init__ -> TSPEnv.__init__ (MRO)
+
+
 class TSPOrderEnv(TSPEnv):
     """PointTSP-v2 (main/envs/TSP_order_env.py:13-113): the observation carries the visiting order of the cities
     (7th row feature 0.5^i for the i-th city of the remaining route) and info['shaped_reward'] is the progress

@@ -292,3 +292,24 @@ def test_integration_md_ctypes_stub_runs(zenv_mod):
     assert np.array_equal(ns["obs"], o) and np.array_equal(ns["zone_obs"], zo)
     assert np.array_equal(ns["reward"], r) and np.array_equal(ns["done"].astype(bool), d)
     env.close()
+
+
+def test_set_state_rejects_a_hinge_velocity_beyond_the_small_angle_update(zenv_mod):
+    """The kernels advance sin / cos of the hinge angle by h * omega per substep with Taylor kernels good to 0.1 rad;
+    validate_config bounds what the model can reach, zenv_set_state applies the same bound (0.05) to a blob."""
+    Z = zenv_mod
+    env = Z.ZoneVecEnv("PointTSP-v1", 70)
+    env.build_bank(1, 70)
+    env.reset()
+    env.rollout(20, Z.POLICY_GREEDY)
+    blob = env.get_state()
+    env.set_state(blob)                                       # its own state passes
+    qc_off = 16 + 70 * 16 * 2                                 # head, qa, qb; then qc = (v1, v2) per env
+    bad = blob.copy()
+    bad[qc_off + 16 * 33 + 8: qc_off + 16 * 33 + 16] = np.frombuffer(np.float64(1e3).tobytes(), np.uint8)   # env 33: omega
+    with pytest.raises(Z.ZenvError, match="small-angle"):
+        env.set_state(bad)
+    ok = blob.copy()
+    ok[qc_off + 16 * 33 + 8: qc_off + 16 * 33 + 16] = np.frombuffer(np.float64(-20.0).tobytes(), np.uint8)  # 0.04 rad
+    env.set_state(ok)
+    env.close()

@@ -395,3 +395,42 @@ def test_skill_boundary_step_resets_envs_left_finished(zenv_mod, oracle_mod):
             assert np.array_equal(obs[i]["zone_obs"].astype(np.float32), ref_obs[i][1]), (t, i)
     assert revived >= P
     penv.close()
+
+
+@pytest.mark.parametrize("env_id,n_free", [("PointTSP-v4", 5), ("PointTSP-v5", 3)])
+def test_goal_conditioned_hard_instances_of_the_zone_goals_tree(zenv_mod, oracle_mod, env_id, n_free):
+    """zone-goals/envs/TSP_hard_env.py:11: there TSPHardEnv derives from TSPNextCityEnv -- `make(id, tree="zone-goals")`.
+    Pre-visited cities are not available goals; a greedy walk over the free cities, every step against the oracle's
+    goal-conditioned step (orc_step_goal) on the same hard config."""
+    Zm, O = zenv_mod, oracle_mod
+    from combinatorial_rl_tasks_amd.envs import TSPHardEnv, TSPNextCityEnv, make
+    env = make(env_id, tree="zone-goals")
+    assert isinstance(env, TSPHardEnv) and isinstance(env, TSPNextCityEnv)
+    assert type(make(env_id)).__name__ == "TSPHardEnv"          # main/ registers the plain TSPEnv subclass
+    env.seed(31)
+    obs = env.reset()
+    ref = O.OracleEnv(_oracle_for(O, env_id, Zm))
+    o_ref, zo_ref = ref.reset(31)
+    avail = env.get_available_goals()
+    assert avail.sum() == n_free and avail[:n_free].all() and np.array_equal(avail, ref.available_goals())
+    with pytest.raises(AssertionError):
+        env.set_goal(n_free)                                     # a city that starts visited
+    t = 0
+    done = False
+    while not done and t < 1000:
+        if env.goal_zone is None:
+            g = int(np.flatnonzero(env.get_available_goals())[0])
+            env.set_goal(g)
+            ref.set_goal(g)
+        a = ref.policy(O.POLICY_GREEDY, o_ref, zo_ref, 0, t)
+        obs, r, done, info = env.step(a)
+        r_ref, d_ref, g_ref, sh_ref, need_ref = ref.step_goal(a)
+        o_ref, zo_ref = ref.obs()
+        assert abs(r - r_ref) <= 1e-5 and (done, info["shaped_reward"], info["need_next_goal"]) == (d_ref, sh_ref, need_ref), t
+        # the raw env's observation dict (ZoneEnvBase.obs): one row per city + the robot's own entries
+        rows = np.stack([obs[f"zones_lidar_{i}"] for i in range(15)]).astype(np.float32)
+        rest = np.concatenate([obs[k] for k in ("remaining", "robot_pos", "robot_dir", "robot_velp", "robot_velr")])
+        assert np.array_equal(rows, zo_ref) and np.array_equal(rest.astype(np.float32), o_ref), t
+        t += 1
+    assert done and t > 20
+    env.close()
