@@ -55,6 +55,25 @@ for k in (1, 2, 4, 3, 10, 12, 13):
 for k, v in names.items():
     x = rel[:, :, k]
     print(f"{v:32s} median {np.median(x):7.2f}  p10 {np.percentile(x,10):7.2f}  p90 {np.percentile(x,90):7.2f}  max {x.max():7.2f} us")
+if any(a.startswith("json=") for a in sys.argv):
+    import json
+    path = [a for a in sys.argv if a.startswith("json=")][0][5:]
+    def q(x):
+        return {"median": round(float(np.median(x)), 3), "p10": round(float(np.percentile(x, 10)), 3),
+                "p90": round(float(np.percentile(x, 90)), 3), "p99": round(float(np.percentile(x, 99)), 3),
+                "max": round(float(x.max()), 3)}
+    rec = {"kernel": "k_step_lane", "workload": sys.argv[1], "n_env": n, "launches_sampled": len(acc),
+           "action_source": "fused scripted policy (rollout mode per_step)" if fused else "stand-alone policy kernel before the step kernel",
+           "unit": "us since the first wave of the launch started (s_memrealtime, 10 ns ticks); medians over all 1024 workgroups x sampled launches",
+           "note": "isolated launches (host synchronises between them): the launch ramp is longer than in a back-to-back loop",
+           "dispatch_us": q(np.array(kus)), "first_to_last_stamp_us": q(span),
+           "ramp_plus_drain_us": q(np.array(kus) - span), "block_end_us": q(ends),
+           "blocks_with_a_reset_per_launch": round(float(rs.sum() / a.shape[0]), 1),
+           "phases": {v: q(rel[:, :, k]) for k, v in names.items()}}
+    if rs.any():
+        rec["reset_blocks"] = {nm: q(rel[:, :, k][rs]) for k, nm in ((1, "pose ready"), (5, "reset loop entry"), (6, "bank rows landed (last reset)"), (7, "reset done (last)"), (2, "zone wave at barrier"))}
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    json.dump(rec, open(path, "w"), indent=1)
 if "blocks" in sys.argv:
     late_mask = rel[:, :, 2] > 12
     for k in (0, 1, 5, 6, 7, 2):
