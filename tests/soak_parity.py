@@ -8,6 +8,8 @@ from oracle import oracle as O
 from tests.helpers import oracle_config_from
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
+mode = sys.argv[3] if len(sys.argv) > 3 else "persistent"     # persistent | per_step | unfused
+slice_envs = int(sys.argv[4]) if len(sys.argv) > 4 else None   # zenv_set_rollout_slice (0: one launch over the batch)
 depth = 6
 bad = 0
 for task, zones, keep in ((0, 25, 0.40), (1, 25, 0.40), (2, 6, 0.55), (0, 15, 0.55), (1, 15, 0.55), (0, 5, 0.55)):
@@ -17,8 +19,10 @@ for task, zones, keep in ((0, 25, 0.40), (1, 25, 0.40), (2, 6, 0.55), (0, 15, 0.
         env.build_bank(1, depth * n, n_threads=16)
         env.schedule_sequential(stride=n)
         env.reset()
+        if slice_envs is not None:
+            env.set_rollout_slice(slice_envs)
         t0 = time.time()
-        env.rollout(T, pol_d, policy_seed=77, env_index0=5)
+        env.rollout(T, pol_d, policy_seed=77, env_index0=5, mode=mode)
         ref = O.rollout(oracle_config_from(O, cfg), 1 + np.arange(n), T, pol_o, seed_stride=n, policy_seed=77,
                         env_index0=5, n_threads=16, seed_period=depth)
         ok = (np.array_equal(env.get(Z.F_OBS), ref["obs"]) and np.array_equal(env.get(Z.F_ZONE_OBS), ref["zone_obs"])
@@ -30,4 +34,4 @@ for task, zones, keep in ((0, 25, 0.40), (1, 25, 0.40), (2, 6, 0.55), (0, 15, 0.
             task, zones, pol_d, "bit-identical" if ok else "MISMATCH", n * T, int(ref["episodes"].sum()), time.time() - t0),
             flush=True)
         env.close()
-print("soak:", "all bit-identical" if not bad else f"{bad} MISMATCHES")
+print("soak (%s%s):" % (mode, "" if slice_envs is None else ", slice %d" % slice_envs), "all bit-identical" if not bad else f"{bad} MISMATCHES")
