@@ -24,6 +24,8 @@
 //    takes the per-env zone sums from a float32 array instead of computing them.)
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "mlp_head_out.hpp"
 #include "mlp_policy.hpp"
 
@@ -388,9 +390,184 @@ void k_mlp_zone_f32m(MlpF32 w, int N, int Z, int F, const float *__restrict__ ob
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------ zone part on bf16 x 3
+// ZENV_MLP_BF16X3: the two zone layers -- 96 % of the network's arithmetic -- on the bf16 matrix instruction with every
+// operand written as hi + lo (x_hi = bf16(x), x_lo = bf16(x - x_hi); the weights split the same way on the host) and
+// three products per k-step, hi*hi + hi*lo + lo*hi, accumulated in float32 by the instruction: 16 significant bits per
+// operand instead of 8.  scripts/split_bf16_frontier.py (torch emulation against the float32 restatement of the
+// reference's modules): max |d mu| 3.7e-6, |d std| 2.0e-6, |d value| 7.8e-6 with ALL layers split -- inside the 1e-5 the
+// float32 mode is held to -- and the per-env head here stays on the float32 matrix instruction (head_layer_f32m), so
+// only the zone layers carry the split's error.  v_mfma_f32_32x32x16_bf16 does 8 times the k depth of
+// v_mfma_f32_32x32x2_f32 in half its cycles: 3 products cost 3/16 of the float32 kernel's matrix time.
+//
+// Same shape as k_mlp_zone_f32m: one wave per 64 envs (two groups of 32), tile t = zone t of the group's 32 envs,
+// Y = W X with the feature in the accumulator registers and the env on the lane, so relu(Y1) -- split into hi / lo
+// fragments, registers 0-7 -> k-step 2m, 8-15 -> k-step 2m + 1 of output tile m -- IS layer 2's B operand when W2's
+// fragments are packed in that k order (pack_f32: k_b3), and the per-env sum over the zone rows is a register-wise add
+// into P[], which the float32 head takes over as it stands.  LDS: W2 hi + lo (2 x 72 KiB) and W1 hi + lo (2 x 6 KiB) =
+// 159 744 B, one workgroup per CU.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef float f32x16v __attribute__((__vector_size__(16 * sizeof(float))));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+constexpr int KSB = HP / 16;                       // 12 k-steps (K = 16) per hidden layer
+constexpr size_t kZoneLdsB3 = (size_t)(NT * KSB + NT) * 2 * 64 * 16;   // (72 + 6) fragments x {hi, lo} x 1 KiB = 159 744 B
+
+__device__ __forceinline__ f32x16v mfma_bf(const uint4 a, const uint4 b, const f32x16v c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// (a, b) -> one dword of their bf16 roundings (hi) and one of the roundings of what is left (lo)
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t &hi, uint32_t &lo)
+{
+    const f32x2v v = { a, b };
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
+    const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xFFFF0000u);
+    const f32x2v r = { a - ah, b - bh };
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2v));
+}
+__device__ __forceinline__ void split8(const float *v, uint4 &hi, uint4 &lo)
+{
+    split_pair(v[0], v[1], hi.x, lo.x);
+    split_pair(v[2], v[3], hi.y, lo.y);
+    split_pair(v[4], v[5], hi.z, lo.z);
+    split_pair(v[6], v[7], hi.w, lo.w);
+}
+
+__global__ __launch_bounds__(kZoneWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_mlp_zone_b3(MlpF32 w, int N, int Z, int F, const float *__restrict__ obs, const float *__restrict__ zone_obs,
+                   float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value,
+                   float *__restrict__ value_sigma, MlpAction act, int envs_per_wave)
+{
+    extern __shared__ __align__(16) uint4 zb[];
+    uint4 *w2s = zb;                              // [NT][KSB][2][64]   fragment (n, s): hi, then lo
+    uint4 *w1s = zb + NT * KSB * 2 * 64;          // [NT][2][64]
+    {
+        const uint4 *s2 = reinterpret_cast<const uint4 *>(w.w2b), *s1 = reinterpret_cast<const uint4 *>(w.w1b);
+        for (int i = threadIdx.x; i < NT * KSB * 2 * 64; i += kZoneWaves * 64) w2s[i] = s2[i];
+        for (int i = threadIdx.x; i < NT * 2 * 64; i += kZoneWaves * 64) w1s[i] = s1[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int env0 = (blockIdx.x * kZoneWaves + wave) * envs_per_wave;
+    for (int e_base = 0; e_base < envs_per_wave && env0 + e_base < N; e_base += 32) {
+        const bool valid = env0 + e_base + r < N;
+        const int env = valid ? env0 + e_base + r : env0;
+        // the float32 head's obs operand (natural order, K = 2 per step) ...
+        float xo[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xo[s] = valid ? obs[(size_t)env * 8 + 2 * s + h] : 0.f;
+        // ... and layer 1's: lane half 0 carries k = 0..7 = the env's obs (the same for every tile of the group)
+        uint4 xoh = make_uint4(0u, 0u, 0u, 0u), xol = make_uint4(0u, 0u, 0u, 0u);
+        if (h == 0 && valid) {
+            const float4 *o4 = reinterpret_cast<const float4 *>(obs + (size_t)env * 8);
+            const float4 a = o4[0], b = o4[1];
+            const float v8[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+            split8(v8, xoh, xol);
+        }
+        f32x16 P[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) P[n][i] = 0.f;
+        for (int t = 0; t < Z; ++t) {
+            // ---- layer 1's B operand: k = 8 h + j; half 1 = the zone row (k = 8 .. 8 + F - 1), zeros, the constant 1 (k = 15)
+            uint4 x0h = xoh, x0l = xol;
+            if (h == 1) {
+                const float *row = zone_obs + ((size_t)env * Z + t) * F;
+                float v8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v8[j] = (valid && j < F) ? row[j] : 0.f;
+                v8[7] = 1.0f;
+                split8(v8, x0h, x0l);
+            }
+            // ---- zone_net_.0 + ReLU, split into layer 2's hi / lo B fragments
+            uint4 xh[KSB], xl[KSB];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const uint4 ah = w1s[(n * 2 + 0) * 64 + lane], al = w1s[(n * 2 + 1) * 64 + lane];
+                f32x16v acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                acc = mfma_bf(ah, x0h, acc);
+                acc = mfma_bf(ah, x0l, acc);
+                acc = mfma_bf(al, x0h, acc);
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
+                split8(v, xh[2 * n], xl[2 * n]);
+                split8(v + 8, xh[2 * n + 1], xl[2 * n + 1]);
+            }
+            // ---- zone_net_.2 + ReLU, summed over the tiles.  Output tile n2: 12 k-steps x 3 products on one accumulator;
+            // the fragments of k-steps s + 2, s + 3 are read from LDS while those of s, s + 1 are in the matrix pipe
+            // (explicit double buffer between scheduling barriers, as in k_mlp_zone_f32m)
+            uint4 wa[2][2][2];          // [buffer][k-step of the pair][hi, lo]
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                wa[0][q][0] = w2s[((0 * KSB + q) * 2 + 0) * 64 + lane];
+                wa[0][q][1] = w2s[((0 * KSB + q) * 2 + 1) * 64 + lane];
+            }
+            f32x16v acc;
+#pragma unroll
+            for (int c = 0; c < NT * (KSB / 2); ++c) {
+                const int n2 = c / (KSB / 2), sc = c % (KSB / 2);
+                if (c + 1 < NT * (KSB / 2)) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        wa[(c + 1) & 1][q][0] = w2s[(((c + 1) * 2 + q) * 2 + 0) * 64 + lane];
+                        wa[(c + 1) & 1][q][1] = w2s[(((c + 1) * 2 + q) * 2 + 1) * 64 + lane];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (sc == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int s = 2 * sc + q;
+                    acc = mfma_bf(wa[c & 1][q][0], xh[s], acc);
+                    acc = mfma_bf(wa[c & 1][q][0], xl[s], acc);
+                    acc = mfma_bf(wa[c & 1][q][1], xh[s], acc);
+                }
+                if (sc == KSB / 2 - 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) P[n2][i] += fmaxf(acc[i], 0.f);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- the per-env head on the float32 matrix instruction, exactly as in k_mlp_zone_f32m
+        const float inv_z = 1.0f / (float)Z;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) P[n][i] *= inv_z;
+        f32x16 e3[NT], cc[NT];
+        head_layer_f32m<4, false>(w.wcm, lane, P, xo, cc);
+        float v_mu = 0.f, v_sigma = 0.f;
+        if (w.has_critic) {
+            head_layer_f32m<0, true>(w.wv1m, lane, cc, xo, e3);
+            f32x16 hv = head_rows_f32m(w.whvm, lane, e3);
+            v_mu = hv[0];
+            v_sigma = hv[1];
+        }
+        head_layer_f32m<0, true>(w.wam, lane, cc, xo, e3);
+        const f32x16 hd = head_rows_f32m(w.whm, lane, e3);
+        if (h == 0 && valid) {
+            if (w.has_critic) {
+                value[env] = v_mu;
+                if (w.distributional && value_sigma) value_sigma[env] = softplus03(v_sigma) + 1e-3f;
+            }
+            head_outputs(env, hd[0], hd[1], hd[2], hd[3], v_mu, mu, stdv, act);
+        }
+    }
+}
 }  // namespace
 
-size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[21])
+size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[23])
 {
     const int h = w.h_dim;
     out.clear();
@@ -514,6 +691,43 @@ size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_
         offs[19] = pack_hidden(hidden(w.critic_w1, w.critic_b1, 0, h), nullptr, 0);
         offs[20] = pack_rows({ { w.critic_w2, w.critic_b2 }, { w.critic_sigma_w, w.critic_sigma_b } });
     }
+    // ---- ZENV_MLP_BF16X3: the two zone layers as bf16 hi / lo fragments for k_mlp_zone_b3 (8 bf16 = 16 bytes per lane and
+    // fragment, stored here as 4 float-sized words).  A operand of v_mfma_f32_32x32x16_bf16: lane (m, hh) element j =
+    // W[32 n + m][k], zone_net_.0: k = 8 hh + j (natural); zone_net_.2: the k order in which relu(Y1)'s accumulator
+    // registers arrive -- k-step s = 2 t + q takes registers 8 q .. 8 q + 7 of tile t:
+    //   k_b3(s, hh, j) = 32 (s / 2) + 16 (s % 2) + (j & 3) + 8 (j >> 2) + 4 hh
+    auto bf16_rne = [](float x) -> uint16_t {
+        uint32_t u;
+        std::memcpy(&u, &x, 4);
+        if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);       // inf / nan: truncate
+        return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    };
+    auto bf16_val = [](uint16_t b) -> float {
+        const uint32_t u = (uint32_t)b << 16;
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
+    auto push_frag = [&](auto ext, int n, auto kof) {       // one fragment pair (hi, lo): 2 x 64 lanes x 8 bf16
+        std::vector<uint16_t> hi(64 * 8), lo(64 * 8);
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const float v = ext(32 * n + (lane & 31), kof(lane >> 5, j));
+                const uint16_t hb = bf16_rne(v);
+                hi[lane * 8 + j] = hb;
+                lo[lane * 8 + j] = bf16_rne(v - bf16_val(hb));
+            }
+        const size_t at = out.size();
+        out.resize(at + 2 * 64 * 4);
+        std::memcpy(&out[at], hi.data(), 64 * 16);
+        std::memcpy(&out[at + 64 * 4], lo.data(), 64 * 16);
+    };
+    offs[21] = out.size();
+    for (int n = 0; n < NT; ++n) push_frag(w1ext, n, [](int hh, int j) { return 8 * hh + j; });
+    offs[22] = out.size();
+    for (int n = 0; n < NT; ++n)
+        for (int s2 = 0; s2 < HP / 16; ++s2)
+            push_frag(w2ext, n, [s2](int hh, int j) { return 32 * (s2 / 2) + 16 * (s2 % 2) + (j & 3) + 8 * (j >> 2) + 4 * hh; });
     return out.size();
 }
 
@@ -524,6 +738,15 @@ hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const fl
     // whatever N is, as long as there is at most one wave per SIMD -- one group per wave up to N = 32 768, two above.
     // Small batches (evaluate(): 500 envs) are faster on the vector-ALU kernel, which spreads 4 envs per workgroup over
     // the chip (0.50 ms at N = 8 192, 0.86 ms at 16 384): crossover N ~ 10 000.
+    if (w.split3 && (w.on_mfma == 2 || (w.on_mfma == 1 && N >= kMfmaMinEnvs))) {
+        // ZENV_MLP_BF16X3: the zone layers as three bf16 products per k-step, the head on the float32 matrix instruction
+        const int epw = N <= 32768 ? 32 : 64;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone_b3),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kZoneLdsB3);
+        hipLaunchKernelGGL(k_mlp_zone_b3, dim3((N + kZoneWaves * epw - 1) / (kZoneWaves * epw)), dim3(kZoneWaves * 64),
+                           kZoneLdsB3, s, w, N, Z, F, obs, zone_obs, mu, stdv, value, value_sigma, act, epw);
+        return hipGetLastError();
+    }
     if (w.on_mfma == 2 || (w.on_mfma == 1 && N >= kMfmaMinEnvs)) {
         // the whole network on the float32 matrix instruction (one workgroup of 4 waves per CU, the two zone layers'
         // images in LDS)

@@ -47,11 +47,13 @@ struct MlpF32 {
     // zone_net_.4 [6][96], combine_net_ [6][100], actor.enc_ [6][96], actor heads [1][96], critic.0 [6][96], critic
     // heads [1][96]
     const float *w1m, *w2m, *w3m, *wcm, *wam, *whm, *wv1m, *whvm;
-    int on_mfma, pad2;          // 0: always the vector-ALU kernel k_mlp_f32 (ZENV_MLP_F32_VALU=1); 2: always the MFMA kernel
-                                // (ZENV_MLP_F32_MFMA=1); 1: by batch size
+    int on_mfma, split3;        // on_mfma 0: always the vector-ALU kernel k_mlp_f32 (ZENV_MLP_F32_VALU=1); 2: always the MFMA
+                                // kernel (ZENV_MLP_F32_MFMA=1); 1: by batch size.  split3: ZENV_MLP_BF16X3 -- the MFMA kernel is
+                                // k_mlp_zone_b3 (zone layers as hi / lo bf16 fragments, three products per k-step)
+    const void *w1b, *w2b;      // k_mlp_zone_b3's images: zone_net_.0 [6][{hi, lo}][64 x 16 B], zone_net_.2 [6][12][{hi, lo}][64 x 16 B]
 };
-// floats needed for the device image and the packer (offsets of the arrays above, in floats, in `offs[21]`)
-size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[21]);
+// floats needed for the device image and the packer (offsets of the arrays above, in floats, in `offs[23]`)
+size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[23]);
 hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const float *obs, const float *zone_obs, float *mu,
                                   float *stdv, float *value, float *value_sigma, const struct MlpAction &act,
                                   hipStream_t s);

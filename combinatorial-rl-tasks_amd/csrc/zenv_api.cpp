@@ -1016,7 +1016,7 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     const int n_sigma = (w->critic_sigma_w != nullptr) + (w->critic_sigma_b != nullptr);
     if (n_sigma == 1 || (n_sigma == 2 && n_critic == 0))
         return fail(ZENV_E_ARG, "the distributional critic needs critic.0, critic_mu (as critic_w2 / _b2) and critic_sigma");
-    if (w->precision != ZENV_MLP_BF16 && w->precision != ZENV_MLP_F32)
+    if (w->precision != ZENV_MLP_BF16 && w->precision != ZENV_MLP_F32 && w->precision != ZENV_MLP_BF16X3)
         return fail(ZENV_E_ARG, "unknown zenv_mlp_weights.precision %d", w->precision);
     std::vector<uint16_t> img;
     size_t offs[8];
@@ -1044,9 +1044,9 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     h->mlp = MlpImages{ base + offs[0], base + offs[1], base + offs[2], base + offs[3], base + offs[4], base + offs[5],
                         n_critic ? base + offs[6] : nullptr, n_critic ? base + offs[7] : nullptr, nullptr,
                         n_sigma == 2 ? 1 : 0 };
-    if (w->precision == ZENV_MLP_F32) {
+    if (w->precision == ZENV_MLP_F32 || w->precision == ZENV_MLP_BF16X3) {
         std::vector<float> f32;
-        size_t fo[21];
+        size_t fo[23];
         pack_f32(*w, h->p.F, f32, fo);
         // (diagnostic: ZENV_MLP_F32_VALU=1 runs the network on the vector ALU, k_mlp_f32, instead of the f32 MFMA)
         // ZENV_MLP_F32_MFMA=1 the MFMA kernel whatever the batch; default: by batch size, see launch_mlp_forward_f32)
@@ -1058,7 +1058,8 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
                              fb + fo[0], fb + fo[1], fb + fo[2], fb + fo[3], fb + fo[4], fb + fo[5], fb + fo[6],
                              fb + fo[7], fb + fo[8], fb + fo[9], n_critic ? fb + fo[10] : nullptr,
                              n_critic ? fb + fo[11] : nullptr, fb + fo[12], fb + fo[13], fb + fo[14], fb + fo[15], fb + fo[16], fb + fo[17], fb + fo[18],
-                             n_critic ? fb + fo[19] : nullptr, n_critic ? fb + fo[20] : nullptr, on_mfma, 0 };
+                             n_critic ? fb + fo[19] : nullptr, n_critic ? fb + fo[20] : nullptr, on_mfma,
+                             w->precision == ZENV_MLP_BF16X3 ? 1 : 0, fb + fo[21], fb + fo[22] };
         h->mlp.f32 = &h->mlp_f32;
     }
     h->mlp_ready = true;

@@ -338,7 +338,7 @@ class ZoneVecEnv:
                 "critic_w1": (h, h), "critic_b1": (h,), "critic_w2": (1, h), "critic_b2": (1,),
                 "critic_sigma_w": (1, h), "critic_sigma_b": (1,)}
         keep = {}
-        w = nat.MlpWeights(h_dim=h, precision={"bf16": nat.MLP_BF16, "f32": nat.MLP_F32}[precision])
+        w = nat.MlpWeights(h_dim=h, precision={"bf16": nat.MLP_BF16, "f32": nat.MLP_F32, "bf16x3": nat.MLP_BF16X3}[precision])
         names = nat.MLP_TENSORS + (nat.MLP_CRITIC_TENSORS if "critic_w1" in tensors else ()) + (
             nat.MLP_SIGMA_TENSORS if "critic_sigma_w" in tensors else ())
         self._mlp_has_critic = "critic_w1" in tensors

@@ -288,8 +288,12 @@ int zenv_route_ranks(const double *robot_xy, const double *zone_xy, int num_zone
  * layout (row-major [out][in]); F = zenv_zone_feat(cfg).  h_dim <= 191 (the reference uses 185). */
 enum {
     ZENV_MLP_BF16 = 0,  /* bf16 MFMA, float32 accumulation: ~20x faster, mu / std within 4e-2 of the reference's float32 */
-    ZENV_MLP_F32 = 1    /* float32 throughout (f32 MFMA / FMA): mu / std / value within 1e-5 of the reference's torch float32 --
+    ZENV_MLP_F32 = 1,   /* float32 throughout (f32 MFMA / FMA): mu / std / value within 1e-5 of the reference's torch float32 --
                          * the mode in which evaluate() with a checkpoint reproduces the reference's arithmetic */
+    ZENV_MLP_BF16X3 = 2 /* float32 accuracy at a third of its time on big batches: the two zone layers (96 % of the
+                         * arithmetic) as three bf16 products per k-step on hi / lo split operands (16 significant bits),
+                         * float32 accumulation, the per-env head in float32; within 1e-5 of torch float32 like ZENV_MLP_F32.
+                         * Batches too small for the matrix kernels (< 10 240 envs) run the float32 vector kernel. */
 };
 typedef struct zenv_mlp_weights {
     int32_t h_dim;

@@ -412,3 +412,50 @@ def test_float32_mfma_kernel_with_two_groups_per_wave(zenv_mod):
     for name, a, b in zip(("mu", "std", "value", "sigma"), out, ref):
         assert a.shape == b.shape and np.isfinite(a).all() and np.abs(a - b).max() <= 1e-5, (name, float(np.abs(a - b).max()))
     env.close()
+
+
+@pytest.mark.parametrize("env_id,n,steps,h", [("PointTSP-v0", 203, 40, 185), ("PointTTSP-v0", 130, 25, 185),
+                                              ("ColourMatch-v0", 77, 60, 185), ("PointTSP-v1", 65, 10, 33),
+                                              ("PointTSP-v4", 9, 30, 191)])
+def test_split_bf16_mode_holds_the_float32_tolerance(zenv_mod, env_id, n, steps, h, monkeypatch):
+    """ZENV_MLP_BF16X3 (k_mlp_zone_b3: the zone layers as hi / lo bf16 operands, three products per k-step; float32
+    head): the same 1e-5 as the float32 mode against the torch float32 restatement, and it is NOT the float32 kernel
+    (the outputs differ in the last bits) nor the plain bf16 one (orders of magnitude closer)."""
+    from oracle import policy_ref as P
+    Z = zenv_mod
+    monkeypatch.setenv("ZENV_MLP_F32_MFMA", "1")       # batches this small default to k_mlp_f32: pin the matrix kernel
+    env = _env_with_obs(Z, env_id, n, steps)
+    for distributional in (False, True):
+        t = P.random_tensors(env.zone_feat, h=h, seed=5, critic=True, distributional=distributional)
+        env.load_mlp(t, precision="bf16x3")
+        out = env.mlp_forward(with_value=True)
+        obs, zo = env.observations()
+        ref = P.forward_fp32(t, obs, zo)
+        assert len(out) == len(ref) == (4 if distributional else 3)
+        for name, a, b in zip(("mu", "std", "value", "sigma"), out, ref):
+            assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-5, (name, float(np.abs(a - b).max()))
+    env.load_mlp(t, precision="f32")
+    out32 = env.mlp_forward(with_value=True)
+    assert 0 < np.abs(out32[2] - out[2]).max() <= 2e-5
+    env.policy(Z.POLICY_MLP_MEAN)
+    env.load_mlp(t, precision="bf16x3")
+    env.policy(Z.POLICY_MLP_MEAN)
+    assert np.array_equal(env.get(Z.F_ACTIONS), out[0])
+    env.close()
+
+
+def test_split_bf16_mode_on_the_full_batch_layout(zenv_mod):
+    """N > 32 768 (two groups of 32 envs per wave, ragged last workgroup), default kernel choice by batch size."""
+    from oracle import policy_ref as P
+    Z = zenv_mod
+    n = 32768 + 200 + 17
+    for env_id in ("ColourMatch-v0", "PointTTSP-v0"):
+        env = _env_with_obs(Z, env_id, n, 30)
+        t = P.random_tensors(env.zone_feat, h=185, seed=11, distributional=True)
+        env.load_mlp(t, precision="bf16x3")
+        out = env.mlp_forward(with_value=True)
+        obs, zo = env.observations()
+        ref = P.forward_fp32(t, obs, zo)
+        for name, a, b in zip(("mu", "std", "value", "sigma"), out, ref):
+            assert a.shape == b.shape and np.isfinite(a).all() and np.abs(a - b).max() <= 1e-5, (name, float(np.abs(a - b).max()))
+        env.close()
