@@ -749,7 +749,17 @@ def mlp_policy_rate(env, zones, steps=300):
         env.load_mlp(t, precision="f32")
         env.rollout(5, Z.POLICY_MLP_SAMPLE, policy_seed=1)
         ms32, _ = env.rollout(20, Z.POLICY_MLP_SAMPLE, policy_seed=1)
-        return {"us_per_step": round(us, 1), "f32_mode_us_per_step": round(ms32 / 20 * 1e3, 1), "env_steps_per_s": round(n * steps / (ms * 1e-3), 1),
+        # the float32-grade modes on the 16-bit matrix instruction (hi / lo split operands, three products per k-step):
+        # ZENV_MLP_F16X3 within 3e-6 of torch float32, ZENV_MLP_BF16X3 within 2e-5
+        split = {}
+        for prec in ("f16x3", "bf16x3"):
+            env.load_mlp(t, precision=prec)
+            env.rollout(5, Z.POLICY_MLP_SAMPLE, policy_seed=1)
+            msx, _ = env.rollout(40, Z.POLICY_MLP_SAMPLE, policy_seed=1)
+            split[prec + "_mode_us_per_step"] = round(msx / 40 * 1e3, 1)
+        env.load_mlp(t)
+        return {"us_per_step": round(us, 1), "f32_mode_us_per_step": round(ms32 / 20 * 1e3, 1), **split,
+                "env_steps_per_s": round(n * steps / (ms * 1e-3), 1),
                 "network_gflop_per_step": round(flop / 1e9, 1), "dtype": "bf16 MFMA, f32 accumulate",
                 "network_tflops_incl_env_step": round(flop / (us * 1e-6) / 1e12, 1), "mfma_peak_tflops": 2500.0,
                 # a bare v_mfma_f32_32x32x16_bf16 chain on every SIMD with random operands: the power controller

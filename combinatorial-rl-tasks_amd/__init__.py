@@ -9,7 +9,7 @@ Layout of this package (only what the hot path needs):
   penv.py      ParallelEnv-shaped vector env over one batched handle
   sharding.py  one-process-per-GPU env sharding + gather of episodic returns
 """
-from ._native import (Config, ZenvError, TASK_TSP, TASK_TIMED_TSP, TASK_COLOUR_MATCH,
+from ._native import (Config, ZenvError, E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE, E_RANGE, TASK_TSP, TASK_TIMED_TSP, TASK_COLOUR_MATCH,
                       POLICY_UNIFORM, POLICY_GREEDY, POLICY_MLP_MEAN, POLICY_MLP_SAMPLE, F_OBS, F_ZONE_OBS, F_REWARD, F_DONE,
                       F_GOAL_MET, F_EP_RETURN, F_EP_LEN, F_LAST_RETURN, F_LAST_LEN, F_EPISODES,
                       F_VISIT_COUNT, F_SEED, F_ACTIONS, F_POLICY_MU, F_POLICY_STD, F_POLICY_VALUE,

@@ -24,7 +24,7 @@ ROLLOUT_ASYNC = 4
 ROLLOUT_CHUNK = 256
 COMM_ID_BYTES = 128
 
-E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE = -1, -2, -3, -4, -5
+E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE, E_RANGE = -1, -2, -3, -4, -5, -6
 
 (F_OBS, F_ZONE_OBS, F_REWARD, F_DONE, F_GOAL_MET, F_EP_RETURN, F_EP_LEN, F_LAST_RETURN,
  F_LAST_LEN, F_EPISODES, F_VISIT_COUNT, F_SEED, F_ACTIONS, F_POLICY_MU, F_POLICY_STD, F_POLICY_VALUE,
@@ -39,7 +39,7 @@ MLP_TENSORS = ("zone_w1", "zone_b1", "zone_w2", "zone_b2", "zone_w3", "zone_b3",
                "enc_w", "enc_b", "mu_w", "mu_b", "std_w", "std_b")
 MLP_CRITIC_TENSORS = ("critic_w1", "critic_b1", "critic_w2", "critic_b2")   # optional, all or none
 MLP_SIGMA_TENSORS = ("critic_sigma_w", "critic_sigma_b")   # optional: the distributional critic (critic_w2 = critic_mu)
-MLP_BF16, MLP_F32, MLP_BF16X3 = 0, 1, 2
+MLP_BF16, MLP_F32, MLP_BF16X3, MLP_F16X3 = 0, 1, 2, 3
 
 
 class MlpWeights(C.Structure):

@@ -24,6 +24,7 @@
 //    takes the per-env zone sums from a float32 array instead of computing them.)
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 
 #include "mlp_head_out.hpp"
@@ -391,67 +392,289 @@ void k_mlp_zone_f32m(MlpF32 w, int N, int Z, int F, const float *__restrict__ ob
     }
 }
 
-// ------------------------------------------------------------------------------------------ zone part on bf16 x 3
-// ZENV_MLP_BF16X3: the two zone layers -- 96 % of the network's arithmetic -- on the bf16 matrix instruction with every
-// operand written as hi + lo (x_hi = bf16(x), x_lo = bf16(x - x_hi); the weights split the same way on the host) and
-// three products per k-step, hi*hi + hi*lo + lo*hi, accumulated in float32 by the instruction: 16 significant bits per
-// operand instead of 8.  scripts/split_bf16_frontier.py (torch emulation against the float32 restatement of the
-// reference's modules): max |d mu| 3.7e-6, |d std| 2.0e-6, |d value| 7.8e-6 with ALL layers split -- inside the 1e-5 the
-// float32 mode is held to -- and the per-env head here stays on the float32 matrix instruction (head_layer_f32m), so
-// only the zone layers carry the split's error.  v_mfma_f32_32x32x16_bf16 does 8 times the k depth of
-// v_mfma_f32_32x32x2_f32 in half its cycles: 3 products cost 3/16 of the float32 kernel's matrix time.
+// ------------------------------------------------------------------------------------------ the network on split operands
+// ZENV_MLP_BF16X3 / ZENV_MLP_F16X3: the 16-bit matrix instruction with every operand written as hi + lo
+// (x_hi = round16(x), x_lo = round16(x - x_hi); the weights split the same way on the host) and three products per
+// k-step, hi*hi + hi*lo + lo*hi, accumulated in float32 by the instruction.  v_mfma_f32_32x32x16_{bf16,f16} does 8 times
+// the k depth of v_mfma_f32_32x32x2_f32 in half its cycles: 3 products cost 3/16 of the float32 kernel's matrix time.
+//   bf16 halves: 8 + 8 = 16 significant bits, float32's exponent range.  scripts/split_bf16_frontier.py (torch
+//     emulation against the float32 restatement of the reference's modules) with ALL layers split: max |d mu| 3.7e-6,
+//     |d std| 2.0e-6, |d value| 7.8e-6 -- right at the 1e-5 the float32 mode is held to, so in this mode only the two
+//     zone layers (96 % of the arithmetic) are split and the per-env head stays on the float32 matrix instruction
+//     (head_layer_f32m); on the device: up to 1.1e-5 on the test matrix, stated as 2e-5.
+//   f16 halves: 11 + 11 = 22 bits (subnormal lo halves are kept by the matrix pipe: scripts/probes/mfma_f16_denorm.hip),
+//     the same emulation: 2.4e-7 / 1.8e-7 / 4.8e-7, the float32 accumulation's own noise -- so here the head is split
+//     too.  The price is float16's range: an operand of 65 520 or more becomes inf.  Weights are checked when they are
+//     loaded; activations are watched by the kernel (the running v_pk_max_f16 over every hi half it makes costs one
+//     instruction per two values) and a hit sets MlpF32::range_flag, which the next synchronising call reports as
+//     ZENV_E_RANGE.
 //
 // Same shape as k_mlp_zone_f32m: one wave per 64 envs (two groups of 32), tile t = zone t of the group's 32 envs,
 // Y = W X with the feature in the accumulator registers and the env on the lane, so relu(Y1) -- split into hi / lo
 // fragments, registers 0-7 -> k-step 2m, 8-15 -> k-step 2m + 1 of output tile m -- IS layer 2's B operand when W2's
 // fragments are packed in that k order (pack_f32: k_b3), and the per-env sum over the zone rows is a register-wise add
-// into P[], which the float32 head takes over as it stands.  LDS: W2 hi + lo (2 x 72 KiB) and W1 hi + lo (2 x 6 KiB) =
-// 159 744 B, one workgroup per CU.
+// into P[].  LDS: W2 hi + lo (2 x 72 KiB) and W1 hi + lo (2 x 6 KiB) = 159 744 B, one workgroup per CU.
+//
+// The zone loop is software-pipelined by hand (zone_tile): while the matrix pipe works through one k-step pair of the
+// second layer, the vector ALU -- idle otherwise -- makes the next pair from the first layer's next output tile (ReLU,
+// hi / lo split) and folds finished accumulators into P; the zone row of tile t + 2 is already on its way from memory.
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16v __attribute__((__vector_size__(16 * sizeof(float))));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4 gu32x4;
 constexpr int KSB = HP / 16;                       // 12 k-steps (K = 16) per hidden layer
-constexpr size_t kZoneLdsB3 = (size_t)(NT * KSB + NT) * 2 * 64 * 16;   // (72 + 6) fragments x {hi, lo} x 1 KiB = 159 744 B
+constexpr size_t kZoneLdsS3 = (size_t)(NT * KSB + NT) * 2 * 64 * 16;   // (72 + 6) fragments x {hi, lo} x 1 KiB = 159 744 B
 
-__device__ __forceinline__ f32x16v mfma_bf(const uint4 a, const uint4 b, const f32x16v c)
+template <bool F16>
+__device__ __forceinline__ f32x16v mfma_s(const u32x4 a, const u32x4 b, const f32x16v c)
 {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
-// (a, b) -> one dword of their bf16 roundings (hi) and one of the roundings of what is left (lo)
-__device__ __forceinline__ void split_pair(float a, float b, uint32_t &hi, uint32_t &lo)
+// max(x, 0) as an integer maximum of the bit patterns (negative floats are negative integers; -0 is the most negative).
+// fmaxf() -- and the median with 0 and +inf, which the compiler folds back into it -- first quiets its argument: a second
+// v_max_f32 per value, 200 per zone tile on a vector ALU that has to keep up with the matrix pipe.
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+__device__ __forceinline__ f32x16v zero16()
+{
+    f32x16v z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+// (a, b) -> one dword of their 16-bit roundings (hi) and one of the roundings of what is left (lo).  F16: mx keeps the
+// largest |hi| seen (ABS false: the values are known to be >= 0)
+template <bool F16, bool ABS>
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t &hi, uint32_t &lo, uint32_t &mx)
 {
     const f32x2v v = { a, b };
-    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
-    const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xFFFF0000u);
-    const f32x2v r = { a - ah, b - bh };
-    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2v));
+    if constexpr (F16) {
+        const f16x2v hv = __builtin_convertvector(v, f16x2v);
+        hi = __builtin_bit_cast(uint32_t, hv);
+        const f32x2v r = v - __builtin_convertvector(hv, f32x2v);          // one v_pk_add_f32
+        lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2v));
+        const uint32_t mag = ABS ? (hi & 0x7FFF7FFFu) : hi;
+        mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(f16x2v, mx), __builtin_bit_cast(f16x2v, mag)));
+    } else {
+        hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
+        const f32x2v hf = { __uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u) };
+        const f32x2v r = v - hf;
+        lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2v));
+    }
 }
-__device__ __forceinline__ void split8(const float *v, uint4 &hi, uint4 &lo)
+template <bool F16, bool ABS>
+__device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo, uint32_t &mx)
 {
-    split_pair(v[0], v[1], hi.x, lo.x);
-    split_pair(v[2], v[3], hi.y, lo.y);
-    split_pair(v[4], v[5], hi.z, lo.z);
-    split_pair(v[6], v[7], hi.w, lo.w);
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    split_pair<F16, ABS>(v[0], v[1], h0, l0, mx);
+    split_pair<F16, ABS>(v[2], v[3], h1, l1, mx);
+    split_pair<F16, ABS>(v[4], v[5], h2, l2, mx);
+    split_pair<F16, ABS>(v[6], v[7], h3, l3, mx);
+    hi = u32x4{ h0, h1, h2, h3 };
+    lo = u32x4{ l0, l1, l2, l3 };
+}
+// relu (or not) of a finished accumulator tile -> its two hi / lo fragment pairs (registers 0-7, 8-15)
+template <bool F16, bool RELU>
+__device__ __forceinline__ void split_tile(const f32x16v acc, u32x4 &h0, u32x4 &l0, u32x4 &h1, u32x4 &l1, uint32_t &mx)
+{
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = RELU ? relu1(acc[i]) : acc[i];
+    split8<F16, !RELU>(v, h0, l0, mx);
+    split8<F16, !RELU>(v + 8, h1, l1, mx);
 }
 
+// One zone tile, k-step-major: relu(Y1) is never held whole.  Step n turns output tile n of zone_net_.0 into the two
+// hi / lo fragment pairs X = (h[2], l[2]) -- k-steps 2 n, 2 n + 1 of zone_net_.2 -- which go straight into all six of
+// its output accumulators (6 chunks of 6 matrix instructions), while the vector ALU prepares step n + 1: zone_net_.0's
+// tile n + 1 (for n = 5: tile 0 of the NEXT zone, from its input pair x0n) in chunk 0, its ReLU and split spread over
+// chunks 1-5.  acc[] is finished at the end of the call; P[j] += relu(acc[j]) is done in chunk j - 1 of the next call,
+// right before chunk j starts acc[j] afresh (P[0]: in the last two chunks of this one; the caller does the very last
+// P[1..5]).  One wave per SIMD: nothing else hides the vector work, so every chunk's instructions are laid out
+// explicitly -- per matrix instruction one LDS read and up to five vector instructions (sched_group_barrier) -- instead
+// of the scheduler's choice, all vector work first and the matrix instructions back to back after it.
+struct XFrag {
+    u32x4 h[2], l[2];
+};
+typedef __attribute__((address_space(3))) u32x4 lu32x4;
+// fragment pair f of an LDS image, half i (0 hi, 1 lo): 1 KiB each; three bases 60 KiB apart keep every offset inside
+// ds_read_b128's 16-bit immediate
+__device__ __forceinline__ u32x4 lds_frag(const lu32x4 *const (&lb)[3], int f, int i)
+{
+    const int off = (f * 2 + i) * 64, k = off / 3840;      // in 16-byte units: 3840 = 60 KiB
+    return lb[k][off - k * 3840];
+}
+template <int MFMAS>
+__device__ __forceinline__ void interleave()
+{
+#pragma unroll
+    for (int m = 0; m < MFMAS; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one matrix instruction,
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read,
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);      // five vector instructions
+    }
+}
+template <bool F16>
+__device__ __forceinline__ void zone_tile(const lu32x4 *const (&lb)[3], int lane, XFrag &x, const u32x4 x0h,
+                                          const u32x4 x0l, const u32x4 x0nh, const u32x4 x0nl, f32x16 (&P)[NT],
+                                          f32x16v (&acc)[NT], u32x4 (&wa)[2][2][2], u32x4 (&w1)[2], uint32_t &mx)
+{
+    constexpr int W1F = NT * KSB;       // zone_net_.0's fragment pairs follow zone_net_.2's
+    f32x16v a1 = zero16();
+    XFrag xn;
+#pragma unroll
+    for (int c = 0; c < NT * NT; ++c) {
+        const int n = c / NT, n2 = c % NT;          // step (= k-step pair) n, output tile n2
+        {                                           // the next chunk's fragments (chunk 36 = chunk 0 of the next call)
+            const int cn = (c + 1) % (NT * NT), nn = cn / NT, nn2 = cn % NT;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                wa[(c + 1) & 1][q][0] = lds_frag(lb, nn2 * KSB + 2 * nn + q, 0);
+                wa[(c + 1) & 1][q][1] = lds_frag(lb, nn2 * KSB + 2 * nn + q, 1);
+            }
+            if (nn2 == 0) {                         // ... and zone_net_.0's pair for the tile made in that chunk
+                w1[0] = lds_frag(lb, W1F + (nn + 1) % NT, 0);
+                w1[1] = lds_frag(lb, W1F + (nn + 1) % NT, 1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (constant trip counts with the chunk's share picked by a condition: bounds that depend on c would keep these
+        // loops from unrolling before the chunk loop does, and the vectors they index would go to scratch)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const bool mine = j == 0 ? (n == NT - 1 && ((n2 == NT - 2 && i < 8) || (n2 == NT - 1 && i >= 8)))
+                                         : (n == 0 && n2 == j - 1);
+                if (mine) {
+                    const f32x2v sum = f32x2v{ P[j][i], P[j][i + 1] } + f32x2v{ relu1(acc[j][i]), relu1(acc[j][i + 1]) };
+                    P[j][i] = sum[0];
+                    P[j][i + 1] = sum[1];
+                }
+            }
+        if (n2 == 0) {                              // zone_net_.0's next output tile
+            const u32x4 ah = w1[0], al = w1[1];
+            const u32x4 bh = n + 1 < NT ? x0h : x0nh, bl = n + 1 < NT ? x0l : x0nl;
+            a1 = mfma_s<F16>(ah, bh, zero16());
+            a1 = mfma_s<F16>(ah, bl, a1);
+            a1 = mfma_s<F16>(al, bh, a1);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {            // its ReLU and split: value pairs 0-1, 2-3, 4-5, 6, 7 in chunks 1-5
+            const int at = pr < 6 ? 1 + pr / 2 : pr - 2;
+            if (n2 == at) {
+                uint32_t hi, lo;
+                split_pair<F16, false>(relu1(a1[2 * pr]), relu1(a1[2 * pr + 1]), hi, lo, mx);
+                xn.h[pr >> 2][pr & 3] = hi;
+                xn.l[pr >> 2][pr & 3] = lo;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            acc[n2] = mfma_s<F16>(wa[c & 1][q][0], x.h[q], (n == 0 && q == 0) ? zero16() : acc[n2]);
+            acc[n2] = mfma_s<F16>(wa[c & 1][q][0], x.l[q], acc[n2]);
+            acc[n2] = mfma_s<F16>(wa[c & 1][q][1], x.h[q], acc[n2]);
+        }
+        if (n2 == 0) interleave<9>(); else interleave<6>();
+        if (n2 == NT - 1) x = xn;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Y = W [obs; X] for a 32-env group with X given as hi / lo fragments and Y returned the same way: TILES output tiles
+// of KSB (+ 1 leading, the obs in natural order) k-steps, three matrix instructions each.  The fragments come from L2
+// through a ring of D k-steps (2 KiB each per wave), loaded D steps ahead across tile boundaries; done(n, acc) takes
+// every finished tile.
+template <bool F16, bool OBS, int TILES, typename Done>
+__device__ __forceinline__ void head_product(const void *img, int lane, const u32x4 (&xh)[KSB], const u32x4 (&xl)[KSB],
+                                             const u32x4 xoh, const u32x4 xol, Done done)
+{
+    constexpr int KT = KSB + (OBS ? 1 : 0), S = TILES * KT, D = 12;
+    const gu32x4 *pl = (const gu32x4 *)img + lane;       // runs D steps ahead of the arithmetic; opaque to the compiler so
+    u32x4 ring[D][2];                                    // that every load is (pointer, immediate offset)
+#pragma unroll
+    for (int g = 0; g < D && g < S; ++g) {
+        ring[g][0] = pl[0];
+        ring[g][1] = pl[64];
+        pl += 128;
+        asm volatile("" : "+v"(pl));
+    }
+    f32x16v acc = zero16();
+#pragma unroll
+    for (int g = 0; g < S; ++g) {
+        const int n = g / KT, s = g % KT;
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4 bh = (OBS && s == 0) ? xoh : xh[s - (OBS ? 1 : 0)], bl = (OBS && s == 0) ? xol : xl[s - (OBS ? 1 : 0)];
+        acc = mfma_s<F16>(ring[g % D][0], bh, s == 0 ? zero16() : acc);
+        acc = mfma_s<F16>(ring[g % D][0], bl, acc);
+        acc = mfma_s<F16>(ring[g % D][1], bh, acc);
+        if (g + D < S) {
+            ring[g % D][0] = pl[0];
+            ring[g % D][1] = pl[64];
+            pl += 128;
+            asm volatile("" : "+v"(pl));
+        }
+        if (s == KT - 1) done(n, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <bool F16, bool OBS, bool RELU>
+__device__ __forceinline__ void head_layer_s3(const void *img, int lane, const u32x4 (&xh)[KSB], const u32x4 (&xl)[KSB],
+                                              const u32x4 xoh, const u32x4 xol, u32x4 (&yh)[KSB], u32x4 (&yl)[KSB],
+                                              uint32_t &mx)
+{
+    head_product<F16, OBS, NT>(img, lane, xh, xl, xoh, xol, [&](int n, const f32x16v acc) __attribute__((always_inline)) {
+        split_tile<F16, RELU>(acc, yh[2 * n], yl[2 * n], yh[2 * n + 1], yl[2 * n + 1], mx);
+    });
+}
+template <bool F16>
+__device__ __forceinline__ f32x16v head_rows_s3(const void *img, int lane, const u32x4 (&xh)[KSB], const u32x4 (&xl)[KSB])
+{
+    f32x16v out = zero16();
+    const u32x4 none = { 0u, 0u, 0u, 0u };
+    head_product<F16, false, 1>(img, lane, xh, xl, none, none, [&](int, const f32x16v acc) __attribute__((always_inline)) { out = acc; });
+    return out;
+}
+
+template <bool F16>
 __global__ __launch_bounds__(kZoneWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_mlp_zone_b3(MlpF32 w, int N, int Z, int F, const float *__restrict__ obs, const float *__restrict__ zone_obs,
+void k_mlp_zone_s3(MlpF32 w, int N, int Z, int F, const float *__restrict__ obs, const float *__restrict__ zone_obs,
                    float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value,
                    float *__restrict__ value_sigma, MlpAction act, int envs_per_wave)
 {
-    extern __shared__ __align__(16) uint4 zb[];
-    uint4 *w2s = zb;                              // [NT][KSB][2][64]   fragment (n, s): hi, then lo
-    uint4 *w1s = zb + NT * KSB * 2 * 64;          // [NT][2][64]
+    extern __shared__ __align__(16) u32x4 zs[];
+    // zs: zone_net_.2's fragment pairs [NT][KSB][{hi, lo}][64], then zone_net_.0's [NT][{hi, lo}][64]
     {
-        const uint4 *s2 = reinterpret_cast<const uint4 *>(w.w2b), *s1 = reinterpret_cast<const uint4 *>(w.w1b);
-        for (int i = threadIdx.x; i < NT * KSB * 2 * 64; i += kZoneWaves * 64) w2s[i] = s2[i];
-        for (int i = threadIdx.x; i < NT * 2 * 64; i += kZoneWaves * 64) w1s[i] = s1[i];
+        // the images sit back to back in memory in the order they have in LDS (pack_f32): one copy of 39 x 4 KiB, 13 loads
+        // in flight per thread (one after the other, each round trip to L2 would cost as much as eight zone tiles)
+        const gu32x4 *src = (const gu32x4 *)(F16 ? w.w2h : w.w2b) + threadIdx.x;
+        constexpr int PER_THREAD = (NT * KSB + NT) * 2 * 64 / (kZoneWaves * 64), BATCH = 13;
+        static_assert(PER_THREAD % BATCH == 0, "39 = 3 x 13");
+#pragma unroll 1
+        for (int b0 = 0; b0 < PER_THREAD; b0 += BATCH) {
+            u32x4 v[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) v[k] = src[(b0 + k) * kZoneWaves * 64];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) zs[(b0 + k) * kZoneWaves * 64 + threadIdx.x] = v[k];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int env0 = (blockIdx.x * kZoneWaves + wave) * envs_per_wave;
+    // the lane's window on the images: three bases, opaque to the compiler so that it keeps them (see lds_frag)
+    const lu32x4 *lb0 = (const lu32x4 *)zs + lane, *lb1 = lb0 + 3840, *lb2 = lb0 + 7680;
+    asm volatile("" : "+v"(lb0), "+v"(lb1), "+v"(lb2));
+    const lu32x4 *const lb[3] = { lb0, lb1, lb2 };
+    constexpr int W1F = NT * KSB;
+    uint32_t mx = 0u;                             // F16: the largest |hi half| this lane has made, as two f16
     for (int e_base = 0; e_base < envs_per_wave && env0 + e_base < N; e_base += 32) {
         const bool valid = env0 + e_base + r < N;
         const int env = valid ? env0 + e_base + r : env0;
@@ -459,115 +682,124 @@ void k_mlp_zone_b3(MlpF32 w, int N, int Z, int F, const float *__restrict__ obs,
         float xo[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) xo[s] = valid ? obs[(size_t)env * 8 + 2 * s + h] : 0.f;
-        // ... and layer 1's: lane half 0 carries k = 0..7 = the env's obs (the same for every tile of the group)
-        uint4 xoh = make_uint4(0u, 0u, 0u, 0u), xol = make_uint4(0u, 0u, 0u, 0u);
+        // ... and the split products': lane half 0 carries k = 0..7 = the env's obs, half 1 nothing
+        u32x4 xoh = { 0u, 0u, 0u, 0u }, xol = { 0u, 0u, 0u, 0u };
         if (h == 0 && valid) {
             const float4 *o4 = reinterpret_cast<const float4 *>(obs + (size_t)env * 8);
             const float4 a = o4[0], b = o4[1];
             const float v8[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
-            split8(v8, xoh, xol);
+            split8<F16, true>(v8, xoh, xol, mx);
         }
+        // layer 1's B operand of tile t: k = 8 h + j; half 0 = the obs pair above, half 1 = the zone row (k = 8 ..
+        // 8 + F - 1), zeros, the constant 1 (k = 15).  Rows are fetched two tiles ahead of their use.
+        const float *rows = zone_obs + (size_t)env * Z * F;
+        auto fetch_row = [&](int t, float (&v)[8]) {
+            const float *row = rows + (size_t)(t < Z ? t : Z - 1) * F;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = (h == 1 && valid && j < F) ? row[j] : 0.f;
+            v[7] = 1.0f;
+        };
+        auto input_pair = [&](const float (&v)[8], u32x4 &x0h, u32x4 &x0l) {
+            u32x4 zh, zl;
+            split8<F16, true>(v, zh, zl, mx);
+            x0h = h == 1 ? zh : xoh;
+            x0l = h == 1 ? zl : xol;
+        };
         f32x16 P[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int i = 0; i < 16; ++i) P[n][i] = 0.f;
-        for (int t = 0; t < Z; ++t) {
-            // ---- layer 1's B operand: k = 8 h + j; half 1 = the zone row (k = 8 .. 8 + F - 1), zeros, the constant 1 (k = 15)
-            uint4 x0h = xoh, x0l = xol;
-            if (h == 1) {
-                const float *row = zone_obs + ((size_t)env * Z + t) * F;
-                float v8[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v8[j] = (valid && j < F) ? row[j] : 0.f;
-                v8[7] = 1.0f;
-                split8(v8, x0h, x0l);
-            }
-            // ---- zone_net_.0 + ReLU, split into layer 2's hi / lo B fragments
-            uint4 xh[KSB], xl[KSB];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const uint4 ah = w1s[(n * 2 + 0) * 64 + lane], al = w1s[(n * 2 + 1) * 64 + lane];
-                f32x16v acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                acc = mfma_bf(ah, x0h, acc);
-                acc = mfma_bf(ah, x0l, acc);
-                acc = mfma_bf(al, x0h, acc);
-                float v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
-                split8(v, xh[2 * n], xl[2 * n]);
-                split8(v + 8, xh[2 * n + 1], xl[2 * n + 1]);
-            }
-            // ---- zone_net_.2 + ReLU, summed over the tiles.  Output tile n2: 12 k-steps x 3 products on one accumulator;
-            // the fragments of k-steps s + 2, s + 3 are read from LDS while those of s, s + 1 are in the matrix pipe
-            // (explicit double buffer between scheduling barriers, as in k_mlp_zone_f32m)
-            uint4 wa[2][2][2];          // [buffer][k-step of the pair][hi, lo]
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                wa[0][q][0] = w2s[((0 * KSB + q) * 2 + 0) * 64 + lane];
-                wa[0][q][1] = w2s[((0 * KSB + q) * 2 + 1) * 64 + lane];
-            }
-            f32x16v acc;
-#pragma unroll
-            for (int c = 0; c < NT * (KSB / 2); ++c) {
-                const int n2 = c / (KSB / 2), sc = c % (KSB / 2);
-                if (c + 1 < NT * (KSB / 2)) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        wa[(c + 1) & 1][q][0] = w2s[(((c + 1) * 2 + q) * 2 + 0) * 64 + lane];
-                        wa[(c + 1) & 1][q][1] = w2s[(((c + 1) * 2 + q) * 2 + 1) * 64 + lane];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (sc == 0) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int s = 2 * sc + q;
-                    acc = mfma_bf(wa[c & 1][q][0], xh[s], acc);
-                    acc = mfma_bf(wa[c & 1][q][0], xl[s], acc);
-                    acc = mfma_bf(wa[c & 1][q][1], xh[s], acc);
-                }
-                if (sc == KSB / 2 - 1) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) P[n2][i] += fmaxf(acc[i], 0.f);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        float rowv[8];
+        u32x4 x0h, x0l, x0nh, x0nl;
+        fetch_row(0, rowv);
+        input_pair(rowv, x0h, x0l);
+        fetch_row(1, rowv);
+        XFrag x;
+        {
+            const u32x4 wh = lds_frag(lb, W1F, 0), wl = lds_frag(lb, W1F, 1);
+            f32x16v a = mfma_s<F16>(wh, x0h, zero16());
+            a = mfma_s<F16>(wh, x0l, a);
+            split_tile<F16, true>(mfma_s<F16>(wl, x0h, a), x.h[0], x.l[0], x.h[1], x.l[1], mx);
         }
-        // ---- the per-env head on the float32 matrix instruction, exactly as in k_mlp_zone_f32m
+        f32x16v acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = zero16();
+        u32x4 wa[2][2][2];                 // [buffer][k-step of the pair][hi, lo], chunk 0 to start with
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            wa[0][q][0] = lds_frag(lb, q, 0);
+            wa[0][q][1] = lds_frag(lb, q, 1);
+        }
+        u32x4 w1[2] = { lds_frag(lb, W1F + 1, 0), lds_frag(lb, W1F + 1, 1) };   // chunk 0 makes zone_net_.0's tile 1
+        for (int t = 0; t < Z; ++t) {
+            input_pair(rowv, x0nh, x0nl);                // zone t + 1's (the last one: a clamped row, never used)
+            fetch_row(t + 2, rowv);
+            zone_tile<F16>(lb, lane, x, x0h, x0l, x0nh, x0nl, P, acc, wa, w1, mx);
+            x0h = x0nh;
+            x0l = x0nl;
+        }
         const float inv_z = 1.0f / (float)Z;
+#pragma unroll
+        for (int j = 1; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) P[j][i] += relu1(acc[j][i]);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) P[n][i] *= inv_z;
-        f32x16 e3[NT], cc[NT];
-        head_layer_f32m<4, false>(w.wcm, lane, P, xo, cc);
-        float v_mu = 0.f, v_sigma = 0.f;
-        if (w.has_critic) {
-            head_layer_f32m<0, true>(w.wv1m, lane, cc, xo, e3);
-            f32x16 hv = head_rows_f32m(w.whvm, lane, e3);
-            v_mu = hv[0];
-            v_sigma = hv[1];
+            for (int i = 0; i < 16; ++i) P[n][i] *= inv_z;              // the mean; its feature h_dim is the constant 1
+        u32x4 ah[KSB], al[KSB], bh[KSB], bl[KSB];
+        float v_mu = 0.f, v_sigma = 0.f, m0, m1, s0, s1;
+        if constexpr (F16) {
+            // ---- the per-env head on split operands as well: zone_net_.4 folded into combine_net_ (pack_f32), critic.0 +
+            // critic heads, actor.enc_ + actor heads; (ah, al) / (bh, bl) are free again
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                f32x16v pv;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pv[i] = P[n][i];
+                split_tile<true, true>(pv, ah[2 * n], al[2 * n], ah[2 * n + 1], al[2 * n + 1], mx);    // means of ReLUs: >= 0
+            }
+            head_layer_s3<true, true, false>(w.wch, lane, ah, al, xoh, xol, bh, bl, mx);              // c
+            if (w.has_critic) {
+                head_layer_s3<true, false, true>(w.wv1h, lane, bh, bl, xoh, xol, ah, al, mx);         // relu(critic.0(c))
+                const f32x16v hv = head_rows_s3<true>(w.whvh, lane, ah, al);
+                v_mu = hv[0];
+                v_sigma = hv[1];
+            }
+            head_layer_s3<true, false, true>(w.wah, lane, bh, bl, xoh, xol, ah, al, mx);              // relu(actor.enc_(c))
+            const f32x16v hd = head_rows_s3<true>(w.whh, lane, ah, al);
+            m0 = hd[0], m1 = hd[1], s0 = hd[2], s1 = hd[3];
+        } else {
+            // ---- the per-env head on the float32 matrix instruction, exactly as in k_mlp_zone_f32m
+            f32x16 e3[NT], cc[NT];
+            head_layer_f32m<4, false>(w.wcm, lane, P, xo, cc);
+            if (w.has_critic) {
+                head_layer_f32m<0, true>(w.wv1m, lane, cc, xo, e3);
+                const f32x16 hv = head_rows_f32m(w.whvm, lane, e3);
+                v_mu = hv[0];
+                v_sigma = hv[1];
+            }
+            head_layer_f32m<0, true>(w.wam, lane, cc, xo, e3);
+            const f32x16 hd = head_rows_f32m(w.whm, lane, e3);
+            m0 = hd[0], m1 = hd[1], s0 = hd[2], s1 = hd[3];
         }
-        head_layer_f32m<0, true>(w.wam, lane, cc, xo, e3);
-        const f32x16 hd = head_rows_f32m(w.whm, lane, e3);
         if (h == 0 && valid) {
             if (w.has_critic) {
                 value[env] = v_mu;
                 if (w.distributional && value_sigma) value_sigma[env] = softplus03(v_sigma) + 1e-3f;
             }
-            head_outputs(env, hd[0], hd[1], hd[2], hd[3], v_mu, mu, stdv, act);
+            head_outputs(env, m0, m1, s0, s1, v_mu, mu, stdv, act);
         }
+    }
+    if constexpr (F16) {
+        // an operand of 65 520 or more became inf on its way to float16: tell the host (pinned memory; read at its next sync)
+        if (((mx & 0x7FFFu) >= 0x7C00u || (mx >> 16 & 0x7FFFu) >= 0x7C00u) && w.range_flag) *w.range_flag = 1;
     }
 }
 }  // namespace
 
-size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[23])
+size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[30])
 {
     const int h = w.h_dim;
     out.clear();
@@ -691,10 +923,11 @@ size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_
         offs[19] = pack_hidden(hidden(w.critic_w1, w.critic_b1, 0, h), nullptr, 0);
         offs[20] = pack_rows({ { w.critic_w2, w.critic_b2 }, { w.critic_sigma_w, w.critic_sigma_b } });
     }
-    // ---- ZENV_MLP_BF16X3: the two zone layers as bf16 hi / lo fragments for k_mlp_zone_b3 (8 bf16 = 16 bytes per lane and
-    // fragment, stored here as 4 float-sized words).  A operand of v_mfma_f32_32x32x16_bf16: lane (m, hh) element j =
-    // W[32 n + m][k], zone_net_.0: k = 8 hh + j (natural); zone_net_.2: the k order in which relu(Y1)'s accumulator
-    // registers arrive -- k-step s = 2 t + q takes registers 8 q .. 8 q + 7 of tile t:
+    // ---- ZENV_MLP_BF16X3 / ZENV_MLP_F16X3: hi / lo fragment pairs for k_mlp_zone_s3 (8 halves = 16 bytes per lane and
+    // fragment, stored here as 4 float-sized words; a pair = 64 x 16 B of hi, then 64 x 16 B of lo).  A operand of
+    // v_mfma_f32_32x32x16_*: lane (m, hh) element j = W[32 n + m][k]; zone_net_.0 and the obs step of combine_net_:
+    // k = 8 hh + j (natural); everything else: the k order in which the previous layer's accumulator registers arrive --
+    // k-step s = 2 t + q takes registers 8 q .. 8 q + 7 of tile t:
     //   k_b3(s, hh, j) = 32 (s / 2) + 16 (s % 2) + (j & 3) + 8 (j >> 2) + 4 hh
     auto bf16_rne = [](float x) -> uint16_t {
         uint32_t u;
@@ -708,26 +941,80 @@ size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_
         std::memcpy(&f, &u, 4);
         return f;
     };
-    auto push_frag = [&](auto ext, int n, auto kof) {       // one fragment pair (hi, lo): 2 x 64 lanes x 8 bf16
+    auto f16_rne = [](float x) -> uint16_t {        // round to nearest even, subnormals kept, 65 520 and up -> inf
+        uint32_t u;
+        std::memcpy(&u, &x, 4);
+        const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+        u &= 0x7FFFFFFFu;
+        if (u >= 0x47800000u) return (uint16_t)(sign | (u > 0x7F800000u ? 0x7E00u : 0x7C00u));
+        if (u < 0x38800000u) {                                                  // below 2^-14: a multiple of 2^-24
+            float f;
+            std::memcpy(&f, &u, 4);
+            return (uint16_t)(sign | (uint16_t)std::lrintf(f * 16777216.0f));   // 1024 = the smallest normal's encoding
+        }
+        u += 0xC8000FFFu + ((u >> 13) & 1u);                                    // exponent bias 127 -> 15, half-ulp - 1 + odd
+        return (uint16_t)(sign | (u >> 13));
+    };
+    auto f16_val = [](uint16_t b) -> float {
+        const int e = (b >> 10) & 31, m = b & 1023;
+        const float mag = e == 0 ? std::ldexp((float)m, -24) : e == 31 ? (m ? NAN : INFINITY) : std::ldexp((float)(1024 + m), e - 25);
+        return (b & 0x8000u) ? -mag : mag;
+    };
+    auto push_frag = [&](bool f16, auto ext, int n, auto kof) {       // one fragment pair (hi, lo): 2 x 64 lanes x 8 halves
         std::vector<uint16_t> hi(64 * 8), lo(64 * 8);
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
                 const float v = ext(32 * n + (lane & 31), kof(lane >> 5, j));
-                const uint16_t hb = bf16_rne(v);
+                const uint16_t hb = f16 ? f16_rne(v) : bf16_rne(v);
                 hi[lane * 8 + j] = hb;
-                lo[lane * 8 + j] = bf16_rne(v - bf16_val(hb));
+                lo[lane * 8 + j] = f16 ? f16_rne(v - f16_val(hb)) : bf16_rne(v - bf16_val(hb));
             }
         const size_t at = out.size();
         out.resize(at + 2 * 64 * 4);
         std::memcpy(&out[at], hi.data(), 64 * 16);
         std::memcpy(&out[at + 64 * 4], lo.data(), 64 * 16);
     };
-    offs[21] = out.size();
-    for (int n = 0; n < NT; ++n) push_frag(w1ext, n, [](int hh, int j) { return 8 * hh + j; });
-    offs[22] = out.size();
-    for (int n = 0; n < NT; ++n)
-        for (int s2 = 0; s2 < HP / 16; ++s2)
-            push_frag(w2ext, n, [s2](int hh, int j) { return 32 * (s2 / 2) + 16 * (s2 % 2) + (j & 3) + 8 * (j >> 2) + 4 * hh; });
+    auto k_nat = [](int hh, int j) { return 8 * hh + j; };
+    auto k_b3 = [](int s2) {
+        return [s2](int hh, int j) { return 32 * (s2 / 2) + 16 * (s2 % 2) + (j & 3) + 8 * (j >> 2) + 4 * hh; };
+    };
+    for (int f16 = 0; f16 < 2; ++f16) {         // zone_net_.2 then zone_net_.0, back to back: the kernel's LDS image in one copy
+        offs[22 + 2 * f16] = out.size();
+        for (int n = 0; n < NT; ++n)
+            for (int s2 = 0; s2 < HP / 16; ++s2) push_frag(f16, w2ext, n, k_b3(s2));
+        offs[21 + 2 * f16] = out.size();
+        for (int n = 0; n < NT; ++n) push_frag(f16, w1ext, n, k_nat);
+    }
+    // the head layers (ZENV_MLP_F16X3 only): [tile][k-step]; combine_net_ (zone_net_.4 folded in) has one leading k-step
+    // whose lane half 0 is the obs in natural order (half 1: nothing); the two head images are one tile whose first rows
+    // are the outputs
+    auto pack_hidden16 = [&](auto ext, const float *Wobs, int in_stride) {
+        const size_t at = out.size();
+        for (int n = 0; n < NT; ++n) {
+            if (Wobs)
+                push_frag(true, [&](int o, int k) { return (o < h && k < 8) ? Wobs[(size_t)o * in_stride + k] : 0.f; }, n, k_nat);
+            for (int s2 = 0; s2 < HP / 16; ++s2) push_frag(true, ext, n, k_b3(s2));
+        }
+        return at;
+    };
+    auto pack_rows16 = [&](std::initializer_list<std::pair<const float *, const float *>> rows) {
+        const size_t at = out.size();
+        std::vector<std::pair<const float *, const float *>> rv(rows);
+        auto ext = [&](int o, int k) -> float {
+            if (o < (int)rv.size() && rv[o].first && k <= h) return k == h ? rv[o].second[0] : rv[o].first[k];
+            return 0.f;
+        };
+        for (int s2 = 0; s2 < HP / 16; ++s2) push_frag(true, ext, 0, k_b3(s2));
+        return at;
+    };
+    offs[25] = pack_hidden16(hidden(combf.data(), bcf.data(), 8, 8 + h), combf.data(), 8 + h);
+    offs[27] = pack_hidden16(hidden(w.enc_w, w.enc_b, 0, h), nullptr, 0);
+    offs[28] = pack_rows16({ { w.mu_w, w.mu_b }, { w.mu_w + h, w.mu_b + 1 }, { w.std_w, w.std_b }, { w.std_w + h, w.std_b + 1 } });
+    offs[26] = offs[29] = 0;
+    if (w.critic_w1) {
+        offs[26] = pack_hidden16(hidden(w.critic_w1, w.critic_b1, 0, h), nullptr, 0);
+        offs[29] = pack_rows16({ { w.critic_w2, w.critic_b2 }, { w.critic_sigma_w, w.critic_sigma_b } });
+    }
     return out.size();
 }
 
@@ -739,12 +1026,20 @@ hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const fl
     // Small batches (evaluate(): 500 envs) are faster on the vector-ALU kernel, which spreads 4 envs per workgroup over
     // the chip (0.50 ms at N = 8 192, 0.86 ms at 16 384): crossover N ~ 10 000.
     if (w.split3 && (w.on_mfma == 2 || (w.on_mfma == 1 && N >= kMfmaMinEnvs))) {
-        // ZENV_MLP_BF16X3: the zone layers as three bf16 products per k-step, the head on the float32 matrix instruction
+        // ZENV_MLP_BF16X3 / ZENV_MLP_F16X3: three 16-bit products per k-step on hi / lo operands
         const int epw = N <= 32768 ? 32 : 64;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone_b3),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kZoneLdsB3);
-        hipLaunchKernelGGL(k_mlp_zone_b3, dim3((N + kZoneWaves * epw - 1) / (kZoneWaves * epw)), dim3(kZoneWaves * 64),
-                           kZoneLdsB3, s, w, N, Z, F, obs, zone_obs, mu, stdv, value, value_sigma, act, epw);
+        const dim3 grid((N + kZoneWaves * epw - 1) / (kZoneWaves * epw)), block(kZoneWaves * 64);
+        if (w.split3 == 2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone_s3<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kZoneLdsS3);
+            hipLaunchKernelGGL(k_mlp_zone_s3<true>, grid, block, kZoneLdsS3, s, w, N, Z, F, obs, zone_obs, mu, stdv, value,
+                               value_sigma, act, epw);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_zone_s3<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kZoneLdsS3);
+            hipLaunchKernelGGL(k_mlp_zone_s3<false>, grid, block, kZoneLdsS3, s, w, N, Z, F, obs, zone_obs, mu, stdv, value,
+                               value_sigma, act, epw);
+        }
         return hipGetLastError();
     }
     if (w.on_mfma == 2 || (w.on_mfma == 1 && N >= kMfmaMinEnvs)) {

@@ -48,12 +48,17 @@ struct MlpF32 {
     // heads [1][96]
     const float *w1m, *w2m, *w3m, *wcm, *wam, *whm, *wv1m, *whvm;
     int on_mfma, split3;        // on_mfma 0: always the vector-ALU kernel k_mlp_f32 (ZENV_MLP_F32_VALU=1); 2: always the MFMA
-                                // kernel (ZENV_MLP_F32_MFMA=1); 1: by batch size.  split3: ZENV_MLP_BF16X3 -- the MFMA kernel is
-                                // k_mlp_zone_b3 (zone layers as hi / lo bf16 fragments, three products per k-step)
-    const void *w1b, *w2b;      // k_mlp_zone_b3's images: zone_net_.0 [6][{hi, lo}][64 x 16 B], zone_net_.2 [6][12][{hi, lo}][64 x 16 B]
+                                // kernel (ZENV_MLP_F32_MFMA=1); 1: by batch size.  split3: the MFMA kernel is k_mlp_zone_s3 on
+                                // hi / lo split operands, three products per k-step -- 1: bf16 halves, zone layers only
+                                // (ZENV_MLP_BF16X3); 2: f16 halves, every layer (ZENV_MLP_F16X3)
+    // k_mlp_zone_s3's images, fragment pairs of 64 x 16 B hi + 64 x 16 B lo: zone_net_.0 [6], zone_net_.2 [6][12] in bf16
+    // (w1b, w2b) and f16 (w1h, w2h); f16 only: combine_net_ [6][1 + 12], critic.0 [6][12], actor.enc_ [6][12], actor
+    // heads [12], critic heads [12]
+    const void *w1b, *w2b, *w1h, *w2h, *wch, *wv1h, *wah, *whh, *whvh;
+    int *range_flag;            // pinned host word the f16 kernel sets when an operand left float16's range
 };
-// floats needed for the device image and the packer (offsets of the arrays above, in floats, in `offs[23]`)
-size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[23]);
+// floats needed for the device image and the packer (offsets of the arrays above, in floats, in `offs[30]`)
+size_t pack_f32(const zenv_mlp_weights &w, int F, std::vector<float> &out, size_t offs[30]);
 hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const float *obs, const float *zone_obs, float *mu,
                                   float *stdv, float *value, float *value_sigma, const struct MlpAction &act,
                                   hipStream_t s);

@@ -93,6 +93,7 @@ struct zenv {
     MlpImages mlp{};
     void *mlp_pooled = nullptr;
     float *mlp_mu = nullptr, *mlp_std = nullptr, *mlp_value = nullptr, *mlp_value_sigma = nullptr;
+    int *mlp_range_flag = nullptr;      // pinned host word, see mlp_range_check()
     void *mlp_f32_mem = nullptr;        // float32 path (ZENV_MLP_F32): transposed float32 weights
     MlpF32 mlp_f32{};
     bool mlp_ready = false;
@@ -540,6 +541,7 @@ extern "C" int zenv_destroy(zenv_t *h)
     if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_self) (void)hipFree(h->d_self);
     if (h->refill_host) (void)hipHostFree(h->refill_host);
+    if (h->mlp_range_flag) (void)hipHostFree(h->mlp_range_flag);
     if (h->refill_dev) (void)hipFree(h->refill_dev);
     if (h->refill_done) (void)hipEventDestroy(h->refill_done);
     for (void *m : { h->mlp_mem, h->mlp_f32_mem, (void *)h->mlp_value_sigma, h->mlp_pooled, (void *)h->mlp_mu,
@@ -1003,6 +1005,16 @@ extern "C" int zenv_solver_goals(zenv_t *h, int32_t *goals)
     return ZENV_OK;
 }
 
+// ZENV_MLP_F16X3: the network kernel sets *mlp_range_flag (pinned host memory) when one of its operands left float16's
+// range; every entry point that waits for the device looks at it once the stream has drained
+static int mlp_range_check(zenv *h)
+{
+    if (!h->mlp_range_flag || !*(volatile int *)h->mlp_range_flag) return ZENV_OK;
+    *(volatile int *)h->mlp_range_flag = 0;
+    return fail(ZENV_E_RANGE, "an input or activation of the network reached 65 520, beyond float16: the actions since the last "
+                              "synchronising call are invalid -- load these weights with ZENV_MLP_BF16X3 or ZENV_MLP_F32");
+}
+
 // ============================================================================ actor network
 extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
 {
@@ -1016,8 +1028,28 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     const int n_sigma = (w->critic_sigma_w != nullptr) + (w->critic_sigma_b != nullptr);
     if (n_sigma == 1 || (n_sigma == 2 && n_critic == 0))
         return fail(ZENV_E_ARG, "the distributional critic needs critic.0, critic_mu (as critic_w2 / _b2) and critic_sigma");
-    if (w->precision != ZENV_MLP_BF16 && w->precision != ZENV_MLP_F32 && w->precision != ZENV_MLP_BF16X3)
+    if (w->precision < ZENV_MLP_BF16 || w->precision > ZENV_MLP_F16X3)
         return fail(ZENV_E_ARG, "unknown zenv_mlp_weights.precision %d", w->precision);
+    if (w->precision == ZENV_MLP_F16X3 && w->h_dim >= 1 && w->h_dim < kMlpHP) {
+        // float16 halves: a weight of 65 520 or more would be inf on the device
+        const int hd = w->h_dim, F = h->p.F;
+        const struct { const float *t; size_t n; const char *name; } all[] = {
+            { w->zone_w1, (size_t)hd * (8 + F), "zone_net_.0.weight" }, { w->zone_b1, (size_t)hd, "zone_net_.0.bias" },
+            { w->zone_w2, (size_t)hd * hd, "zone_net_.2.weight" },      { w->zone_b2, (size_t)hd, "zone_net_.2.bias" },
+            { w->zone_w3, (size_t)hd * hd, "zone_net_.4.weight" },      { w->zone_b3, (size_t)hd, "zone_net_.4.bias" },
+            { w->comb_w, (size_t)hd * (8 + hd), "combine_net_.weight" }, { w->comb_b, (size_t)hd, "combine_net_.bias" },
+            { w->enc_w, (size_t)hd * hd, "actor.enc_.0.0.weight" },     { w->enc_b, (size_t)hd, "actor.enc_.0.0.bias" },
+            { w->mu_w, (size_t)2 * hd, "actor.mu_.weight" },            { w->mu_b, 2, "actor.mu_.bias" },
+            { w->std_w, (size_t)2 * hd, "actor.std_.weight" },          { w->std_b, 2, "actor.std_.bias" },
+            { w->critic_w1, (size_t)hd * hd, "critic.0.weight" },       { w->critic_b1, (size_t)hd, "critic.0.bias" },
+            { w->critic_w2, (size_t)hd, "critic.2.weight" },            { w->critic_b2, 1, "critic.2.bias" },
+            { w->critic_sigma_w, (size_t)hd, "critic_sigma.weight" },   { w->critic_sigma_b, 1, "critic_sigma.bias" } };
+        for (const auto &a : all)
+            for (size_t i = 0; a.t && i < a.n; ++i)
+                if (!(std::fabs(a.t[i]) < 32768.0f))
+                    return fail(ZENV_E_RANGE, "%s[%zu] = %g: ZENV_MLP_F16X3 keeps weights as float16 pairs (|w| < 32 768); use "
+                                              "ZENV_MLP_BF16X3 or ZENV_MLP_F32", a.name, i, (double)a.t[i]);
+    }
     std::vector<uint16_t> img;
     size_t offs[8];
     if (pack_images(*w, h->p.F, img, offs) != 0)
@@ -1044,13 +1076,17 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     h->mlp = MlpImages{ base + offs[0], base + offs[1], base + offs[2], base + offs[3], base + offs[4], base + offs[5],
                         n_critic ? base + offs[6] : nullptr, n_critic ? base + offs[7] : nullptr, nullptr,
                         n_sigma == 2 ? 1 : 0 };
-    if (w->precision == ZENV_MLP_F32 || w->precision == ZENV_MLP_BF16X3) {
+    if (w->precision != ZENV_MLP_BF16) {
         std::vector<float> f32;
-        size_t fo[23];
+        size_t fo[30];
         pack_f32(*w, h->p.F, f32, fo);
         // (diagnostic: ZENV_MLP_F32_VALU=1 runs the network on the vector ALU, k_mlp_f32, instead of the f32 MFMA)
         // ZENV_MLP_F32_MFMA=1 the MFMA kernel whatever the batch; default: by batch size, see launch_mlp_forward_f32)
         const int on_mfma = std::getenv("ZENV_MLP_F32_VALU") ? 0 : std::getenv("ZENV_MLP_F32_MFMA") ? 2 : 1;
+        if (!h->mlp_range_flag) {
+            HIP_TRY(hipHostMalloc((void **)&h->mlp_range_flag, sizeof(int), hipHostMallocDefault));
+            *h->mlp_range_flag = 0;
+        }
         HIP_TRY(hipMalloc(&h->mlp_f32_mem, f32.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->mlp_f32_mem, f32.data(), f32.size() * sizeof(float), hipMemcpyHostToDevice));
         const float *fb = static_cast<const float *>(h->mlp_f32_mem);
@@ -1059,7 +1095,10 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
                              fb + fo[7], fb + fo[8], fb + fo[9], n_critic ? fb + fo[10] : nullptr,
                              n_critic ? fb + fo[11] : nullptr, fb + fo[12], fb + fo[13], fb + fo[14], fb + fo[15], fb + fo[16], fb + fo[17], fb + fo[18],
                              n_critic ? fb + fo[19] : nullptr, n_critic ? fb + fo[20] : nullptr, on_mfma,
-                             w->precision == ZENV_MLP_BF16X3 ? 1 : 0, fb + fo[21], fb + fo[22] };
+                             w->precision == ZENV_MLP_BF16X3 ? 1 : w->precision == ZENV_MLP_F16X3 ? 2 : 0,
+                             fb + fo[21], fb + fo[22], fb + fo[23], fb + fo[24], fb + fo[25],
+                             n_critic ? fb + fo[26] : nullptr, fb + fo[27], fb + fo[28], n_critic ? fb + fo[29] : nullptr,
+                             h->mlp_range_flag };
         h->mlp.f32 = &h->mlp_f32;
     }
     h->mlp_ready = true;
@@ -1307,6 +1346,7 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     hipEvent_t ev_first = own_bracket ? h->events[0] : h->events[2];
     hipEvent_t ev_last = own_bracket ? h->events[1] : h->events[3 + 2 * (n_sampled - 1)];
     HIP_TRY(hipEventSynchronize(ev_last));
+    if (int rr = mlp_range_check(h)) return rr;
     if (ms_total) HIP_TRY(hipEventElapsedTime(ms_total, ev_first, ev_last));
     if (per_kernel) {
         double sum = 0.0;
@@ -1336,6 +1376,7 @@ extern "C" int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device)
     HIP_TRY(hipMemcpyAsync(dst, f.ptr, f.bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                            h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rr = mlp_range_check(h)) return rr;
     return ZENV_OK;
 }
 
@@ -1353,6 +1394,7 @@ extern "C" int zenv_get_rows(zenv_t *h, int field, int first_env, int count, voi
     HIP_TRY(hipMemcpyAsync(dst, static_cast<const char *>(f.ptr) + per_env * first_env, (size_t)(per_env * count),
                            hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rr = mlp_range_check(h)) return rr;
     return ZENV_OK;
 }
 
@@ -1383,6 +1425,7 @@ extern "C" int zenv_get_many(zenv_t *h, int n_fields, const int *fields, void *c
         HIP_TRY(hipMemcpyAsync(dst[i], f.ptr, f.bytes, hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rr = mlp_range_check(h)) return rr;
     return ZENV_OK;
 }
 
@@ -1406,6 +1449,7 @@ extern "C" int zenv_step_results(zenv_t *h, const float *actions, int auto_reset
     }
     HIP_TRY(hipMemcpyAsync(host_slab, h->results_slab, (size_t)h->results_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rr = mlp_range_check(h)) return rr;
     return ZENV_OK;
 }
 
@@ -1634,6 +1678,7 @@ extern "C" int zenv_sync(zenv_t *h)
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rr = mlp_range_check(h)) return rr;
     return ZENV_OK;
 }
 

@@ -328,8 +328,11 @@ class ZoneVecEnv:
         """The reference's ZoneEnvModel + actor (env_model.py:48-79, policy_network.py:12-53) for the
         device policies POLICY_MLP_MEAN / POLICY_MLP_SAMPLE.  tensors: dict of float32 arrays named as in
         ``_native.MLP_TENSORS`` (see ``mlp_tensors_from_state_dict``), state_dict layout [out][in].
-        precision "bf16": bf16 MFMA kernels (fast; mu / std within 4e-2 of torch float32); "f32": float32 FMA kernels
-        (~20x slower; within 1e-5 of torch float32 -- what evaluate() uses for a checkpoint)."""
+        precision "bf16": bf16 MFMA kernels (fastest; mu / std within 4e-2 of torch float32); "f32": float32 throughout
+        (8x slower; within 1e-5 of torch float32); "f16x3" / "bf16x3": the 16-bit matrix instruction on hi / lo split
+        operands, three products per k-step -- "f16x3" within 3e-6 of torch float32 at 0.30 of "f32"'s time, "bf16x3"
+        within 2e-5 at 0.35.  "f16x3" is bound to float16's range: a weight >= 32 768 is refused here and an input /
+        activation >= 65 520 raises ZenvError(E_RANGE) at the next call that waits for the device."""
         F = self.zone_feat
         h = int(np.asarray(tensors["zone_b1"]).shape[0])
         want = {"zone_w1": (h, 8 + F), "zone_b1": (h,), "zone_w2": (h, h), "zone_b2": (h,), "zone_w3": (h, h),
@@ -338,7 +341,8 @@ class ZoneVecEnv:
                 "critic_w1": (h, h), "critic_b1": (h,), "critic_w2": (1, h), "critic_b2": (1,),
                 "critic_sigma_w": (1, h), "critic_sigma_b": (1,)}
         keep = {}
-        w = nat.MlpWeights(h_dim=h, precision={"bf16": nat.MLP_BF16, "f32": nat.MLP_F32, "bf16x3": nat.MLP_BF16X3}[precision])
+        w = nat.MlpWeights(h_dim=h, precision={"bf16": nat.MLP_BF16, "f32": nat.MLP_F32, "bf16x3": nat.MLP_BF16X3,
+                                                   "f16x3": nat.MLP_F16X3}[precision])
         names = nat.MLP_TENSORS + (nat.MLP_CRITIC_TENSORS if "critic_w1" in tensors else ()) + (
             nat.MLP_SIGMA_TENSORS if "critic_sigma_w" in tensors else ())
         self._mlp_has_critic = "critic_w1" in tensors

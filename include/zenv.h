@@ -41,7 +41,8 @@ enum {
     ZENV_E_HIP = -2,        /* HIP runtime / no device */
     ZENV_E_STATE = -3,      /* call order (e.g. step before bank/reset) */
     ZENV_E_LAYOUT = -4,     /* ResamplingError: no layout in 10000 tries */
-    ZENV_E_DONE = -5        /* single-env semantics: 'Environment must be reset before stepping' */
+    ZENV_E_DONE = -5,       /* single-env semantics: 'Environment must be reset before stepping' */
+    ZENV_E_RANGE = -6       /* ZENV_MLP_F16X3: a weight, input or activation of the network beyond float16's range */
 };
 
 /* zenv_get()/zenv_device_ptr() selectors */
@@ -290,10 +291,16 @@ enum {
     ZENV_MLP_BF16 = 0,  /* bf16 MFMA, float32 accumulation: ~20x faster, mu / std within 4e-2 of the reference's float32 */
     ZENV_MLP_F32 = 1,   /* float32 throughout (f32 MFMA / FMA): mu / std / value within 1e-5 of the reference's torch float32 --
                          * the mode in which evaluate() with a checkpoint reproduces the reference's arithmetic */
-    ZENV_MLP_BF16X3 = 2 /* float32 accuracy at a third of its time on big batches: the two zone layers (96 % of the
-                         * arithmetic) as three bf16 products per k-step on hi / lo split operands (16 significant bits),
-                         * float32 accumulation, the per-env head in float32; within 1e-5 of torch float32 like ZENV_MLP_F32.
-                         * Batches too small for the matrix kernels (< 10 240 envs) run the float32 vector kernel. */
+    ZENV_MLP_BF16X3 = 2, /* the two zone layers -- 96 % of the arithmetic -- as three bf16 products per k-step on hi / lo split
+                         * operands (16 significant bits, float32's range), float32 accumulation, the per-env head on the
+                         * float32 matrix instruction: within 2e-5 of torch float32 (measured: up to 1.1e-5) at a third of
+                         * ZENV_MLP_F32's time */
+    ZENV_MLP_F16X3 = 3  /* the same with float16 halves (22 significant bits: within 3e-6 of torch float32, float32's own
+                         * rounding noise) on every layer -- the fastest of the float32-grade modes (0.30 of ZENV_MLP_F32).  float16's range applies to every
+                         * operand: weights of 32 768 or more are refused by zenv_mlp_load (ZENV_E_RANGE); an input or
+                         * activation that reaches 65 520 is caught on the device and reported as ZENV_E_RANGE by the next
+                         * call that waits for it (zenv_get*, zenv_sync, zenv_rollout, zenv_step_results).
+                         * Batches too small for the matrix kernels (< 10 240 envs) run the float32 vector kernel in both. */
 };
 typedef struct zenv_mlp_weights {
     int32_t h_dim;

@@ -23,10 +23,13 @@ sys.path.insert(0, ROOT)
 from oracle import policy_ref as P   # noqa: E402
 
 
+ELEM = torch.bfloat16       # main() also runs the table with torch.float16 (11 significant bits per term, subnormals kept)
+
+
 def split(x, k):
     terms, r = [], x.float()
     for _ in range(k):
-        t = r.to(torch.bfloat16).float()
+        t = r.to(ELEM).float()
         terms.append(t)
         r = r - t
     return terms
@@ -76,14 +79,17 @@ def main():
     obs = np.concatenate([rs.uniform(0, 1, (B, 1)), rs.uniform(-1, 1, (B, 7))], 1).astype(np.float32)
     zo = np.concatenate([rs.uniform(-1, 1, (B, Z, 2)), rs.randint(0, 2, (B, Z, 3)), np.full((B, Z, 1), 0.25)], 2).astype(np.float32)
     print(f"{'variant':28s} {'products':>8s} {'MFMA/tile':>9s} {'max|d mu|':>10s} {'max|d std|':>10s} {'max|d value|':>12s}")
+    global ELEM
     for seed in (0, 1):
         t = P.random_tensors(F, h=185, seed=seed, critic=True)
         mu0, std0, v0 = P.forward_fp32(t, obs, zo)
-        for name, k, order in (("bf16 (shipped K4/K5)", 1, 2), ("bf16x3: hh + hl + lh", 2, 3), ("bf16x4: + ll", 2, 4),
-                               ("bf16x6: 3 terms, order 4", 3, 4), ("bf16x9: 3 terms, all", 3, 6)):
-            mu, std, v, n = forward_split(t, obs, zo, k, order)
-            print(f"{name:28s} {n:8d} {90 * n:9d} {np.abs(mu - mu0).max():10.2e} {np.abs(std - std0).max():10.2e} "
-                  f"{np.abs(v - v0).max():12.2e}   (weights seed {seed})")
+        for elem, ename in ((torch.bfloat16, "bf16"), (torch.float16, "f16")):
+            ELEM = elem
+            for name, k, order in (("%s", 1, 2), ("%sx3: hh + hl + lh", 2, 3), ("%sx4: + ll", 2, 4),
+                                   ("%sx6: 3 terms, order 4", 3, 4), ("%sx9: 3 terms, all", 3, 6)):
+                mu, std, v, n = forward_split(t, obs, zo, k, order)
+                print(f"{name % ename:28s} {n:8d} {90 * n:9d} {np.abs(mu - mu0).max():10.2e} {np.abs(std - std0).max():10.2e} "
+                      f"{np.abs(v - v0).max():12.2e}   (weights seed {seed})")
 
 
 if __name__ == "__main__":

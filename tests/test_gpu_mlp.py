@@ -417,34 +417,42 @@ def test_float32_mfma_kernel_with_two_groups_per_wave(zenv_mod):
 @pytest.mark.parametrize("env_id,n,steps,h", [("PointTSP-v0", 203, 40, 185), ("PointTTSP-v0", 130, 25, 185),
                                               ("ColourMatch-v0", 77, 60, 185), ("PointTSP-v1", 65, 10, 33),
                                               ("PointTSP-v4", 9, 30, 191)])
-def test_split_bf16_mode_holds_the_float32_tolerance(zenv_mod, env_id, n, steps, h, monkeypatch):
-    """ZENV_MLP_BF16X3 (k_mlp_zone_b3: the zone layers as hi / lo bf16 operands, three products per k-step; float32
-    head): the same 1e-5 as the float32 mode against the torch float32 restatement, and it is NOT the float32 kernel
-    (the outputs differ in the last bits) nor the plain bf16 one (orders of magnitude closer)."""
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("f16x3", 3e-6)])
+def test_split_operand_modes_hold_the_float32_tolerance(zenv_mod, env_id, n, steps, h, precision, tol, monkeypatch):
+    """ZENV_MLP_BF16X3 / ZENV_MLP_F16X3 (k_mlp_zone_s3: hi / lo 16-bit operands, three products per k-step; bf16: zone
+    layers only, float32 head; f16: every layer) against the torch float32 restatement: f16 halves 3e-6 -- inside the
+    1e-5 of the float32 mode with room to spare; bf16 halves 2e-5 (measured up to 1.1e-5: 16 significant bits sit right
+    at that bar).  Neither is the float32 kernel (the outputs differ in the last bits) nor the plain bf16 one (orders of
+    magnitude closer)."""
     from oracle import policy_ref as P
     Z = zenv_mod
     monkeypatch.setenv("ZENV_MLP_F32_MFMA", "1")       # batches this small default to k_mlp_f32: pin the matrix kernel
     env = _env_with_obs(Z, env_id, n, steps)
     for distributional in (False, True):
         t = P.random_tensors(env.zone_feat, h=h, seed=5, critic=True, distributional=distributional)
-        env.load_mlp(t, precision="bf16x3")
+        env.load_mlp(t, precision=precision)
         out = env.mlp_forward(with_value=True)
         obs, zo = env.observations()
         ref = P.forward_fp32(t, obs, zo)
         assert len(out) == len(ref) == (4 if distributional else 3)
         for name, a, b in zip(("mu", "std", "value", "sigma"), out, ref):
-            assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-5, (name, float(np.abs(a - b).max()))
+            assert np.isfinite(a).all() and np.abs(a - b).max() <= tol, (name, float(np.abs(a - b).max()))
     env.load_mlp(t, precision="f32")
     out32 = env.mlp_forward(with_value=True)
     assert 0 < np.abs(out32[2] - out[2]).max() <= 2e-5
-    env.policy(Z.POLICY_MLP_MEAN)
-    env.load_mlp(t, precision="bf16x3")
+    env.load_mlp(t, precision=precision)
     env.policy(Z.POLICY_MLP_MEAN)
     assert np.array_equal(env.get(Z.F_ACTIONS), out[0])
+    # a network without a critic
+    ta = {k: v for k, v in t.items() if not k.startswith("critic")}
+    env.load_mlp(ta, precision=precision)
+    mu_a, std_a = env.mlp_forward()
+    assert np.array_equal(mu_a, out[0]) and np.array_equal(std_a, out[1])
     env.close()
 
 
-def test_split_bf16_mode_on_the_full_batch_layout(zenv_mod):
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-5), ("f16x3", 3e-6)])
+def test_split_operand_modes_on_the_full_batch_layout(zenv_mod, precision, tol):
     """N > 32 768 (two groups of 32 envs per wave, ragged last workgroup), default kernel choice by batch size."""
     from oracle import policy_ref as P
     Z = zenv_mod
@@ -452,10 +460,46 @@ def test_split_bf16_mode_on_the_full_batch_layout(zenv_mod):
     for env_id in ("ColourMatch-v0", "PointTTSP-v0"):
         env = _env_with_obs(Z, env_id, n, 30)
         t = P.random_tensors(env.zone_feat, h=185, seed=11, distributional=True)
-        env.load_mlp(t, precision="bf16x3")
+        env.load_mlp(t, precision=precision)
         out = env.mlp_forward(with_value=True)
         obs, zo = env.observations()
         ref = P.forward_fp32(t, obs, zo)
         for name, a, b in zip(("mu", "std", "value", "sigma"), out, ref):
-            assert a.shape == b.shape and np.isfinite(a).all() and np.abs(a - b).max() <= 1e-5, (name, float(np.abs(a - b).max()))
+            assert a.shape == b.shape and np.isfinite(a).all() and np.abs(a - b).max() <= tol, (name, float(np.abs(a - b).max()))
         env.close()
+
+
+def test_float16_range_is_enforced(zenv_mod, monkeypatch):
+    """ZENV_MLP_F16X3 keeps every operand as float16 pairs: a weight beyond the range is refused when it is loaded, an
+    activation that gets there on the device fails the next call that waits for it (once), and the wider modes take the
+    same weights."""
+    from oracle import policy_ref as P
+    Z = zenv_mod
+    monkeypatch.setenv("ZENV_MLP_F32_MFMA", "1")
+    env = _env_with_obs(Z, "PointTSP-v0", 300, 20)
+    t = P.random_tensors(env.zone_feat, h=185, seed=2, critic=True)
+    big = dict(t)
+    big["enc_w"] = t["enc_w"].copy()
+    big["enc_w"][7, 3] = 4.0e4
+    with pytest.raises(Z.ZenvError) as e:
+        env.load_mlp(big, precision="f16x3")
+    assert e.value.code == Z.E_RANGE and "actor.enc_.0.0.weight" in str(e.value)
+    env.load_mlp(big, precision="bf16x3")
+    hot = dict(t)
+    hot["zone_w1"] = (t["zone_w1"] * 1.0e3).astype(np.float32)          # every weight < 32 768, second-layer outputs ~1e6
+    hot["zone_w2"] = (t["zone_w2"] * 1.0e3).astype(np.float32)
+    assert max(np.abs(hot["zone_w1"]).max(), np.abs(hot["zone_w2"]).max()) < 32768
+    env.load_mlp(hot, precision="f16x3")
+    with pytest.raises(Z.ZenvError) as e:
+        env.mlp_forward()
+    assert e.value.code == Z.E_RANGE and "float16" in str(e.value)
+    env.get(Z.F_OBS)                                                     # reported once
+    env.load_mlp(hot, precision="bf16x3")
+    mu, std = env.mlp_forward()
+    obs, zo = env.observations()
+    ref = P.forward_fp32(hot, obs, zo)
+    assert np.isfinite(mu).all() and np.abs(mu - ref[0]).max() < 1e-2    # huge activations, saturated sigmoids: sanity only
+    env.load_mlp(t, precision="f16x3")
+    mu, std = env.mlp_forward()
+    assert np.abs(mu - P.forward_fp32(t, obs, zo)[0]).max() <= 3e-6
+    env.close()
