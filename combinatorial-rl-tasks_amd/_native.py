@@ -128,6 +128,8 @@ _PROTOTYPES = {
     "zenv_get_many": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
     "zenv_results_layout": (C.c_int64, [_H, C.POINTER(C.c_int64)]),
     "zenv_step_results": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p]),
+    "zenv_host_io": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "zenv_step_host": (C.c_int, [_H, C.c_int]),
     "zenv_set_stream": (C.c_int, [_H, C.c_void_p]),
     "zenv_comm_unique_id": (C.c_int, [C.c_void_p]),
     "zenv_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),

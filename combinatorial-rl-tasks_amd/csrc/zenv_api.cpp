@@ -70,6 +70,9 @@ struct zenv {
     // The per-step results (obs, reward, done, goal_met, exception, zone_obs) share ONE allocation, 256-byte aligned
     // pieces in that order, so that a host policy fetches them with one copy (zenv_step_results).
     void *results_slab = nullptr;
+    // zenv_host_io(): results slab + action buffer in page-locked host memory that the kernels write / read directly
+    void *host_io_slab = nullptr;
+    float *host_io_actions = nullptr, *dev_actions = nullptr;
     int64_t results_off[ZENV_N_RESULTS] = {};
     int64_t results_bytes = 0;
     void *bank_mem[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // robot, zone, aux, seed, derived first rows
@@ -533,9 +536,12 @@ extern "C" int zenv_destroy(zenv_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm) (void)zenv_comm_destroy(h);
+    if (h->host_io_actions) h->p.actions = h->dev_actions;       // the slot below is the device buffer again
     for (Alloc &a : h->allocs)
         if (*a.slot && a.slab_off < 0) (void)hipFree(*a.slot);
     if (h->results_slab) (void)hipFree(h->results_slab);
+    if (h->host_io_slab) (void)hipHostFree(h->host_io_slab);
+    if (h->host_io_actions) (void)hipHostFree(h->host_io_actions);
     for (void *m : h->bank_mem)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
@@ -892,6 +898,11 @@ extern "C" int zenv_step(zenv_t *h, const float *actions, int actions_on_device,
     if (actions) {
         if (actions_on_device) {
             d_act = actions;
+        } else if (h->host_io_actions) {
+            // the kernel reads the page-locked buffer itself; nothing of an earlier step can still be reading it only if
+            // the stream has drained -- which every zenv_host_io caller's step ends with (zenv_step_host / _results)
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (actions != h->host_io_actions) std::memcpy(h->host_io_actions, actions, sizeof(float) * 2 * (size_t)h->n_env);
         } else {
             HIP_TRY(hipMemcpyAsync(h->p.actions, actions, sizeof(float) * 2 * (size_t)h->n_env,
                                    hipMemcpyHostToDevice, h->stream));
@@ -1143,6 +1154,7 @@ extern "C" int zenv_collect(zenv_t *h, int T, uint64_t policy_seed, uint64_t env
     if (T < 1) return fail(ZENV_E_ARG, "frames_per_proc must be positive");
     if (!h->was_reset) return fail(ZENV_E_STATE, "Environment must be reset before stepping");
     if (!h->mlp_ready || !h->mlp.wv1) return fail(ZENV_E_STATE, "zenv_mlp_load with actor and critic weights first");
+    if (h->host_io_slab) return fail(ZENV_E_STATE, "zenv_collect records on the device: switch zenv_host_io off first");
     if (h->order_enabled)
         return fail(ZENV_E_STATE, "solver-ordered envs are stepped with zenv_step (their order feature is not part of "
                                   "the network input this call evaluates)");
@@ -1373,8 +1385,7 @@ extern "C" int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device)
     if (!f.ptr) return fail(ZENV_E_ARG, "unknown field %d", field);
     int rc = use_device(h);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(dst, f.ptr, f.bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
-                           h->stream));
+    HIP_TRY(hipMemcpyAsync(dst, f.ptr, f.bytes, hipMemcpyDefault, h->stream));   // (a zenv_host_io field is host memory)
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (int rr = mlp_range_check(h)) return rr;
     return ZENV_OK;
@@ -1392,7 +1403,7 @@ extern "C" int zenv_get_rows(zenv_t *h, int field, int first_env, int count, voi
     if (rc) return rc;
     const int64_t per_env = f.bytes / h->n_env;
     HIP_TRY(hipMemcpyAsync(dst, static_cast<const char *>(f.ptr) + per_env * first_env, (size_t)(per_env * count),
-                           hipMemcpyDeviceToHost, h->stream));
+                           hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (int rr = mlp_range_check(h)) return rr;
     return ZENV_OK;
@@ -1422,7 +1433,7 @@ extern "C" int zenv_get_many(zenv_t *h, int n_fields, const int *fields, void *c
     for (int i = 0; i < n_fields; ++i) {
         const FieldInfo f = field_info(h, fields[i]);
         if (!f.ptr || !dst[i]) return fail(ZENV_E_ARG, "unknown field %d or null destination", fields[i]);
-        HIP_TRY(hipMemcpyAsync(dst[i], f.ptr, f.bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(dst[i], f.ptr, f.bytes, hipMemcpyDefault, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (int rr = mlp_range_check(h)) return rr;
@@ -1447,7 +1458,65 @@ extern "C" int zenv_step_results(zenv_t *h, const float *actions, int auto_reset
         const int rc = use_device(h);
         if (rc) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(host_slab, h->results_slab, (size_t)h->results_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (h->host_io_slab) {                       // the kernels wrote the results into host memory themselves
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (host_slab != h->host_io_slab) std::memcpy(host_slab, h->host_io_slab, (size_t)h->results_bytes);
+    } else {
+        HIP_TRY(hipMemcpyAsync(host_slab, h->results_slab, (size_t)h->results_bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (int rr = mlp_range_check(h)) return rr;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_host_io(zenv_t *h, int enable, void **results, float **actions)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t act_bytes = sizeof(float) * 2 * (size_t)h->n_env;
+    if (enable && !h->host_io_slab) {
+        void *slab = nullptr, *act = nullptr;
+        HIP_TRY(hipHostMalloc(&slab, (size_t)h->results_bytes, hipHostMallocDefault));
+        hipError_t err = hipHostMalloc(&act, act_bytes, hipHostMallocDefault);
+        if (err == hipSuccess) err = hipMemcpy(slab, h->results_slab, (size_t)h->results_bytes, hipMemcpyDefault);
+        if (err == hipSuccess) err = hipMemcpy(act, h->p.actions, act_bytes, hipMemcpyDefault);
+        if (err != hipSuccess) {
+            (void)hipHostFree(slab);
+            if (act) (void)hipHostFree(act);
+            return fail(ZENV_E_HIP, "zenv_host_io: %s", hipGetErrorString(err));
+        }
+        h->host_io_slab = slab;
+        h->host_io_actions = static_cast<float *>(act);
+        h->dev_actions = h->p.actions;
+        h->p.actions = h->host_io_actions;
+        for (Alloc &a : h->allocs)
+            if (a.slab_off >= 0) *a.slot = static_cast<char *>(slab) + a.slab_off;
+        h->act_tag.valid = false;
+    } else if (!enable && h->host_io_slab) {
+        HIP_TRY(hipMemcpy(h->results_slab, h->host_io_slab, (size_t)h->results_bytes, hipMemcpyDefault));
+        HIP_TRY(hipMemcpy(h->dev_actions, h->host_io_actions, act_bytes, hipMemcpyDefault));
+        h->p.actions = h->dev_actions;
+        for (Alloc &a : h->allocs)
+            if (a.slab_off >= 0) *a.slot = static_cast<char *>(h->results_slab) + a.slab_off;
+        (void)hipHostFree(h->host_io_slab);
+        (void)hipHostFree(h->host_io_actions);
+        h->host_io_slab = nullptr;
+        h->host_io_actions = h->dev_actions = nullptr;
+        h->act_tag.valid = false;
+    }
+    if (results) *results = h->host_io_slab;
+    if (actions) *actions = h->host_io_actions;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_step_host(zenv_t *h, int auto_reset)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (!h->host_io_slab) return fail(ZENV_E_STATE, "zenv_host_io(h, 1, ...) first");
+    const int rc = zenv_step(h, h->host_io_actions, 0, auto_reset);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (int rr = mlp_range_check(h)) return rr;
     return ZENV_OK;
@@ -1729,7 +1798,7 @@ extern "C" int zenv_get_state(zenv_t *h, void *dst, int64_t bytes)
     out += 16;
     for (const Alloc &a : h->allocs) {
         if (!a.is_state) continue;
-        HIP_TRY(hipMemcpy(out, *a.slot, a.bytes, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out, *a.slot, a.bytes, hipMemcpyDefault));
         out += a.bytes;
     }
     return ZENV_OK;
@@ -1772,7 +1841,7 @@ extern "C" int zenv_set_state(zenv_t *h, const void *src, int64_t bytes)
     }
     for (const Alloc &a : h->allocs) {
         if (!a.is_state) continue;
-        HIP_TRY(hipMemcpy(*a.slot, in, a.bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(*a.slot, in, a.bytes, hipMemcpyDefault));
         in += a.bytes;
     }
     h->step_count = head[0];

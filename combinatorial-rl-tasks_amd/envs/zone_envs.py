@@ -70,6 +70,7 @@ class ZoneEnvBase:
                                    time_saved_reward=float(self.time_saved_reward),
                                    **self._native_overrides(), **native_overrides)
         self._vec = ZoneVecEnv(self._cfg, 1, device=device)
+        self._vec.host_io(True)           # one env: a step is one launch and one wait, actions / results in host memory
         self._seed = None
         self.done = True      # Engine: must reset before the first step
         self.steps = 0

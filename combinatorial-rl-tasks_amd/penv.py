@@ -50,6 +50,7 @@ class ParallelEnv:
                 raise ValueError("all envs of a ParallelEnv must share one configuration")
         self.num_envs = len(envs)
         self._vec = ZoneVecEnv(cfg, self.num_envs, device=device)
+        self._vec.host_io("if small")     # 16 procs: the kernel writes the results into host memory itself, no copies
         if all(f is not None for f in fixed):
             lo, hi = fixed[0].min_seed, fixed[0].max_seed
             if any((f.min_seed, f.max_seed) != (lo, hi) for f in fixed):

@@ -170,6 +170,7 @@ class ZoneVecEnv:
             # the handle's own page-locked images (copy=False views of step_results() die with the env)
             ptrs = [a.ctypes.data for a in getattr(self, "_own_pinned", [])]
             self._own_pinned, self._slab, self._slab_views, self._goal_host = [], None, None, None
+            self._host_actions, self._host_io = None, False      # (zenv_host_io's buffers went with the handle)
             for ptr in ptrs:
                 lib().zenv_host_free(C.c_void_p(ptr))
 
@@ -526,12 +527,36 @@ class ZoneVecEnv:
         d = (C.c_void_p * len(fields))(*[a.ctypes.data for a in arrays])
         check(lib().zenv_get_many(self._h, len(fields), f, d))
 
-    def _results_slab(self):
+    # results of up to this many bytes per step (16 envs of 25 zones: 10 KB) are worth keeping in host memory: two copy
+    # enqueues cost more than the kernel writing them over the bus itself
+    HOST_IO_MAX_BYTES = 256 << 10
+
+    def host_io(self, enable=True):
+        """zenv_host_io: the results slab and the action buffer in page-locked HOST memory that the kernels write / read
+        themselves -- step_results() is then one launch and one wait, no upload, no download (for small batches driven
+        by a host policy: ParallelEnv and the single-env gym surface switch it on by themselves, enable="if small":
+        results of at most HOST_IO_MAX_BYTES per step)."""
+        if enable == "if small":
+            enable = lib().zenv_results_layout(self._h, (C.c_int64 * nat.N_RESULTS)()) <= self.HOST_IO_MAX_BYTES
+        res, act = C.c_void_p(), C.c_void_p()
+        check(lib().zenv_host_io(self._h, int(bool(enable)), C.byref(res), C.byref(act)))
+        self._slab = self._slab_views = self._host_actions = None
+        self._host_io = bool(enable)
+        if enable:
+            off = (C.c_int64 * nat.N_RESULTS)()
+            total = lib().zenv_results_layout(self._h, off)
+            self._host_actions = np.ctypeslib.as_array((C.c_float * (2 * self.num_envs)).from_address(act.value)).reshape(
+                self.num_envs, 2)
+            self._results_slab(raw=np.ctypeslib.as_array((C.c_uint8 * total).from_address(res.value)))
+        return self
+
+    def _results_slab(self, raw=None):
         """One page-locked host image of the handle's results slab, with typed views of its pieces."""
         if getattr(self, "_slab", None) is None:
             off = (C.c_int64 * nat.N_RESULTS)()
             total = lib().zenv_results_layout(self._h, off)
-            raw = self._own_pinned_array((total,), np.uint8)
+            if raw is None:
+                raw = self._own_pinned_array((total,), np.uint8)
             N, Zn, F = self.num_envs, self.num_zones, self.zone_feat
 
             def view(i, count, dtype, shape):
@@ -563,6 +588,13 @@ class ZoneVecEnv:
             return (self.get(nat.F_OBS), self.get(nat.F_ZONE_OBS), self.get(nat.F_REWARD),
                     self.get(nat.F_DONE).view(bool), self.get(nat.F_GOAL_MET).view(bool),
                     self.get(nat.F_EXCEPTION).view(bool))
+        if getattr(self, "_host_io", False):      # the kernel reads the actions from, and writes the results to, host memory
+            if a is not None:
+                self._host_actions[...] = a
+                check(lib().zenv_step_host(self._h, int(bool(auto_reset))))
+            else:
+                self.sync()
+            return tuple(v.copy() for v in self._slab_views) if copy else self._slab_views
         slab = self._results_slab()
         check(lib().zenv_step_results(self._h, None if a is None else a.ctypes.data, int(bool(auto_reset)),
                                       slab.ctypes.data))

@@ -368,6 +368,18 @@ enum {
 };
 int64_t zenv_results_layout(const zenv_t *h, int64_t *offsets /* [ZENV_N_RESULTS] or NULL */);
 int zenv_step_results(zenv_t *h, const float *actions, int auto_reset, void *host_slab);
+
+/* Host-resident I/O for small batches driven from the host (the reference's own shape: 16 worker envs and a policy on
+ * the host, train_ppo.py:29-30 / penv.py:63-77).  enable = 1 moves the results slab (zenv_results_layout) and the action
+ * buffer into page-locked host memory that the kernels write and read THEMSELVES over the bus: a step is then one kernel
+ * launch and one wait -- no upload, no download (zenv_step_results: two copy enqueues that cost more than the kernel at
+ * this size).  *results / *actions receive the two buffers (NULL when switched off); write the actions, call
+ * zenv_step_host, read the results in place.  Every other entry point keeps working (zenv_get*, zenv_step_results,
+ * snapshots), device-side readers of the observations (the network kernels) then read them over the bus: meant for
+ * batches of a few hundred envs at most.  zenv_collect is refused while it is on.  enable = 0 moves everything back. */
+int zenv_host_io(zenv_t *h, int enable, void **results, float **actions);
+/* zenv_step with the actions already in the zenv_host_io buffer; returns when the results are in theirs. */
+int zenv_step_host(zenv_t *h, int auto_reset);
 /* Enqueue everything from now on onto the caller's HIP stream (hipStream_t passed as void*; NULL =
  * back to the handle's own stream; the null stream is named by hipStreamLegacy).  The handle first
  * drains the stream it was using.  This is how
