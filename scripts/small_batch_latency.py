@@ -20,7 +20,10 @@ for P in (1, 16, 256, 4096):
     for name, fn in (("ParallelEnv.step (tuples of dicts)", lambda: list(pe.step(a))),
                      ("step_arrays (struct of arrays)", lambda: pe.step_arrays(a)),
                      ("vec.step only (H2D + launch, no download)", lambda: pe.vec.step(a)),
-                     ("vec.step + sync", lambda: (pe.vec.step(a), pe.vec.sync()))):
+                     ("vec.step + sync", lambda: (pe.vec.step(a), pe.vec.sync())),
+                     # the platform's floor for "launch one kernel and wait for it": the uniform-action kernel writes 8 bytes per env
+                     ("smallest kernel (uniform actions) + sync", lambda: (pe.vec.policy(Z.POLICY_UNIFORM), pe.vec.sync())),
+                     ("sync of an idle stream", lambda: pe.vec.sync())):
         for _ in range(20):
             fn()
         pe.vec.sync()
