@@ -193,6 +193,7 @@ constexpr int KS1 = KIN / 2;       // 8 k-steps of zone_net_.0 (K = 2 per v_mfma
 constexpr int KS2 = HP / 2;        // 96 k-steps of zone_net_.2
 constexpr int kZoneWaves = 4;
 constexpr int kMfmaMinEnvs = 10240;
+constexpr int kSplitMinEnvs = 2048;     // k_mlp_zone_s3
 constexpr size_t kZoneLds = (size_t)(NT * KS2 + NT * KS1) * 64 * sizeof(float);   // 159 744 B of the CU's 163 840
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
@@ -1025,7 +1026,8 @@ hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const fl
     // whatever N is, as long as there is at most one wave per SIMD -- one group per wave up to N = 32 768, two above.
     // Small batches (evaluate(): 500 envs) are faster on the vector-ALU kernel, which spreads 4 envs per workgroup over
     // the chip (0.50 ms at N = 8 192, 0.86 ms at 16 384): crossover N ~ 10 000.
-    if (w.split3 && (w.on_mfma == 2 || (w.on_mfma == 1 && N >= kMfmaMinEnvs))) {
+    // (a wave of the split-operand kernel is through its 25 tiles in ~0.16 ms: it overtakes the vector kernel near 2 000 envs)
+    if (w.split3 && (w.on_mfma == 2 || (w.on_mfma == 1 && N >= kSplitMinEnvs))) {
         // ZENV_MLP_BF16X3 / ZENV_MLP_F16X3: three 16-bit products per k-step on hi / lo operands
         const int epw = N <= 32768 ? 32 : 64;
         const dim3 grid((N + kZoneWaves * epw - 1) / (kZoneWaves * epw)), block(kZoneWaves * 64);

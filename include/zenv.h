@@ -300,7 +300,7 @@ enum {
                          * operand: weights of 32 768 or more are refused by zenv_mlp_load (ZENV_E_RANGE); an input or
                          * activation that reaches 65 520 is caught on the device and reported as ZENV_E_RANGE by the next
                          * call that waits for it (zenv_get*, zenv_sync, zenv_rollout, zenv_step_results).
-                         * Batches too small for the matrix kernels (< 10 240 envs) run the float32 vector kernel in both. */
+                         * Batches too small for the matrix kernel (< 2 048 envs) run the float32 vector kernel in both. */
 };
 typedef struct zenv_mlp_weights {
     int32_t h_dim;

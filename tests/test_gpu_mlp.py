@@ -503,3 +503,24 @@ def test_float16_range_is_enforced(zenv_mod, monkeypatch):
     mu, std = env.mlp_forward()
     assert np.abs(mu - P.forward_fp32(t, obs, zo)[0]).max() <= 3e-6
     env.close()
+
+
+def test_split_mode_takes_over_from_the_vector_kernel_at_2048_envs(zenv_mod):
+    """Default kernel choice of ZENV_MLP_F16X3 by batch size: the float32 vector kernel below 2 048 envs, k_mlp_zone_s3
+    from there on -- both within the mode's tolerance, and not the same arithmetic."""
+    from oracle import policy_ref as P
+    Z = zenv_mod
+    outs = {}
+    for n in (2047, 2048 + 65):
+        env = _env_with_obs(Z, "PointTSP-v0", n, 20)
+        t = P.random_tensors(env.zone_feat, h=185, seed=4, critic=True)
+        env.load_mlp(t, precision="f16x3")
+        out = env.mlp_forward(with_value=True)
+        obs, zo = env.observations()
+        ref = P.forward_fp32(t, obs, zo)
+        for name, a, b in zip(("mu", "std", "value"), out, ref):
+            assert np.abs(a - b).max() <= 3e-6, (n, name, float(np.abs(a - b).max()))
+        env.load_mlp(t, precision="f32")
+        outs[n] = float(np.abs(env.mlp_forward(with_value=True)[2] - out[2]).max())
+        env.close()
+    assert outs[2047] == 0.0 and outs[2048 + 65] > 0.0
