@@ -36,6 +36,11 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool: the host driver only supports dmabuf IPC, and without this RCCL's
+# hipIpcGetMemHandle fails.  The launcher exports it; kept here for a launch that does not (read when HSA initialises,
+# i.e. at the first HIP call, long after this line)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
