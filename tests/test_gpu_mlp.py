@@ -524,3 +524,24 @@ def test_split_mode_takes_over_from_the_vector_kernel_at_2048_envs(zenv_mod):
         outs[n] = float(np.abs(env.mlp_forward(with_value=True)[2] - out[2]).max())
         env.close()
     assert outs[2047] == 0.0 and outs[2048 + 65] > 0.0
+
+
+def test_split_modes_at_odd_sizes(zenv_mod):
+    """scripts/mlp_split_fuzz.py: random widths (around every 32-feature tile edge, down to 1), zone counts 1-30, batch
+    sizes around the 32-env group edges, weight scales 0.1-3, all three tasks, both critics -- the split-operand kernel
+    against the torch float32 restatement, held to its tolerance or to a multiple of the float32 kernel's own error
+    where the weights make the activations large."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "mlp_split_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "mlp_split_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    keep = os.environ.get("ZENV_MLP_F32_MFMA")
+    try:
+        spec.loader.exec_module(mod)
+        assert mod.run(24) == 0
+    finally:
+        if keep is None:
+            os.environ.pop("ZENV_MLP_F32_MFMA", None)
+        else:
+            os.environ["ZENV_MLP_F32_MFMA"] = keep
