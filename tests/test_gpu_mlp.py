@@ -226,8 +226,10 @@ def test_mlp_policy_actions_and_rollout(zenv_mod):
     env.close()
 
 
-@pytest.mark.parametrize("env_id,goals", [("PointTSP-v1", False), ("PointTTSP-v1", False), ("PointTSP-v0", True)])
-def test_collect_experiences(zenv_mod, oracle_mod, env_id, goals):
+@pytest.mark.parametrize("env_id,goals,precision", [("PointTSP-v1", False, "bf16"), ("PointTTSP-v1", False, "bf16"),
+                                                    ("PointTSP-v0", True, "bf16"), ("PointTSP-v1", False, "f16x3"),
+                                                    ("ColourMatch-v0", False, "f32")])
+def test_collect_experiences(zenv_mod, oracle_mod, env_id, goals, precision, monkeypatch):
     """BaseAlgo.collect_experiences (base.py:131-227) on the device.  The recorded actions
     replayed through the oracle reproduce the recorded observations and rewards bit for bit (the env half);
     log_prob, masks and the GAE recursion are recomputed in numpy from the recorded values (the bookkeeping
@@ -243,7 +245,9 @@ def test_collect_experiences(zenv_mod, oracle_mod, env_id, goals):
         env.enable_goals()
     env.reset()
     t = P.random_tensors(env.zone_feat, seed=2, critic=True)
-    env.load_mlp(t)
+    if precision != "bf16":
+        monkeypatch.setenv("ZENV_MLP_F32_MFMA", "1")      # the matrix kernels of the float32-grade modes, also at 70 envs
+    env.load_mlp(t, precision=precision)
     refs = [O.OracleEnv(oracle_config_from(O, cfg)) for _ in range(n)]
     for i, e in enumerate(refs):
         e.reset(5 + i)
@@ -281,11 +285,17 @@ def test_collect_experiences(zenv_mod, oracle_mod, env_id, goals):
         if goals:
             break                                      # the rewards recorded above were the shaped ones
         # ---- bookkeeping half
-        mu, std, val = P.forward_bf16_emulated(t, x["obs"].reshape(-1, 8), x["zone_obs"].reshape(n * T, cfg.num_zones, -1))
-        assert np.abs(val.reshape(n, T) - x["value"]).max() < 4e-3
+        flat = (x["obs"].reshape(-1, 8), x["zone_obs"].reshape(n * T, cfg.num_zones, -1))
+        if precision == "bf16":
+            mu, std, val = P.forward_bf16_emulated(t, *flat)
+            tol_v, tol_lp = 4e-3, 0.15                     # mu / std carry the 4e-3 bf16 tolerance, divided by std
+        else:                                              # the float32-grade modes: the reference's own arithmetic
+            mu, std, val = P.forward_fp32(t, *flat)
+            tol_v, tol_lp = 1e-5, 2e-3
+        assert np.abs(val.reshape(n, T) - x["value"]).max() < tol_v
         mu, std = mu.reshape(n, T, 2), std.reshape(n, T, 2)
         lp = -0.5 * ((x["action"] - mu) / std) ** 2 - np.log(std) - 0.5 * np.log(2 * np.pi)
-        assert np.abs(lp - x["log_prob"]).max() < 0.15      # mu / std carry the 4e-3 bf16 tolerance, divided by std
+        assert np.abs(lp - x["log_prob"]).max() < tol_lp
         _, _, next_value = env.mlp_forward(with_value=True)
         nv, nm, na = next_value.astype(np.float32), prev_mask.copy(), np.zeros(n, np.float32)
         adv = np.zeros((n, T), np.float32)
