@@ -1065,6 +1065,21 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     size_t offs[8];
     if (pack_images(*w, h->p.F, img, offs) != 0)
         return fail(ZENV_E_ARG, "h_dim %d outside [1, %d]", w->h_dim, kMlpHP - 1);
+    std::vector<float> f32;         // the float32-grade modes' images (packed before the handle is touched: it can refuse)
+    size_t fo[30];
+    if (w->precision != ZENV_MLP_BF16) {
+        pack_f32(*w, h->p.F, f32, fo);
+        if (w->precision == ZENV_MLP_F16X3) {
+            // the float16 images start at fo[24] (zone_net_.2): combine_net_ arrives with zone_net_.4 folded in, a product of
+            // two in-range matrices that need not be in range itself
+            const uint16_t *hw = reinterpret_cast<const uint16_t *>(f32.data() + fo[24]);
+            const size_t n16 = (f32.size() - fo[24]) * 2;
+            for (size_t i = 0; i < n16; ++i)
+                if ((hw[i] & 0x7C00u) == 0x7C00u)
+                    return fail(ZENV_E_RANGE, "combine_net_ folded over zone_net_.4 leaves float16's range: use ZENV_MLP_BF16X3 "
+                                              "or ZENV_MLP_F32 for these weights");
+        }
+    }
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1088,9 +1103,6 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
                         n_critic ? base + offs[6] : nullptr, n_critic ? base + offs[7] : nullptr, nullptr,
                         n_sigma == 2 ? 1 : 0 };
     if (w->precision != ZENV_MLP_BF16) {
-        std::vector<float> f32;
-        size_t fo[30];
-        pack_f32(*w, h->p.F, f32, fo);
         // (diagnostic: ZENV_MLP_F32_VALU=1 runs the network on the vector ALU, k_mlp_f32, instead of the f32 MFMA)
         // ZENV_MLP_F32_MFMA=1 the MFMA kernel whatever the batch; default: by batch size, see launch_mlp_forward_f32)
         const int on_mfma = std::getenv("ZENV_MLP_F32_VALU") ? 0 : std::getenv("ZENV_MLP_F32_MFMA") ? 2 : 1;

@@ -495,6 +495,18 @@ def test_float16_range_is_enforced(zenv_mod, monkeypatch):
         env.load_mlp(big, precision="f16x3")
     assert e.value.code == Z.E_RANGE and "actor.enc_.0.0.weight" in str(e.value)
     env.load_mlp(big, precision="bf16x3")
+    fold = dict(t)                                                       # each matrix in range, their folded product not
+    fold["zone_w3"] = (t["zone_w3"] * 3.0e3).astype(np.float32)
+    fold["comb_w"] = (t["comb_w"] * 3.0e3).astype(np.float32)
+    assert max(np.abs(fold["zone_w3"]).max(), np.abs(fold["comb_w"]).max()) < 32768
+    env.load_mlp(t, precision="f16x3")
+    before = env.mlp_forward()
+    with pytest.raises(Z.ZenvError) as e:
+        env.load_mlp(fold, precision="f16x3")
+    assert e.value.code == Z.E_RANGE and "folded" in str(e.value)
+    after = env.mlp_forward()                                            # a refused load leaves the loaded network alone
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    env.load_mlp(fold, precision="bf16x3")
     hot = dict(t)
     hot["zone_w1"] = (t["zone_w1"] * 1.0e3).astype(np.float32)          # every weight < 32 768, second-layer outputs ~1e6
     hot["zone_w2"] = (t["zone_w2"] * 1.0e3).astype(np.float32)
