@@ -1,0 +1,55 @@
+"""The reference's own PointTSP animation (gifs/pointtsp.gif, a rendering by the real MuJoCo stack) against the oracle's
+model constants: DESIGN.md section 0.2.  The track was extracted once by tests/golden/make_gif_track.py (data only); the
+fit is scripts/gif_dynamics_evidence.py.  This is evidence for ONE constant (the geom density of point.xml, i.e. the
+time constant m / b), not a parity pin: the oracle stays "parity unpinned" for the dynamics half."""
+import importlib.util
+import os
+
+import numpy as np
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _mod():
+    spec = importlib.util.spec_from_file_location("gif_dynamics_evidence",
+                                                  os.path.join(ROOT, "scripts", "gif_dynamics_evidence.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_metric_scale_of_the_animation_is_consistent_with_the_placement_rule():
+    """Three in-tree constants fix the picture's scale independently: the zone radius (ZoneEnvBase.py:51), and the
+    placement rule's bounds (ZoneEnvBase.py:50,52: no zone beyond 3 - 0.55, no two closer than 1.1)."""
+    g = _mod()
+    tr = g.load_track()
+    lo, hi = g.scale_window(tr["raw_zones"])
+    assert lo < hi and lo - 0.01 <= tr["scale"] <= hi + 0.01
+    assert len(tr["zones"]) == 15 and tr["visited"][-1] == 14 and len(tr["robot"]) == 57
+    # the homography behind the numbers: interior tile boundaries land on whole tiles
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "gif_pointtsp_track.json")) as fh:
+        d = json.load(fh)
+    row = np.array(d["tile_check_row"])
+    assert len(row) == 19 and np.abs(row - np.arange(1, 20)).max() < 0.08
+
+
+def test_animation_track_needs_the_oracles_time_constant_not_the_five_times_heavier_robot():
+    """With the time base the plateau speed sets (terminal speed 1.5 m/s = the oracle's g F / b and the normaliser of
+    ZoneEnvBase.py:223), a robot with the oracle's m / b follows the measured track to about 5 cm rms; the density-5
+    robot (the alternative SURVEY.md A.3 could not exclude) misses it by half a metre whatever it does."""
+    g = _mod()
+    tr = g.load_track()
+    cfg = O.default_config(O.TASK_TSP, 15)
+    tau, v_term = cfg.mass / cfg.damping[0], cfg.gear * cfg.forcerange / cfg.damping[0]
+    assert abs(tau - g.constants(1.0)[0]) < 1e-12 and abs(v_term - 1.5) < 1e-12
+    disp = np.linalg.norm(np.diff(tr["robot"], axis=0), axis=1)
+    k = int(round(float(np.median(np.sort(disp)[-12:])) / v_term / g.H_STEP))
+    assert k == 16                                             # one frame = 16 env steps, the episode ~ 890 steps
+    light = g.track_fit(tr["robot"], tau, v_term, k, rounds=2, iters=600)
+    heavy = g.track_fit(tr["robot"], 5.0 * tau, v_term, k, rounds=2, iters=600)
+    assert light[0] < 0.065 and heavy[0] > 0.40 and heavy[1] > 1.0, (light, heavy)
+    # and with the time base left free the heavy robot still needs 1.5 x the light one's steps for the same residual
+    assert g.track_fit(tr["robot"], 5.0 * tau, v_term, 24, rounds=2, iters=600)[0] > light[0]
