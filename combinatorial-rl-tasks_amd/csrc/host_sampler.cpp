@@ -327,29 +327,72 @@ void det_sincos(double x, double &s, double &c) { det_sincos_inl(x, s, c); }
 
 void route_ranks(double robot_x, double robot_y, const double (*zone_xy)[2], int Z, int32_t *rank)
 {
-    // node 0 = the robot (depot), nodes 1..Z = zones
+    // What TSP_Solver.get_optim_route (main/src/utils/TSP_Solver.py:24-62) asks OR-tools for, restated without OR-tools:
+    // a closed tour over node 0 = the robot (depot) and nodes 1..Z = the zones, arc cost = the callback's 10 x distance
+    // as the routing library's int64 sees it (truncated), first solution PATH_CHEAPEST_ARC, then the default local search
+    // (greedy descent, first improvement) to a local optimum.  The library's own operator order and tie-breaks are not
+    // reproducible without it: this is the same problem, the same first solution and the same kind of local optimum
+    // (relocate, exchange, 2-opt, or-opt of chains up to 3), not its bit-exact route -- a caller who has OR-tools passes
+    // its ranks instead (zenv_bank_set / route_fn).
     const int n = Z + 1;
     std::vector<double> x(n), y(n);
     x[0] = robot_x; y[0] = robot_y;
     for (int z = 0; z < Z; ++z) { x[z + 1] = zone_xy[z][0]; y[z + 1] = zone_xy[z][1]; }
-    auto d = [&](int a, int b) { return std::sqrt((x[a] - x[b]) * (x[a] - x[b]) + (y[a] - y[b]) * (y[a] - y[b])); };
+    std::vector<int64_t> cost((size_t)n * n);
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b)
+            cost[(size_t)a * n + b] =
+                (int64_t)(std::sqrt((x[a] - x[b]) * (x[a] - x[b]) + (y[a] - y[b]) * (y[a] - y[b])) * 10.0);
+    auto d = [&](int a, int b) { return cost[(size_t)a * n + b]; };
+    // PATH_CHEAPEST_ARC: extend the path from the depot by the cheapest arc to a free node, lowest index on ties
     std::vector<int> tour(1, 0);
     std::vector<char> used(n, 0);
     used[0] = 1;
-    for (int step = 1; step < n; ++step) {           // nearest neighbour, lowest index on ties
+    for (int step = 1; step < n; ++step) {
         int best = -1;
         for (int c = 1; c < n; ++c)
             if (!used[c] && (best < 0 || d(tour.back(), c) < d(tour.back(), best))) best = c;
         used[best] = 1;
         tour.push_back(best);
     }
-    bool improved = true;                            // 2-opt on the closed tour, depot fixed at position 0
+    auto at = [&](int i) { return tour[i % n]; };            // closed: position n is the depot again
+    auto length = [&]() {
+        int64_t s = 0;
+        for (int i = 0; i < n; ++i) s += d(at(i), at(i + 1));
+        return s;
+    };
+    bool improved = n > 3;
     while (improved) {
         improved = false;
-        for (int i = 1; i < n - 1; ++i)
-            for (int j = i + 1; j < n; ++j) {
-                const int a = tour[i - 1], b = tour[i], c = tour[j], e = tour[(j + 1) % n];
-                if (d(a, c) + d(b, e) < d(a, b) + d(c, e) - 1e-12) {
+        // or-opt / relocate: the chain tour[i .. i + len - 1] moves between tour[j] and tour[j + 1], orientation kept
+        for (int len = 1; len <= 3 && !improved; ++len)
+            for (int i = 1; i + len <= n && !improved; ++i)
+                for (int j = 0; j < n && !improved; ++j) {
+                    if (j >= i - 1 && j < i + len) continue;               // the chain itself or its own predecessor
+                    const int p = at(i - 1), f = at(i), l = at(i + len - 1), q = at(i + len), a = at(j), b = at(j + 1);
+                    const int64_t gain = d(p, f) + d(l, q) + d(a, b) - d(p, q) - d(a, f) - d(l, b);
+                    if (gain <= 0) continue;
+                    std::vector<int> chain(tour.begin() + i, tour.begin() + i + len), rest;
+                    for (int k = 0; k < n; ++k)
+                        if (k < i || k >= i + len) rest.push_back(tour[k]);
+                    const int where = (int)(std::find(rest.begin(), rest.end(), a) - rest.begin()) + 1;
+                    rest.insert(rest.begin() + where, chain.begin(), chain.end());
+                    tour = rest;
+                    improved = true;
+                }
+        // exchange: two zones swap places
+        for (int i = 1; i < n && !improved; ++i)
+            for (int j = i + 1; j < n && !improved; ++j) {
+                const int64_t before = length();
+                std::swap(tour[i], tour[j]);
+                if (length() < before) improved = true;
+                else std::swap(tour[i], tour[j]);
+            }
+        // 2-opt: reverse tour[i .. j]
+        for (int i = 1; i < n - 1 && !improved; ++i)
+            for (int j = i + 1; j < n && !improved; ++j) {
+                const int a = at(i - 1), b = at(i), c = at(j), e = at(j + 1);
+                if (d(a, c) + d(b, e) < d(a, b) + d(c, e)) {
                     std::reverse(tour.begin() + i, tour.begin() + j + 1);
                     improved = true;
                 }

@@ -385,6 +385,9 @@ __device__ __forceinline__ bf16x8 zone_frag(const ZoneRow &x, const uint4 obs_fr
 
 constexpr int kZone1Waves = 4;
 constexpr int kMlpSplitMaxEnvs = 8192;    // at most this many envs: zone tiles of a 32-env group split over the workgroup's waves
+#ifndef MLP_TIE
+#define MLP_TIE 1          // fragment pins tied into the accumulation chain (see zone_tile); 0: the round-2 kernel
+#endif
 #ifndef MLP_GAPS
 #define MLP_GAPS 6          // MFMA gaps that carry VALU work in a region ...
 #define MLP_PER_GAP 6       // ... and instructions per gap (32 per region: 16 + 16 conversions)
@@ -430,7 +433,20 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
         const f32x16 prev = acc[(n + 1) & 1];                   // the chain before this one (n = 0: pend)
         acc[n & 1] = zero16();
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc[n & 1] = mfma(xa[kk], in_agpr(wf[n & 1][kk]), acc[n & 1]);
+        for (int kk = 0; kk < KS; ++kk) {
+#if MLP_TIE
+            // the fragment's AGPR pin is tied to the running accumulator, so it sits between the chain's MFMAs kk - 1 and
+            // kk and the wait for its ds_read with it: lgkmcnt(11 - kk) in front of MFMA kk.  Untied, all twelve pins
+            // (and a lgkmcnt(0)) were hoisted to the head of the region -- the chain's first MFMA waited for the reads
+            // issued three MFMAs earlier, with nothing but the two pooling products in the matrix pipe.
+            bf16x8 b = wf[n & 1][kk];
+            if (kk == 0) asm("" : "+a"(b));
+            else asm("" : "+a"(b), "+v"(acc[n & 1]));
+            acc[n & 1] = mfma(xa[kk], b, acc[n & 1]);
+#else
+            acc[n & 1] = mfma(xa[kk], in_agpr(wf[n & 1][kk]), acc[n & 1]);
+#endif
+        }
         {
             bf16x8 f0, f1;
 #if defined(MLP_EXP) && (MLP_EXP & 1)      // diagnostic: no conversion of the previous chain

@@ -271,7 +271,7 @@ class TSPOrderEnv(TSPEnv):
     """PointTSP-v2 (main/envs/TSP_order_env.py:13-113): the observation carries the visiting order of the cities
     (7th row feature 0.5^i for the i-th city of the remaining route) and info['shaped_reward'] is the progress
     towards the next city of the route.  The reference gets the route from OR-tools (:49-50, not available
-    here); this class uses the library's nearest-neighbour + 2-opt tour, or ``route_fn(robot_xyrot, zone_xy)
+    here); this class uses the library's own solution of the same problem (PATH_CHEAPEST_ARC + local search), or ``route_fn(robot_xyrot, zone_xy)
     -> rank[Z]`` when the caller brings a solver.
 
     Deliberate deviation: the reference's reset() builds the first observation BEFORE generate_route() (:108-113), so

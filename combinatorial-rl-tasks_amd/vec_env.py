@@ -123,7 +123,8 @@ def sample_layout(cfg, seed):
 
 def route_ranks(robot_xy, zone_xy):
     """The built-in visiting order of a layout (TSPOrderEnv without OR-tools): rank[z] = position of zone z in a
-    nearest-neighbour + 2-opt tour from the robot."""
+    tour: TSP_Solver.get_optim_route's problem (closed tour from the robot, int64(10 x distance) arcs,
+    PATH_CHEAPEST_ARC + local search) solved without OR-tools."""
     r = np.ascontiguousarray(robot_xy, np.float64)[:2].copy()
     z = np.ascontiguousarray(zone_xy, np.float64)
     rank = np.zeros(z.shape[0], np.int32)
@@ -288,7 +289,7 @@ class ZoneVecEnv:
     # ------------------------------------------------------------------ solver-ordered variant (8(f) row 3)
     def enable_order(self):
         """TSPOrderEnv semantics (TSP_order_env.py:13-113); call before build_bank / set_bank -- an episode's
-        route is the bank's aux column (built-in nearest-neighbour + 2-opt tour, or the caller's ranks)."""
+        route is the bank's aux column (built-in PATH_CHEAPEST_ARC + local-search tour, or the caller's ranks)."""
         check(lib().zenv_order_enable(self._h))
 
     def order_info(self):

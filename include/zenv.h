@@ -278,8 +278,10 @@ int zenv_solver_goals(zenv_t *h, int32_t *goals);
  * of every zone (ZENV_F_ORDER_VAL, :37-47) -- the reference's (Z,7) row is [zone_obs row (6), order value].
  * Exclusive with zenv_goal_enable; zenv_rollout() is refused on such a handle. */
 int zenv_order_enable(zenv_t *h);
-/* The built-in route of a layout (host only): rank[z] = position of zone z in the nearest-neighbour + 2-opt tour
- * that starts at the robot. */
+/* The built-in route of a layout (host only): rank[z] = position of zone z in the tour.  The problem is the one
+ * TSP_Solver.get_optim_route (main/src/utils/TSP_Solver.py:24-62) hands to OR-tools -- closed tour from the robot, arc
+ * cost int64(10 x distance), first solution PATH_CHEAPEST_ARC, greedy-descent local search (relocate, exchange, 2-opt,
+ * or-opt) to a local optimum -- solved without the library: the same kind of tour, not its bit-exact route. */
 int zenv_route_ranks(const double *robot_xy, const double *zone_xy, int num_zones, int32_t *rank);
 
 /* ---- the reference's actor network on the device ----

@@ -1,7 +1,7 @@
 // Diagnostic: where one wave of K4 (k_mlp_zone) spends a row tile.  Builds the kernel file itself with
 // -DMLP_STAMP=<wave>, runs it on random weights / rows and prints the median cycles between the stamps.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DMLP_STAMP=0 \
-//         -I include scripts/probes/k4_stamps.hip -o gpurun_out/k4_stamps && gpurun_out/k4_stamps
+//         -I include scripts/probes/k4_stamps.hip combinatorial-rl-tasks_amd/csrc/mlp_f32.hip -o gpurun_out/k4_stamps && gpurun_out/k4_stamps
 #include "../../combinatorial-rl-tasks_amd/csrc/mlp_policy.hip"
 
 #include <algorithm>
@@ -10,8 +10,9 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-int main()
+int main(int argc, char **argv)
 {
+    const int iters = argc > 1 ? atoi(argv[1]) : 20;      // timed forwards (power management settles over ~100 ms: use >= 1000 for A/B)
     using namespace zenvk;
     const int N = 65536, Z = 25, F = 6, h = 185;
     std::mt19937 g(1);
@@ -48,9 +49,10 @@ int main()
 #endif
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 20; ++i) CK(launch_mlp_forward(img, N, Z, F, obs, zo, pooled, mu, sd, nullptr, no_mlp_action(), nullptr));
+    for (int i = 0; i < 20; ++i) CK(launch_mlp_forward(img, N, Z, F, obs, zo, pooled, mu, sd, nullptr, nullptr, no_mlp_action(), nullptr));
+    for (int i = 0; i < iters / 2; ++i) CK(launch_mlp_forward(img, N, Z, F, obs, zo, pooled, mu, sd, nullptr, nullptr, no_mlp_action(), nullptr));
     CK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < 20; ++i) CK(launch_mlp_forward(img, N, Z, F, obs, zo, pooled, mu, sd, nullptr, no_mlp_action(), nullptr));
+    for (int i = 0; i < iters; ++i) CK(launch_mlp_forward(img, N, Z, F, obs, zo, pooled, mu, sd, nullptr, nullptr, no_mlp_action(), nullptr));
     CK(hipEventRecord(e1, nullptr));
     CK(hipDeviceSynchronize());
     float ms;
@@ -62,10 +64,10 @@ int main()
 #else
            0,
 #endif
-           ms / 20 * 1e3);
+           ms / iters * 1e3);
     return 0;
 #else
-    printf("K4 + K5 with stamps (wave %d): %.1f us per forward\n", (int)(MLP_STAMP), ms / 20 * 1e3);
+    printf("K4 + K5 with stamps (wave %d): %.1f us per forward\n", (int)(MLP_STAMP), ms / iters * 1e3);
     std::vector<unsigned long long> st(64 * 16);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
 #if MLP_KERNEL == 1

@@ -481,21 +481,37 @@ def test_solver_ordered_semantics_and_route_heuristic(oracle_mod, zenv_mod):
         if d:
             break
     assert visits[:2] == [1, 3]                                # the agent follows the route
-    # the product's host heuristic
+    # the product's host heuristic: TSP_Solver.get_optim_route's problem (closed tour from the robot, int64(10 x distance)
+    # arcs, PATH_CHEAPEST_ARC + local search) -- a permutation, never costlier than its own first solution, and on small
+    # maps (brute force) the optimum nearly always
+    import itertools
+
+    def int_costs(robot, zxy):
+        pts = np.vstack([robot[:2], zxy])
+        return (np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1)) * 10.0).astype(np.int64)
+
+    def tour_cost(c, order):
+        seq = [0] + [int(o) + 1 for o in order] + [0]
+        return sum(c[a, b] for a, b in zip(seq[:-1], seq[1:]))
     for seed in range(5):
         robot, zxy, _, _ = Z.sample_layout(Z.default_config(0, 15), 100 + seed)
         rk = Z.route_ranks(robot, zxy)
         assert sorted(rk) == list(range(15))
-        order = np.argsort(rk)
-
-        def tour_len(order):
-            pts = np.vstack([robot[:2], zxy[order], robot[:2]])
-            return np.sqrt(((pts[1:] - pts[:-1]) ** 2).sum(1)).sum()
-        nn, cur, left = [], robot[:2], list(range(15))
-        while left:
-            j = min(left, key=lambda z: np.hypot(*(zxy[z] - cur)))
-            nn.append(j); left.remove(j); cur = zxy[j]
-        assert tour_len(order) <= tour_len(np.array(nn)) + 1e-9
+        c = int_costs(robot, zxy)
+        first, cur, left = [], 0, list(range(15))
+        while left:                                            # PATH_CHEAPEST_ARC, lowest index on ties
+            j = min(left, key=lambda z: (c[cur, z + 1], z))
+            first.append(j); left.remove(j); cur = j + 1
+        assert tour_cost(c, np.argsort(rk)) <= tour_cost(c, first)
+    hits = 0
+    for seed in range(12):
+        robot, zxy, _, _ = Z.sample_layout(Z.default_config(0, 7), 100 + seed)
+        c = int_costs(robot, zxy)
+        best = min(tour_cost(c, p) for p in itertools.permutations(range(7)))
+        got = tour_cost(c, np.argsort(Z.route_ranks(robot, zxy)))
+        assert got <= 1.05 * best
+        hits += got == best
+    assert hits >= 10
 
 
 def test_oracle_regression_vectors(oracle_mod):
