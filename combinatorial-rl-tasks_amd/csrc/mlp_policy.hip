@@ -68,7 +68,18 @@ __device__ unsigned long long *g_k4_stamps;
         __builtin_amdgcn_sched_barrier(0);                                                                 \
     } while (0)
 #define ZT_STAMP_ARGS , wave, stamp_it++
+// two stamps per launch around the whole tile loop of block 0 / wave MLP_STAMP (slots 60, 61 of the table): cycles and
+// 100 MHz ticks without touching the loop
+#define KSTAMP_WHOLE(which)                                                                                \
+    do {                                                                                                   \
+        if (blockIdx.x == 0 && wave == (MLP_STAMP)) {                                                      \
+            unsigned long long t_, r_;                                                                     \
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory"); \
+            if (lane == 0) { g_k4_stamps[(60 + (which)) * 16] = t_; g_k4_stamps[(60 + (which)) * 16 + 15] = r_; } \
+        }                                                                                                  \
+    } while (0)
 #else
+#define KSTAMP_WHOLE(which) do { } while (0)
 #define KSTAMP(slot) do { } while (0)
 #define ZT_STAMP_ARGS
 #endif
@@ -339,6 +350,32 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
 //     the conversion + pooling of output tile n-1 inside the chain of output tile n (also across tiles);
 //   * the pooled accumulators (96 registers) live in AGPRs (inline-asm MFMA, "+a"), the W2 fragments are
 //     read from LDS straight into AGPRs by the register allocator; VGPRs hold the activations only.
+#ifndef MLP_POOL_VALU
+#define MLP_POOL_VALU 0     // 0 (shipped): the mean over an env's zone rows as two more MFMAs per output tile against the identity
+#endif                      // (bf16-rounded summands); 1: summed on the vector ALU in float32 -- measured and NOT faster, below
+// p += relu(x) in float32: with zone-major tiles the pooling product's selection matrix is the identity, so the product
+// is this register-wise sum -- 16 v_max_i32 (ReLU on the float's bits) + 8 v_pk_add_f32 per output tile instead of 16
+// conversions + 2 MFMAs, with the layer-1 fragments moved to AGPRs (8 v_accvgpr_write) to make room for 96 float32 sums.
+// Round 3, cycles per 32-row tile by two stamps around the whole loop (profiles/r03/k4_whole_loop_cycles.log): MFMA
+// pooling 3 687, no pooling at all 3 302 (every MFMA costs its 32 cycles: 12 x 32 = 384), VALU pooling 4 253 (3 919 in
+// the compiler's own order): a gap between two MFMAs of one wave hides about three vector / LDS instructions, the 48 + 12
+// of this variant do not fit into 13 gaps, and the two pooling MFMAs were the cheaper way to buy two more gaps.
+// (Written with __builtin_bit_cast on x[i] the loop compiled to sixteen copies of x[0]: keep the scalar temporaries.)
+#if MLP_POOL_VALU
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pool_add(f32x16 &p, const f32x16 &x)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const float x0 = x[i], x1 = x[i + 1];
+        const f32x2v v = { __int_as_float(max(__float_as_int(x0), 0)), __int_as_float(max(__float_as_int(x1), 0)) };
+        f32x2v q = { p[i], p[i + 1] };
+        q += v;
+        p[i] = q.x;
+        p[i + 1] = q.y;
+    }
+}
+#endif
 __device__ __forceinline__ void pool_mfma(f32x16 &p, const bf16x8 a, const bf16x8 b)
 {
     // s_nop: the operands come from VALU instructions the hazard recogniser cannot see through the asm
@@ -391,6 +428,9 @@ constexpr int kMlpSplitMaxEnvs = 8192;    // at most this many envs: zone tiles 
 #ifndef MLP_GAPS
 #define MLP_GAPS 6          // MFMA gaps that carry VALU work in a region ...
 #define MLP_PER_GAP 6       // ... and instructions per gap (32 per region: 16 + 16 conversions)
+#endif
+#ifndef MLP_V_PER_GAP
+#define MLP_V_PER_GAP 4     // MLP_POOL_VALU: vector instructions per MFMA gap (48 per region over 12 gaps)
 #endif
 #ifndef MLP_RGAPS
 #define MLP_RGAPS 6         // MFMA gaps behind those that carry the next chain's fragment reads ...
@@ -447,6 +487,21 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
             acc[n & 1] = mfma(xa[kk], in_agpr(wf[n & 1][kk]), acc[n & 1]);
 #endif
         }
+#if MLP_POOL_VALU
+#if !defined(MLP_EXP) || !(MLP_EXP & 8)    // diagnostic (bit 3): no pooling
+        pool_add(pool[(n + NT - 1) % NT], prev);
+#else
+        asm volatile("" ::"v"(prev));
+#endif
+        {
+            // layer 1's fragments go to the accumulation registers as they are made (v_accvgpr_write: the MFMA's A
+            // operand may live there), which is what leaves the 96 float32 sums room among the VGPRs
+            bf16x8 t0, t1;
+            acc_to_frags(a1, true, t0, t1);
+            xb[2 * n] = in_agpr(t0);
+            xb[2 * n + 1] = in_agpr(t1);
+        }
+#else
         {
             bf16x8 f0, f1;
 #if defined(MLP_EXP) && (MLP_EXP & 1)      // diagnostic: no conversion of the previous chain
@@ -470,9 +525,21 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
 #endif
         // (materialised here: otherwise the conversions sink into the next tile's block, behind its branch)
         asm volatile("" : "+v"(xb[2 * n]), "+v"(xb[2 * n + 1]));
+#endif
         a1 = n + 1 < NT ? mfma(w1f[n + 1], x0n, zero16())       // layer 1, next tile, output tile n + 1
                         : mfma(w1f[0], x0nn, zero16());         // ... and output tile 0 of the tile after it
-#if !defined(MLP_EXP) || !(MLP_EXP & 32)
+#if MLP_POOL_VALU && (!defined(MLP_EXP) || !(MLP_EXP & 32))
+        // order of the region: 13 MFMAs (12 of the chain + layer 1's), 48 vector instructions (16 + 8 for layer 1's
+        // fragments, 24 for the sums) and the next chain's 12 fragment reads: one MFMA ahead (the first vector
+        // instruction waits for the previous chain's last result), then 4 + 1 per gap
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int gsl = 0; gsl < 12; ++gsl) {
+            __builtin_amdgcn_sched_group_barrier(0x002, MLP_V_PER_GAP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+#elif !defined(MLP_EXP) || !(MLP_EXP & 32)
         // order of the region: two chain MFMAs ahead of the first conversion (which waits for the previous chain's
         // last result -- the new chain must not queue behind it), then six VALU instructions per MFMA gap
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -560,6 +627,7 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
         for (int j = 0; j < 8; ++j)
             ind[sgm][j] = (16 * sgm + 8 * (j >> 2) + 4 * h + (j & 3) == r) ? (__bf16)1.0f : (__bf16)0.0f;
 
+    KSTAMP_WHOLE(0);
     for (int e_base = 0; e_base < n_env; e_base += 32) {
         const bool valid = e_base + r < n_env;
         const int env = env0 + e_base + (valid ? r : 0);
@@ -575,7 +643,9 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             pool[n] = zero16();
+#if !MLP_POOL_VALU
             asm volatile("" : "+a"(pool[n]));      // AGPR-resident from here on (see pool_mfma)
+#endif
         }
         f32x16 pend = zero16();
         bf16x8 wf0[KS];
@@ -594,6 +664,10 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
             for (int m = 0; m < NT; ++m) {
                 const f32x16 acc1 = mfma(w1f[m], x0, zero16());
                 acc_to_frags(acc1, true, xa[2 * m], xa[2 * m + 1]);
+#if MLP_POOL_VALU
+                xa[2 * m] = in_agpr(xa[2 * m]);
+                xa[2 * m + 1] = in_agpr(xa[2 * m + 1]);
+#endif
             }
             x0n = zone_frag<F>(nxt, obs_frag, valid, h);                           // tile 1
             nxt = load_zone_row<F>(rows, min(zone_of(2), Z - 1));
@@ -616,6 +690,9 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
             }
         }
         // the last chain of the last tile (a wave without tiles -- split, Z < 4 -- has nothing pending)
+#if MLP_POOL_VALU
+        if (n_tiles > 0) pool_add(pool[NT - 1], pend);
+#else
         if (n_tiles > 0) {
             bf16x8 f0, f1;
             acc_to_frags(pend, true, f0, f1);
@@ -623,6 +700,7 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
             pool_mfma(pool[NT - 1], ind[1], f1);
         }
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // asm MFMA results -> v_accvgpr_read
+#endif
         if (split) {
             // waves 1-3 leave their partial sums in LDS ([register][lane]: conflict-free), wave 0 adds them in wave order
             if (wave > 0) {
@@ -652,6 +730,7 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
                     *reinterpret_cast<uint32_t *>(pooled + (size_t)(env0 + e) * HP + 32 * n + r) = pk_bf16(v, vn);
             }
     }
+    KSTAMP_WHOLE(1);
 }
 
 // ------------------------------------------------------------------------------------------ kernel 2

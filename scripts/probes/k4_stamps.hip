@@ -88,6 +88,11 @@ int main(int argc, char **argv)
     for (int it = 3; it < 50; ++it) d.push_back((long long)(st[it * 16] - st[(it - 1) * 16]));
     std::sort(d.begin(), d.end());
     printf("  whole tile (stamp 0 -> next stamp 0): median %lld   min %lld   max %lld\n", d[d.size() / 2], d.front(), d.back());
+    if (st[61 * 16] > st[60 * 16])
+        printf("  whole tile loop (two stamps per launch): %lld cycles = %.0f per tile, %.3f us, clock %.3f GHz\n",
+               (long long)(st[61 * 16] - st[60 * 16]), (double)(st[61 * 16] - st[60 * 16]) / 50.0,
+               (double)(st[61 * 16 + 15] - st[60 * 16 + 15]) * 0.01,
+               (double)(st[61 * 16] - st[60 * 16]) / ((double)(st[61 * 16 + 15] - st[60 * 16 + 15]) * 10.0));
     printf("  shader clock over tiles 4..44: %.3f GHz\n",
            (double)(st[44 * 16] - st[4 * 16]) / ((double)(st[44 * 16 + 15] - st[4 * 16 + 15]) * 10.0));
     return 0;
