@@ -376,6 +376,20 @@ __device__ __forceinline__ void pool_add(f32x16 &p, const f32x16 &x)
     }
 }
 #endif
+#ifndef MLP_POOL_SPARSE
+#define MLP_POOL_SPARSE 1   // the pooling product as ONE v_smfmac_f32_32x32x32_bf16 per output tile (K = 32: the identity is 2:4
+#endif                      // sparse) instead of two dense K = 16 products: every MFMA of this kernel costs its 32 cycles
+// Operand layout of the sparse instruction, found by experiment (scripts/probes/smfmac_layout.hip, profiles/r03/
+// smfmac_layout.log): B = the two dense K = 16 fragments back to back (registers 0-3 k-step 0, 4-7 k-step 1; lane half hb
+// element e is k = 16 (e >> 3) + 8 hb + (e & 7)); A = lane (row, half ha) holds k in [16 ha, 16 ha + 16) as four groups
+// of four with two kept values each (slots 2 g, 2 g + 1), the 2-bit position of slot i in bits [2 i + 1 : 2 i] of the
+// index register.  The identity has one non-zero per row, so the result is that of the two dense products bit for bit.
+typedef __attribute__((__vector_size__(16 * sizeof(__bf16)))) __bf16 bf16x16;
+__device__ __forceinline__ void pool_smfmac(f32x16 &p, const bf16x8 a, const bf16x8 b0, const bf16x8 b1, const int idx)
+{
+    const bf16x16 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    asm volatile("s_nop 1\n\tv_smfmac_f32_32x32x32_bf16 %0, %1, %2, %3" : "+a"(p) : "v"(a), "v"(b), "v"(idx));
+}
 __device__ __forceinline__ void pool_mfma(f32x16 &p, const bf16x8 a, const bf16x8 b)
 {
     // s_nop: the operands come from VALU instructions the hazard recogniser cannot see through the asm
@@ -441,7 +455,8 @@ constexpr int kMlpSplitMaxEnvs = 8192;    // at most this many envs: zone tiles 
 // xb; x0nn is the operand of the tile after that.  pend = the previous tile's last chain, still to be converted and pooled; wf0 = fragments of output
 // tile 0, read by the previous tile.
 __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lane, const bf16x8 (&w1f)[NT],
-                                          const bf16x8 (&ind)[2], const bf16x8 (&xa)[KS], bf16x8 (&xb)[KS],
+                                          const bf16x8 (&ind)[2], const int ind_idx, const bf16x8 (&xa)[KS],
+                                          bf16x8 (&xb)[KS],
                                           const bf16x8 x0n, const bf16x8 x0nn, f32x16 &a1, f32x16 &pend,
                                           f32x16 (&pool)[NT], bf16x8 (&wf0)[KS]
 #ifdef MLP_STAMP
@@ -511,8 +526,12 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
             acc_to_frags(prev, true, f0, f1);
 #endif
 #if !defined(MLP_EXP) || !(MLP_EXP & 8)    // diagnostic (bit 3): no pooling products
+#if MLP_POOL_SPARSE
+            pool_smfmac(pool[(n + NT - 1) % NT], ind[0], f0, f1, ind_idx);
+#else
             pool_mfma(pool[(n + NT - 1) % NT], ind[0], f0);
             pool_mfma(pool[(n + NT - 1) % NT], ind[1], f1);
+#endif
 #else
             asm volatile("" ::"v"(f0), "v"(f1));
 #endif
@@ -621,11 +640,27 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
     // the identity as the pooling product's A operand: lane (slot r, half h) element j of k-step s is tile row
     // 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the accumulator order of H2^T
     bf16x8 ind[2];
+    int ind_idx = 0;
+#if MLP_POOL_SPARSE
+    {
+        // the same identity in 2:4 form: tile row r sits at k = 16 (r >> 4) + 8 ((r >> 2) & 1) + 4 ((r >> 3) & 1) + (r & 3),
+        // i.e. lane half r >> 4, group g, position r & 3 (slot 2 g carries the 1, its partner a 0 at another position)
+        const int g = 2 * ((r >> 2) & 1) + ((r >> 3) & 1), m = r & 3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ind[0][i] = (h == (r >> 4) && i == 2 * g) ? (__bf16)1.0f : (__bf16)0.0f;
+            const int v = i == 2 * g ? m : i == 2 * g + 1 ? ((m + 1) & 3) : (i & 1);
+            ind_idx |= v << (2 * i);
+        }
+        ind[1] = ind[0];
+    }
+#else
 #pragma unroll
     for (int sgm = 0; sgm < 2; ++sgm)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             ind[sgm][j] = (16 * sgm + 8 * (j >> 2) + 4 * h + (j & 3) == r) ? (__bf16)1.0f : (__bf16)0.0f;
+#endif
 
     KSTAMP_WHOLE(0);
     for (int e_base = 0; e_base < n_env; e_base += 32) {
@@ -677,15 +712,19 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
             {
                 const bf16x8 x0nn = zone_frag<F>(nxt, obs_frag, valid, h);         // tile t + 2
                 __builtin_amdgcn_sched_barrier(0);
+#if !defined(MLP_EXP) || !(MLP_EXP & 64)   // diagnostic (bit 6): no zone-row loads inside the tile loop
                 nxt = load_zone_row<F>(rows, zone_of(t + 3));
-                zone_tile(w2s, lane, w1f, ind, xa, xb, x0n, x0nn, a1, pend, pool, wf0 ZT_STAMP_ARGS);
+#endif
+                zone_tile(w2s, lane, w1f, ind, ind_idx, xa, xb, x0n, x0nn, a1, pend, pool, wf0 ZT_STAMP_ARGS);
                 x0n = x0nn;
             }
             if (t + 1 < n_tiles) {
                 const bf16x8 x0nn = zone_frag<F>(nxt, obs_frag, valid, h);         // tile t + 3
                 __builtin_amdgcn_sched_barrier(0);
+#if !defined(MLP_EXP) || !(MLP_EXP & 64)
                 nxt = load_zone_row<F>(rows, zone_of(t + 4));
-                zone_tile(w2s, lane, w1f, ind, xb, xa, x0n, x0nn, a1, pend, pool, wf0 ZT_STAMP_ARGS);
+#endif
+                zone_tile(w2s, lane, w1f, ind, ind_idx, xb, xa, x0n, x0nn, a1, pend, pool, wf0 ZT_STAMP_ARGS);
                 x0n = x0nn;
             }
         }
@@ -696,8 +735,12 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
         if (n_tiles > 0) {
             bf16x8 f0, f1;
             acc_to_frags(pend, true, f0, f1);
+#if MLP_POOL_SPARSE
+            pool_smfmac(pool[NT - 1], ind[0], f0, f1, ind_idx);
+#else
             pool_mfma(pool[NT - 1], ind[0], f0);
             pool_mfma(pool[NT - 1], ind[1], f1);
+#endif
         }
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // asm MFMA results -> v_accvgpr_read
 #endif

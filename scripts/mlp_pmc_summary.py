@@ -10,10 +10,10 @@ for f in sorted(glob.glob(out + "/pass*/*_results.db")):
     db = sqlite3.connect(f)
     for kernel, counter, total, n in db.execute(
             "select kernel_name, counter_name, sum(value), count(*) from counters_collection group by 1, 2"):
-        if "mlp" in kernel:
+        if "mlp_zone" in kernel:
             vals[counter], name = total / n, kernel.split("(")[0]
     if dur is None:
-        row = db.execute("select avg(duration), count(*) from kernels where name like '%mlp%'").fetchone()
+        row = db.execute("select avg(duration), count(*) from kernels where name like '%mlp_zone%'").fetchone()
         if row and row[0]:
             dur = row[0]
 print("# rocprofv3 --pmc passes (scripts/mlp_pmc.sh) over `python scripts/mlp_bench.py N PRECISION short`, kernel", name)
