@@ -1,0 +1,63 @@
+"""README.md:59-69 of the reference publishes one number that needs no trained network to approach: "Solver 25.30" --
+PointTSP (15 zones), mean undiscounted return over the evaluation maps (seeds 1000000-1000099) of an agent that visits
+the zones in the TSP solver's order.  The maps are pinned (numpy goldens), so the oracle can play the same 100 maps:
+zones in the built-in route's order (the solver's problem restated, csrc/host_sampler.cpp route_ranks), a hand-written
+pursuit controller as the low level.  CPU only; run by hand:  python scripts/readme_solver_return.py
+The return of an episode is 15 + (2000 - T) / 100 for T steps, so the table's figure is a statement about T, i.e. about
+the robot's speed and time constant: DESIGN.md section 0.2."""
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def play(O, Z, density, seed, lead=0.3, gain=4.0):
+    m = density * (4.0 / 3.0 * math.pi * 0.1 ** 3 + 0.1 ** 3)
+    m_b = density * 0.1 ** 3
+    cfg = O.default_config(O.TASK_TSP, 15, mass=m, com_x=0.1 * m_b / m,
+                           inertia_zz=density * (0.4 * (4.0 / 3.0 * math.pi * 1e-3) * 0.01 + 1e-3 * (0.005 / 3) + 1e-3 * 0.01))
+    env = O.OracleEnv(cfg)
+    env.reset(seed)
+    robot, zones = env.layout
+    order = list(np.argsort(Z.route_ranks(np.array(robot[:2]), np.array(zones))))
+    tau, ret = m / 0.01, 0.0
+    for step in range(cfg.num_steps):
+        e = env.e
+        nxt = next((i for i in order if not e.visited[i]), None)
+        pos, vel = np.array(e.xpos[:]), np.array(e.xvelp[:])
+        want = np.array(e.zone_xy[nxt][:]) - pos - lead * tau * vel
+        heading = 2.0 * math.atan2(e.xquat3, e.xquat0)
+        ang = (math.atan2(want[1], want[0]) - heading + math.pi) % (2 * math.pi) - math.pi
+        fwd = 1.0 if abs(ang) < math.pi / 2 else -1.0
+        if fwd < 0:
+            ang = (ang + 2 * math.pi) % (2 * math.pi) - math.pi
+        r, done, _ = env.step((fwd, max(-1.0, min(1.0, gain * ang))))
+        ret += r
+        if done:
+            return ret, step + 1
+    return ret, cfg.num_steps
+
+
+def mean_return(O, Z, density, seeds, lead):
+    out = [play(O, Z, density, s, lead) for s in seeds]
+    return float(np.mean([o[0] for o in out])), float(np.mean([o[1] for o in out])), int(sum(o[0] > 15 for o in out))
+
+
+def main():
+    from oracle import oracle as O
+    import combinatorial_rl_tasks_amd as Z
+    seeds = range(1000000, 1000100)
+    print("README.md:59-69, PointTSP: Solver 25.30 (= 15 + (2000 - 970) / 100), best learned method 24.24, PPO 20.35-23.48")
+    for density in (1.0, 5.0):
+        for lead in (0.2, 0.3, 0.5):            # the controller's one knob: how much of tau * v it leads the target by
+            ret, steps, fin = mean_return(O, Z, density, seeds, lead)
+            print(f"density {density:g}, lead {lead}: mean return {ret:.2f}, mean episode length {steps:.0f} steps, "
+                  f"finished {fin}/100")
+
+
+if __name__ == "__main__":
+    main()

@@ -53,3 +53,19 @@ def test_animation_track_needs_the_oracles_time_constant_not_the_five_times_heav
     assert light[0] < 0.065 and heavy[0] > 0.40 and heavy[1] > 1.0, (light, heavy)
     # and with the time base left free the heavy robot still needs 1.5 x the light one's steps for the same residual
     assert g.track_fit(tr["robot"], 5.0 * tau, v_term, 24, rounds=2, iters=600)[0] > light[0]
+
+
+def test_solver_ordered_agent_reaches_the_readmes_return_on_the_evaluation_maps(zenv_mod):
+    """README.md:59-69: "Solver 25.30" on PointTSP = 15 zones in about 970 steps on the maps 1000000-1000099, which ARE
+    pinned here (numpy goldens).  The oracle's robot, zones in the built-in route's order under a hand-written pursuit
+    controller, lands within half a point of it (24.9 over all 100 maps); the density-5 robot cannot finish half of the
+    maps inside the 2 000-step horizon (scripts/readme_solver_return.py: 15.5 at its best setting)."""
+    spec = importlib.util.spec_from_file_location("readme_solver_return",
+                                                  os.path.join(ROOT, "scripts", "readme_solver_return.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    seeds = range(1000000, 1000100, 5)
+    ret, steps, finished = m.mean_return(O, zenv_mod, 1.0, seeds, 0.3)
+    assert finished == len(seeds) and 24.4 <= ret <= 25.8 and 920 <= steps <= 1060, (ret, steps)
+    heavy = max(m.mean_return(O, zenv_mod, 5.0, seeds, lead)[0] for lead in (0.2, 0.3))
+    assert heavy < 18.0, heavy
