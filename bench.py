@@ -757,11 +757,12 @@ def mlp_policy_rate(env, zones, steps=300):
         # the float32-grade modes on the 16-bit matrix instruction (hi / lo split operands, three products per k-step):
         # ZENV_MLP_F16X3 within 3e-6 of torch float32, ZENV_MLP_BF16X3 within 2e-5
         split = {}
-        for prec in ("f16x3", "bf16x3"):
+        # ... and ZENV_MLP_F16: the bf16 kernels compiled for float16 operands (an eighth of bf16's rounding error)
+        for prec, k in (("f16x3", 40), ("bf16x3", 40), ("f16", 200)):
             env.load_mlp(t, precision=prec)
-            env.rollout(5, Z.POLICY_MLP_SAMPLE, policy_seed=1)
-            msx, _ = env.rollout(40, Z.POLICY_MLP_SAMPLE, policy_seed=1)
-            split[prec + "_mode_us_per_step"] = round(msx / 40 * 1e3, 1)
+            env.rollout(max(5, k // 4), Z.POLICY_MLP_SAMPLE, policy_seed=1)
+            msx, _ = env.rollout(k, Z.POLICY_MLP_SAMPLE, policy_seed=1)
+            split[prec + "_mode_us_per_step"] = round(msx / k * 1e3, 1)
         env.load_mlp(t)
         return {"us_per_step": round(us, 1), "f32_mode_us_per_step": round(ms32 / 20 * 1e3, 1), **split,
                 "env_steps_per_s": round(n * steps / (ms * 1e-3), 1),

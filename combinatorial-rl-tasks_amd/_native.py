@@ -39,7 +39,7 @@ MLP_TENSORS = ("zone_w1", "zone_b1", "zone_w2", "zone_b2", "zone_w3", "zone_b3",
                "enc_w", "enc_b", "mu_w", "mu_b", "std_w", "std_b")
 MLP_CRITIC_TENSORS = ("critic_w1", "critic_b1", "critic_w2", "critic_b2")   # optional, all or none
 MLP_SIGMA_TENSORS = ("critic_sigma_w", "critic_sigma_b")   # optional: the distributional critic (critic_w2 = critic_mu)
-MLP_BF16, MLP_F32, MLP_BF16X3, MLP_F16X3 = 0, 1, 2, 3
+MLP_BF16, MLP_F32, MLP_BF16X3, MLP_F16X3, MLP_F16 = 0, 1, 2, 3, 4
 
 
 class MlpWeights(C.Structure):

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libzenv_hip.so")
-SOURCES = ["kernels.hip", "mlp_policy.hip", "mlp_f32.hip", "zenv_api.cpp", "host_sampler.cpp"]
+SOURCES = ["kernels.hip", "mlp_policy.hip", "mlp_policy_f16.hip", "mlp_f32.hip", "zenv_api.cpp", "host_sampler.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-pass-failed",
          # MFMA results land in VGPRs where they are converted to the next layer's bf16 operand anyway:

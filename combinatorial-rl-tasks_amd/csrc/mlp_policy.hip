@@ -39,7 +39,21 @@
 namespace zenvk {
 namespace {
 
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+// The 16-bit element type of every operand.  This file is compiled twice: as it stands (bf16: float32's range, 8
+// significant bits) and through mlp_policy_f16.hip with MLP_ELEM_F16 (float16: 11 significant bits -- the same kernels
+// at the same speed with an eighth of the rounding error, ZENV_MLP_F16 -- and float16's range, which zenv_mlp_load
+// bounds at load time for the zone layers and k_mlp_head watches at run time).  The names below keep "bf16".
+#ifndef MLP_ELEM_F16
+#define MLP_ELEM_F16 0
+#endif
+#if MLP_ELEM_F16
+typedef _Float16 elem_t;
+#define MLP_SFX "f16"
+#else
+typedef __bf16 elem_t;
+#define MLP_SFX "bf16"
+#endif
+typedef __attribute__((__vector_size__(8 * sizeof(elem_t)))) elem_t bf16x8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 constexpr int kWave = 64;
 constexpr int NT = kMlpNT, KS = kMlpKS, HP = kMlpHP;
@@ -87,7 +101,11 @@ __device__ unsigned long long *g_k4_stamps;
 __device__ __forceinline__ bf16x8 as_frag(const uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ f32x16 mfma(const bf16x8 a, const bf16x8 b, const f32x16 c)
 {
+#if MLP_ELEM_F16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ f32x16 zero16()
 {
@@ -110,7 +128,7 @@ __device__ __forceinline__ bf16x8 relu_bf16(const bf16x8 f)
 // two floats -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32.  Converting element
 // by element makes the compiler emit a cvt per element plus a v_perm to pair them up.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef elem_t bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b)
 {
     const f32x2_t v = { a, b };
@@ -198,7 +216,7 @@ constexpr int NH = NT / MLP_SPLIT;       // output tiles per wave
 template <int ZT, int F>
 __global__ __launch_bounds__(kZoneWaves * kWave) __attribute__((amdgpu_waves_per_eu(MLP_SPLIT, MLP_SPLIT)))
 void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, const float *__restrict__ zone_obs,
-                __bf16 *__restrict__ pooled)
+                elem_t *__restrict__ pooled)
 {
     extern __shared__ uint4 lds[];
     uint4 *w2s = lds;                       // [NT*KS][64]
@@ -217,7 +235,7 @@ void k_mlp_zone(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, c
     const int n_env = min(kWave, N - env0), n_rows = n_env * Z;
     const float inv_z = 1.0f / (float)Z;
     const float *zrows = zone_obs + (size_t)env0 * Z * F;
-    const __bf16 one = (__bf16)1.0f, nil = (__bf16)0.0f;
+    const elem_t one = (elem_t)1.0f, nil = (elem_t)0.0f;
     // layer 1's six fragments stay in registers for the whole kernel (read just in time from LDS they cost an
     // exposed LDS round trip per MFMA)
     bf16x8 w1f[NT];
@@ -384,17 +402,19 @@ __device__ __forceinline__ void pool_add(f32x16 &p, const f32x16 &x)
 // element e is k = 16 (e >> 3) + 8 hb + (e & 7)); A = lane (row, half ha) holds k in [16 ha, 16 ha + 16) as four groups
 // of four with two kept values each (slots 2 g, 2 g + 1), the 2-bit position of slot i in bits [2 i + 1 : 2 i] of the
 // index register.  The identity has one non-zero per row, so the result is that of the two dense products bit for bit.
-typedef __attribute__((__vector_size__(16 * sizeof(__bf16)))) __bf16 bf16x16;
+typedef __attribute__((__vector_size__(16 * sizeof(elem_t)))) elem_t bf16x16;
 __device__ __forceinline__ void pool_smfmac(f32x16 &p, const bf16x8 a, const bf16x8 b0, const bf16x8 b1, const int idx)
 {
     const bf16x16 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-    asm volatile("s_nop 1\n\tv_smfmac_f32_32x32x32_bf16 %0, %1, %2, %3" : "+a"(p) : "v"(a), "v"(b), "v"(idx));
+    asm volatile("s_nop 1\n\tv_smfmac_f32_32x32x32_" MLP_SFX " %0, %1, %2, %3" : "+a"(p) : "v"(a), "v"(b), "v"(idx));
 }
+#if !MLP_POOL_SPARSE
 __device__ __forceinline__ void pool_mfma(f32x16 &p, const bf16x8 a, const bf16x8 b)
 {
     // s_nop: the operands come from VALU instructions the hazard recogniser cannot see through the asm
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(p) : "v"(a), "v"(b));
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_" MLP_SFX " %0, %1, %2, %0" : "+a"(p) : "v"(a), "v"(b));
 }
+#endif
 
 // Pins a fragment to the accumulation registers (a value defined by an "a"-constrained asm can only be allocated
 // there); MFMA A/B operands and ds_read destinations may be AGPRs, so this costs no instruction -- it only keeps
@@ -586,7 +606,7 @@ __device__ __forceinline__ void zone_tile(const uint4 *__restrict__ w2s, int lan
 template <int ZT, int F, bool SPLIT>
 __global__ __launch_bounds__(kZone1Waves * kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, const float *__restrict__ zone_obs,
-                 __bf16 *__restrict__ pooled, int envs_per_wave)
+                 elem_t *__restrict__ pooled, int envs_per_wave)
 {
     // Batch layout (launch_mlp_forward picks it by N so that a small batch still spreads over the chip):
     //   !SPLIT: a wave owns envs_per_wave (64 or 32) envs and all their zone tiles;
@@ -648,7 +668,7 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
         const int g = 2 * ((r >> 2) & 1) + ((r >> 3) & 1), m = r & 3;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            ind[0][i] = (h == (r >> 4) && i == 2 * g) ? (__bf16)1.0f : (__bf16)0.0f;
+            ind[0][i] = (h == (r >> 4) && i == 2 * g) ? (elem_t)1.0f : (elem_t)0.0f;
             const int v = i == 2 * g ? m : i == 2 * g + 1 ? ((m + 1) & 3) : (i & 1);
             ind_idx |= v << (2 * i);
         }
@@ -659,7 +679,7 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
     for (int sgm = 0; sgm < 2; ++sgm)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            ind[sgm][j] = (16 * sgm + 8 * (j >> 2) + 4 * h + (j & 3) == r) ? (__bf16)1.0f : (__bf16)0.0f;
+            ind[sgm][j] = (16 * sgm + 8 * (j >> 2) + 4 * h + (j & 3) == r) ? (elem_t)1.0f : (elem_t)0.0f;
 #endif
 
     KSTAMP_WHOLE(0);
@@ -673,6 +693,14 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
             const float4 a = o[0], b = o[1];
             obs_frag = make_uint4(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w));
             if (!valid) obs_frag = make_uint4(0u, 0u, 0u, 0u);
+#if MLP_ELEM_F16
+            // float16: zenv_mlp_load has bounded the zone layers' activations for observations up to kMlpF16ObsBound (the
+            // zone rows are bounded by construction); an env beyond it -- a robot driven 190 m out of the arena -- voids
+            // that bound and is reported like an overflow
+            const float om = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                                   fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+            if (valid && !(om <= kMlpF16ObsBound) && img.range_flag) *img.range_flag = 1;
+#endif
         }
         f32x16 pool[NT];
 #pragma unroll
@@ -809,7 +837,7 @@ __device__ __forceinline__ void stage_fence()
 // and all six accumulators live); xin and xout are different registers.
 template <int NK, bool RELU>
 __device__ __forceinline__ void head_layer(const uint4 *buf, int lane, const bf16x8 (&xin)[KS], const bf16x8 xo,
-                                           bf16x8 (&xout)[KS])
+                                           bf16x8 (&xout)[KS], float &mx)
 {
     f32x16 acc[2];
 #pragma unroll
@@ -820,13 +848,20 @@ __device__ __forceinline__ void head_layer(const uint4 *buf, int lane, const bf1
             for (int kk = 0; kk < KS; ++kk) acc[m & 1] = mfma(as_frag(buf[(m * NK + kk) * kWave + lane]), xin[kk], acc[m & 1]);
             if (NK > KS) acc[m & 1] = mfma(as_frag(buf[(m * NK + KS) * kWave + lane]), xo, acc[m & 1]);
         }
-        if (m > 0) acc_to_frags(acc[(m - 1) & 1], RELU, xout[2 * (m - 1)], xout[2 * (m - 1) + 1]);
+        if (m > 0) {
+#if MLP_ELEM_F16
+            // float16: the largest value about to be rounded (behind a ReLU only the positive side matters)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, RELU ? acc[(m - 1) & 1][i] : fabsf(acc[(m - 1) & 1][i]));
+#endif
+            acc_to_frags(acc[(m - 1) & 1], RELU, xout[2 * (m - 1)], xout[2 * (m - 1) + 1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 __global__ __launch_bounds__(kHeadWaves * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf16 *__restrict__ pooled,
+void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const elem_t *__restrict__ pooled,
                 float *__restrict__ mu, float *__restrict__ stdv, float *__restrict__ value,
                 float *__restrict__ value_sigma, MlpAction act)
 {
@@ -840,6 +875,7 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
     const bool valid = first + r < N;
     const bool critic = img.wv1 != nullptr;
     float value_out = 0.f;
+    float mx = 0.f;                         // float16 build: see head_layer
 
     stage_issue(bufB, img.wc, NT * (KS + 1));
     bf16x8 xa[KS], xb[KS], xo;              // the activations ping-pong between xa and xb
@@ -856,14 +892,14 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
     // them, so the host folds them into ONE layer (pack_images: Wc' = Wc_emb W3 in float64)              xa -> xb
     stage_fence();
     stage_issue(bufA, critic ? img.wv1 : img.wa, NT * KS);
-    head_layer<KS + 1, false>(bufB, lane, xa, xo, xb);
+    head_layer<KS + 1, false>(bufB, lane, xa, xo, xb, mx);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) xa[kk] = xb[kk];          // (register renaming: the layers below read c from xa)
     // ---- value = Wv2 relu(Wv1 c)   (critic, flat_model.py:43-47), from the same embedding c     xa -> xb
     if (critic) {
         stage_fence();
         stage_issue(bufB, img.wv2, KS);
-        head_layer<KS, true>(bufA, lane, xa, xo, xb);
+        head_layer<KS, true>(bufA, lane, xa, xo, xb, mx);
         stage_fence();
         stage_issue(bufA, img.wa, NT * KS);
         f32x16 hv = zero16();
@@ -878,15 +914,20 @@ void k_mlp_head(MlpImages img, int N, const float *__restrict__ obs, const __bf1
     // ---- a = relu(Wa c)   (actor.enc_)                                                          xa -> xb
     stage_fence();
     stage_issue(bufB, img.wh, KS);
-    head_layer<KS, true>(bufA, lane, xa, xo, xb);
+    head_layer<KS, true>(bufA, lane, xa, xo, xb, mx);
     // ---- heads: rows 0-1 = mu_, rows 2-3 = std_ (lane half 0, registers 0..3)
     stage_fence();
     f32x16 hd = zero16();
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) hd = mfma(as_frag(bufB[kk * kWave + lane]), xb[kk], hd);
     if (h == 0 && valid) head_outputs(env, hd[0], hd[1], hd[2], hd[3], value_out, mu, stdv, act);
+#if MLP_ELEM_F16
+    // an activation of 65 520 or more became inf on its way to float16 (NaN compares false): tell the host
+    if (valid && !(mx < 65520.0f) && img.range_flag) *img.range_flag = 1;
+#endif
 }
 
+#if !MLP_ELEM_F16
 // ------------------------------------------------------------------------------------------ experiences
 // collect_experiences (main/src/torch_ac/algos/base.py:131-216) on the device.  Every experience buffer is TIME-major
 // [T][N][...] in memory -- the head kernel's epilogue (MlpRecord) and the GAE scan then touch whole lines, and the
@@ -925,6 +966,28 @@ __global__ __launch_bounds__(256) void k_exp_gae(ExpBuffers x, int N, const floa
     }
 }
 
+// float -> float16 bits, round to nearest even (overflow -> inf: zenv_mlp_load refuses such weights before it packs)
+uint16_t to_f16(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u, ex = (u >> 23) & 0xFFu, man = u & 0x007FFFFFu;
+    if (ex == 0xFFu) return (uint16_t)(sign | 0x7C00u | (man ? 0x200u : 0u));
+    const int e = (int)ex - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7C00u);
+    if (e <= 0) {                                        // subnormal half (or zero)
+        if (e < -10) return (uint16_t)sign;
+        const uint32_t m = (man | 0x00800000u), shift = (uint32_t)(14 - e);
+        uint32_t half = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+        if (rem > mid || (rem == mid && (half & 1u))) ++half;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((uint32_t)e << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) ++half;      // may carry into the exponent: still correct
+    return (uint16_t)(sign | half);
+}
 uint16_t to_bf16(float f)
 {
     uint32_t u;
@@ -937,11 +1000,15 @@ uint16_t to_bf16(float f)
 // logical k of element j of lane half h in k-step kk
 int k_natural(int kk, int h, int j) { return 16 * kk + 8 * h + j; }
 int k_from_acc(int kk, int h, int j) { return 32 * (kk >> 1) + 16 * (kk & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
+#endif   // !MLP_ELEM_F16 (the experience kernels and the packer exist once, in the bf16 build of this file)
 
 }  // namespace
 
+#if !MLP_ELEM_F16
+
 // One image = [n_tiles][n_ksteps] fragments of 64 lanes x 8 bf16.  Lane (r, h) of fragment (n, kk) holds
 // value(out = 32 n + r, k = order(kk, h, j)), j = 0..7.  `value` resolves a (row, logical k) pair.
+static thread_local bool g_pack_f16 = false;      // element type of the images pack_images is packing on this thread
 template <typename ValueFn, typename OrderFn>
 static void pack_image(std::vector<uint16_t> &out, int n_tiles, int n_ksteps, ValueFn value, OrderFn order)
 {
@@ -949,14 +1016,18 @@ static void pack_image(std::vector<uint16_t> &out, int n_tiles, int n_ksteps, Va
         for (int kk = 0; kk < n_ksteps; ++kk)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j)
-                    out.push_back(to_bf16(value(32 * n + (lane & 31), kk, order(kk, lane >> 5, j))));
+                {
+                    const float v = value(32 * n + (lane & 31), kk, order(kk, lane >> 5, j));
+                    out.push_back(g_pack_f16 ? to_f16(v) : to_bf16(v));
+                }
 }
 
-int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, size_t offs[8])
+int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, size_t offs[8], bool f16)
 {
     const int h = w.h_dim;
     if (h < 1 || h + 1 > kMlpHP || 8 + F > 15) return -1;
     out.clear();
+    g_pack_f16 = f16;
     // a hidden layer [h][h] whose input carries the constant 1 in feature h: bias in column h, row h keeps the 1
     auto hidden = [h](const float *W, const float *b) {
         return [=](int row, int, int k) -> float {
@@ -1023,13 +1094,23 @@ int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, si
     }
     return 0;
 }
+#endif   // !MLP_ELEM_F16
 
+#if MLP_ELEM_F16
+hipError_t launch_mlp_forward_f16(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
+                                  void *pooled_v, float *mu, float *stdv, float *value, float *value_sigma,
+                                  const MlpAction &act, hipStream_t s)
+{
+#else
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
                               void *pooled_v, float *mu, float *stdv, float *value, float *value_sigma,
                               const MlpAction &act, hipStream_t s)
 {
     if (img.f32) return launch_mlp_forward_f32(*img.f32, N, Z, F, obs, zone_obs, mu, stdv, value, value_sigma, act, s);
-    __bf16 *pooled = static_cast<__bf16 *>(pooled_v);
+    if (img.elem_f16)       // the same kernels compiled for float16 operands (mlp_policy_f16.hip)
+        return launch_mlp_forward_f16(img, N, Z, F, obs, zone_obs, pooled_v, mu, stdv, value, value_sigma, act, s);
+#endif
+    elem_t *pooled = static_cast<elem_t *>(pooled_v);
     // Batch layout of the zone kernel.  A wave works through its tiles one after the other (~1.1 us each), so a small
     // batch laid out like a full one leaves the chip idle for the same 100 us: below kMlpSplitMaxEnvs a workgroup's four
     // waves share one group of 32 envs (zones w, w + 4, ... each; partial sums meet in LDS), up to 32 768 envs a wave
@@ -1102,6 +1183,7 @@ hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const f
     return hipGetLastError();
 }
 
+#if !MLP_ELEM_F16
 hipError_t launch_exp_reward(const ExpBuffers &x, int N, int t, const float *reward, const double *shaped,
                              const uint8_t *done, hipStream_t s)
 {
@@ -1115,5 +1197,6 @@ hipError_t launch_exp_gae(const ExpBuffers &x, int N, const float *next_value, f
     hipLaunchKernelGGL(k_exp_gae, dim3((N + 255) / 256), dim3(256), 0, s, x, N, next_value, discount, gae_lambda);
     return hipGetLastError();
 }
+#endif   // !MLP_ELEM_F16
 
 }  // namespace zenvk

@@ -30,7 +30,12 @@ struct MlpImages {
     const void *wv2;    // [1][KS]      critic.2 or critic_mu (row 0) and critic_sigma (row 1), accumulator order
     const struct MlpF32 *f32;   // non-null: the float32 path (mlp_f32.hip) runs instead of the bf16 MFMA kernels
     int distributional;         // critic_mu / critic_sigma heads (flat_model.py:35-41) instead of critic.2
+    int elem_f16;               // the images hold float16, not bf16: the float16 build of the same kernels runs (ZENV_MLP_F16)
+    int *range_flag;            // float16 only: pinned host word set when an observation or an activation left the range
 };
+// ZENV_MLP_F16: zenv_mlp_load bounds the zone layers' activations for observations of at most this magnitude (the robot
+// 190 m from the arena's centre); k_mlp_zone1 reports an env beyond it
+constexpr float kMlpF16ObsBound = 64.0f;
 
 // The float32 path's weights: every matrix TRANSPOSED ([in][kMlpHP], so that consecutive threads = consecutive output
 // features read consecutive floats) and zero-padded to kMlpHP columns; biases [kMlpHP].  Device pointers.
@@ -65,7 +70,7 @@ hipError_t launch_mlp_forward_f32(const MlpF32 &w, int N, int Z, int F, const fl
 
 // Packs the float32 state_dict tensors into one host buffer of fragments; offsets (in bytes) of the
 // images are returned in `offs` (the last two only when the critic tensors are given).  h = hidden width (<= 191), F = zone features (6 or 7).
-int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, size_t offs[8]);
+int pack_images(const zenv_mlp_weights &w, int F, std::vector<uint16_t> &out, size_t offs[8], bool f16 = false);
 
 // What the head kernel does with (mu, std) besides storing them: nothing (mode < 0), actions = mu (0), or
 // actions = mu + std * eps with eps ~ N(0,1) from Philox4x32-10 keyed by (seed, global env, step) (1) -- the
@@ -95,6 +100,11 @@ inline MlpAction no_mlp_action() { return MlpAction{ -1, 0u, 0ull, 0ull, nullptr
 hipError_t launch_mlp_forward(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
                               void *pooled, float *mu, float *stdv, float *value, float *value_sigma,
                               const MlpAction &act, hipStream_t s);
+
+// the float16 build of the same two kernels (mlp_policy_f16.hip); called by launch_mlp_forward when img.elem_f16
+hipError_t launch_mlp_forward_f16(const MlpImages &img, int N, int Z, int F, const float *obs, const float *zone_obs,
+                                  void *pooled, float *mu, float *stdv, float *value, float *value_sigma,
+                                  const MlpAction &act, hipStream_t s);
 
 // Experience buffers of one collect_experiences() call (base.py:131-216), all time-major [T][N][...] (the
 // observations are written in place by the step kernel)

@@ -1022,8 +1022,9 @@ static int mlp_range_check(zenv *h)
 {
     if (!h->mlp_range_flag || !*(volatile int *)h->mlp_range_flag) return ZENV_OK;
     *(volatile int *)h->mlp_range_flag = 0;
-    return fail(ZENV_E_RANGE, "an input or activation of the network reached 65 520, beyond float16: the actions since the last "
-                              "synchronising call are invalid -- load these weights with ZENV_MLP_BF16X3 or ZENV_MLP_F32");
+    return fail(ZENV_E_RANGE, "an input or activation of the network reached 65 520, beyond float16 (ZENV_MLP_F16: or an "
+                              "observation beyond 64): the actions since the last synchronising call are invalid -- load these "
+                              "weights with ZENV_MLP_BF16, ZENV_MLP_BF16X3 or ZENV_MLP_F32");
 }
 
 // ============================================================================ actor network
@@ -1039,8 +1040,43 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     const int n_sigma = (w->critic_sigma_w != nullptr) + (w->critic_sigma_b != nullptr);
     if (n_sigma == 1 || (n_sigma == 2 && n_critic == 0))
         return fail(ZENV_E_ARG, "the distributional critic needs critic.0, critic_mu (as critic_w2 / _b2) and critic_sigma");
-    if (w->precision < ZENV_MLP_BF16 || w->precision > ZENV_MLP_F16X3)
+    if (w->precision < ZENV_MLP_BF16 || w->precision > ZENV_MLP_F16)
         return fail(ZENV_E_ARG, "unknown zenv_mlp_weights.precision %d", w->precision);
+    if (w->precision == ZENV_MLP_F16 && w->h_dim >= 1 && w->h_dim < kMlpHP) {
+        // single float16 operands.  (i) every weight must be a finite float16; (ii) the zone layers' activations are bounded
+        // here, over the rows' absolute sums, for observations up to kMlpF16ObsBound and zone rows up to 2 (positions / 3,
+        // flags, timers: bounded by construction) -- the zone kernel has no cycles to spare for watching them; the head
+        // kernel watches its own.
+        const int hd = w->h_dim, F = h->p.F;
+        const struct { const float *t; size_t n; const char *name; } all[] = {
+            { w->zone_w1, (size_t)hd * (8 + F), "zone_net_.0.weight" }, { w->zone_b1, (size_t)hd, "zone_net_.0.bias" },
+            { w->zone_w2, (size_t)hd * hd, "zone_net_.2.weight" },      { w->zone_b2, (size_t)hd, "zone_net_.2.bias" },
+            { w->enc_w, (size_t)hd * hd, "actor.enc_.0.0.weight" },     { w->enc_b, (size_t)hd, "actor.enc_.0.0.bias" },
+            { w->mu_w, (size_t)2 * hd, "actor.mu_.weight" },            { w->mu_b, 2, "actor.mu_.bias" },
+            { w->std_w, (size_t)2 * hd, "actor.std_.weight" },          { w->std_b, 2, "actor.std_.bias" },
+            { w->critic_w1, (size_t)hd * hd, "critic.0.weight" },       { w->critic_b1, (size_t)hd, "critic.0.bias" },
+            { w->critic_w2, (size_t)hd, "critic.2.weight" },            { w->critic_b2, 1, "critic.2.bias" },
+            { w->critic_sigma_w, (size_t)hd, "critic_sigma.weight" },   { w->critic_sigma_b, 1, "critic_sigma.bias" } };
+        for (const auto &a : all)
+            for (size_t i = 0; a.t && i < a.n; ++i)
+                if (!(std::fabs(a.t[i]) < 65504.0f))
+                    return fail(ZENV_E_RANGE, "%s[%zu] = %g is not a finite float16: use ZENV_MLP_BF16 or a split mode",
+                                a.name, i, (double)a.t[i]);
+        double a1 = 0.0, s2 = 0.0, b2 = 0.0;
+        for (int r = 0; r < hd; ++r) {
+            double v = std::fabs((double)w->zone_b1[r]), s = 0.0;
+            for (int k = 0; k < 8 + F; ++k)
+                v += std::fabs((double)w->zone_w1[(size_t)r * (8 + F) + k]) * (k < 8 ? (double)kMlpF16ObsBound : 2.0);
+            a1 = std::max(a1, v);
+            for (int k = 0; k < hd; ++k) s += std::fabs((double)w->zone_w2[(size_t)r * hd + k]);
+            s2 = std::max(s2, s);
+            b2 = std::max(b2, std::fabs((double)w->zone_b2[r]));
+        }
+        if (!(a1 < 65504.0) || !(s2 * a1 + b2 < 65504.0))
+            return fail(ZENV_E_RANGE, "zone_net_'s activations are bounded by %.3g / %.3g for observations up to %g: beyond "
+                                      "float16 -- use ZENV_MLP_BF16 or a split mode for these weights",
+                        a1, s2 * a1 + b2, (double)kMlpF16ObsBound);
+    }
     if (w->precision == ZENV_MLP_F16X3 && w->h_dim >= 1 && w->h_dim < kMlpHP) {
         // float16 halves: a weight of 65 520 or more would be inf on the device
         const int hd = w->h_dim, F = h->p.F;
@@ -1063,11 +1099,17 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     }
     std::vector<uint16_t> img;
     size_t offs[8];
-    if (pack_images(*w, h->p.F, img, offs) != 0)
+    if (pack_images(*w, h->p.F, img, offs, w->precision == ZENV_MLP_F16) != 0)
         return fail(ZENV_E_ARG, "h_dim %d outside [1, %d]", w->h_dim, kMlpHP - 1);
+    if (w->precision == ZENV_MLP_F16)        // zone_net_.4 folded into combine_net_: a product that can leave the range
+        for (size_t i = 0; i < img.size(); ++i)
+            if ((img[i] & 0x7C00u) == 0x7C00u)
+                return fail(ZENV_E_RANGE, "combine_net_ folded over zone_net_.4 leaves float16's range: use ZENV_MLP_BF16 or "
+                                          "a split mode for these weights");
     std::vector<float> f32;         // the float32-grade modes' images (packed before the handle is touched: it can refuse)
     size_t fo[30];
-    if (w->precision != ZENV_MLP_BF16) {
+    const bool f32_grade = w->precision != ZENV_MLP_BF16 && w->precision != ZENV_MLP_F16;
+    if (f32_grade) {
         pack_f32(*w, h->p.F, f32, fo);
         if (w->precision == ZENV_MLP_F16X3) {
             // the float16 images start at fo[24] (zone_net_.2): combine_net_ arrives with zone_net_.4 folded in, a product of
@@ -1101,15 +1143,19 @@ extern "C" int zenv_mlp_load(zenv_t *h, const zenv_mlp_weights *w)
     const char *base = static_cast<const char *>(h->mlp_mem);
     h->mlp = MlpImages{ base + offs[0], base + offs[1], base + offs[2], base + offs[3], base + offs[4], base + offs[5],
                         n_critic ? base + offs[6] : nullptr, n_critic ? base + offs[7] : nullptr, nullptr,
-                        n_sigma == 2 ? 1 : 0 };
-    if (w->precision != ZENV_MLP_BF16) {
+                        n_sigma == 2 ? 1 : 0, 0, nullptr };
+    if (w->precision != ZENV_MLP_BF16 && !h->mlp_range_flag) {
+        HIP_TRY(hipHostMalloc((void **)&h->mlp_range_flag, sizeof(int), hipHostMallocDefault));
+        *h->mlp_range_flag = 0;
+    }
+    if (w->precision == ZENV_MLP_F16) {
+        h->mlp.elem_f16 = 1;
+        h->mlp.range_flag = h->mlp_range_flag;
+    }
+    if (f32_grade) {
         // (diagnostic: ZENV_MLP_F32_VALU=1 runs the network on the vector ALU, k_mlp_f32, instead of the f32 MFMA)
         // ZENV_MLP_F32_MFMA=1 the MFMA kernel whatever the batch; default: by batch size, see launch_mlp_forward_f32)
         const int on_mfma = std::getenv("ZENV_MLP_F32_VALU") ? 0 : std::getenv("ZENV_MLP_F32_MFMA") ? 2 : 1;
-        if (!h->mlp_range_flag) {
-            HIP_TRY(hipHostMalloc((void **)&h->mlp_range_flag, sizeof(int), hipHostMallocDefault));
-            *h->mlp_range_flag = 0;
-        }
         HIP_TRY(hipMalloc(&h->mlp_f32_mem, f32.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->mlp_f32_mem, f32.data(), f32.size() * sizeof(float), hipMemcpyHostToDevice));
         const float *fb = static_cast<const float *>(h->mlp_f32_mem);

@@ -38,7 +38,8 @@ def evaluate(env_id, policy, n_maps=100, n_runs_per_map=5, env_seed0=EVAL_SEED0,
     then runs on the device (``csrc/mlp_policy.hip``), ``dist.sample()`` per step as ``Agent.get_actions`` does
     (agent.py:41-44), or the mean with ``argmax=True``; ``precision`` "f32" (default: the reference's own arithmetic,
     actions within 1e-5 of its torch float32 modules), "f16x3" (within 3e-6 as well, a third of the time on batches of
-    2 048 envs and more -- smaller ones run the float32 vector kernel either way) or "bf16" (the MFMA kernels, 8x faster).
+    2 048 envs and more -- smaller ones run the float32 vector kernel either way) "bf16" (the MFMA kernels, 8x faster) or "f16" (the same kernels on
+    float16 operands: within 1e-3, float16's range guarded).
 
     Returns ``{"return": [[...]], "length": [[...]], "goal_met": [[...]]}``."""
     cfg = config_for_id(env_id) if isinstance(env_id, str) else env_id

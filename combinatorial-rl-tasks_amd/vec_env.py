@@ -334,7 +334,9 @@ class ZoneVecEnv:
         (8x slower; within 1e-5 of torch float32); "f16x3" / "bf16x3": the 16-bit matrix instruction on hi / lo split
         operands, three products per k-step -- "f16x3" within 3e-6 of torch float32 at 0.30 of "f32"'s time, "bf16x3"
         within 2e-5 at 0.35.  "f16x3" is bound to float16's range: a weight >= 32 768 is refused here and an input /
-        activation >= 65 520 raises ZenvError(E_RANGE) at the next call that waits for the device."""
+        activation >= 65 520 raises ZenvError(E_RANGE) at the next call that waits for the device.  "f16": the bf16
+        kernels with float16 operands -- 5 % slower, an eighth of the rounding error (within 1e-3 of torch float32);
+        float16's range is guaranteed by a bound on the zone layers at load plus run-time checks (E_RANGE otherwise)."""
         F = self.zone_feat
         h = int(np.asarray(tensors["zone_b1"]).shape[0])
         want = {"zone_w1": (h, 8 + F), "zone_b1": (h,), "zone_w2": (h, h), "zone_b2": (h,), "zone_w3": (h, h),
@@ -344,7 +346,7 @@ class ZoneVecEnv:
                 "critic_sigma_w": (1, h), "critic_sigma_b": (1,)}
         keep = {}
         w = nat.MlpWeights(h_dim=h, precision={"bf16": nat.MLP_BF16, "f32": nat.MLP_F32, "bf16x3": nat.MLP_BF16X3,
-                                                   "f16x3": nat.MLP_F16X3}[precision])
+                                                   "f16x3": nat.MLP_F16X3, "f16": nat.MLP_F16}[precision])
         names = nat.MLP_TENSORS + (nat.MLP_CRITIC_TENSORS if "critic_w1" in tensors else ()) + (
             nat.MLP_SIGMA_TENSORS if "critic_sigma_w" in tensors else ())
         self._mlp_has_critic = "critic_w1" in tensors

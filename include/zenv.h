@@ -272,8 +272,8 @@ int zenv_solver_goals(zenv_t *h, int32_t *goals);
 
 /* ---- solver-ordered variant: TSPOrderEnv, main/envs/TSP_order_env.py:13-113 (PointTSP-v2) ----
  * TSP handles only; call before building the bank.  The route of an episode is the bank's aux column (rank of
- * every zone in the visiting order): zenv_bank_build* fill it with a nearest-neighbour + 2-opt tour from the
- * robot (OR-tools, which the reference calls at :49-50, is not available), zenv_bank_set takes the caller's.
+ * every zone in the visiting order): zenv_bank_build* fill it with zenv_route_ranks()'s tour (the solver's problem,
+ * solved without OR-tools, which the reference calls at :49-50 and which is not available), zenv_bank_set takes the caller's.
  * Every zenv_step() then also yields info['shaped_reward'] (ZENV_F_SHAPED_REWARD, :63-72) and the order feature
  * of every zone (ZENV_F_ORDER_VAL, :37-47) -- the reference's (Z,7) row is [zone_obs row (6), order value].
  * Exclusive with zenv_goal_enable; zenv_rollout() is refused on such a handle. */
@@ -297,12 +297,19 @@ enum {
                          * operands (16 significant bits, float32's range), float32 accumulation, the per-env head on the
                          * float32 matrix instruction: within 2e-5 of torch float32 (measured: up to 1.1e-5) at a third of
                          * ZENV_MLP_F32's time */
-    ZENV_MLP_F16X3 = 3  /* the same with float16 halves (22 significant bits: within 3e-6 of torch float32, float32's own
+    ZENV_MLP_F16X3 = 3, /* the same with float16 halves (22 significant bits: within 3e-6 of torch float32, float32's own
                          * rounding noise) on every layer -- the fastest of the float32-grade modes (0.30 of ZENV_MLP_F32).  float16's range applies to every
                          * operand: weights of 32 768 or more are refused by zenv_mlp_load (ZENV_E_RANGE); an input or
                          * activation that reaches 65 520 is caught on the device and reported as ZENV_E_RANGE by the next
                          * call that waits for it (zenv_get*, zenv_sync, zenv_rollout, zenv_step_results).
                          * Batches too small for the matrix kernel (< 2 048 envs) run the float32 vector kernel in both. */
+    ZENV_MLP_F16 = 4    /* ZENV_MLP_BF16's two kernels with float16 operands (one product per k-step, float32 accumulation): 5 %
+                         * slower than bf16 (the wider multipliers draw more power), 11 significant bits instead of 8 -- mu / std within 1e-3 of the reference's float32
+                         * (bf16: within 4e-2 by contract, ~4e-3 measured).  float16's range is guaranteed, not assumed:
+                         * zenv_mlp_load refuses weights of 65 504 or more and weights whose zone-layer activations could
+                         * leave the range for observations up to 64 (a bound over the rows' absolute sums: ZENV_E_RANGE, use
+                         * ZENV_MLP_BF16 or a split mode); the head kernel watches its own activations, and the zone kernel
+                         * the observations' magnitude, at run time (ZENV_E_RANGE from the next call that waits). */
 };
 typedef struct zenv_mlp_weights {
     int32_t h_dim;

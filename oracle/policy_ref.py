@@ -68,15 +68,18 @@ def forward_fp32(t, obs, zone_obs):
     return mu.numpy(), std.numpy()
 
 
-def _bf(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+def _round16(x, dtype=torch.bfloat16):
+    return x.to(dtype).to(torch.float32)
 
 
-def forward_bf16_emulated(t, obs, zone_obs):
+def forward_bf16_emulated(t, obs, zone_obs, dtype=torch.bfloat16):
     """What the MFMA kernels compute, restated in torch: weights, biases and layer inputs rounded to
-    bf16, products accumulated in float32 (float64 here; the difference is accumulation order only),
+    bf16 (dtype=torch.float16: the ZENV_MLP_F16 build of the same kernels), products accumulated in float32 (float64 here; the difference is accumulation order only),
     the zone mean taken after the second ReLU (zone_net_.4 is linear, so it commutes with the mean -- and folds into
     combine_net_, which follows it without an activation)."""
+    def _bf(x):
+        return _round16(x, dtype)
+
     raw = {k: torch.as_tensor(v, dtype=torch.float32).double() for k, v in t.items()}
     t = {k: _bf(torch.as_tensor(v, dtype=torch.float32)).double() for k, v in t.items()}
     # zone_net_.4 folded into combine_net_ on the host (float64 products, ONE bf16 rounding): pack_images, mlp_policy.hip

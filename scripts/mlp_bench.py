@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import combinatorial_rl_tasks_amd as Z
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-precision = sys.argv[2] if len(sys.argv) > 2 else "bf16"      # "bf16" | "f32" | "f16x3"
+precision = sys.argv[2] if len(sys.argv) > 2 else "bf16"      # "bf16" | "f16" | "f32" | "f16x3" | "bf16x3"
 short = len(sys.argv) > 3                                      # a few steps only (under the profiler's counters)
 cfg = Z.default_config(0, 25, zones_keepout=0.40)
 env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n, n_threads=16); env.reset()
@@ -23,7 +23,7 @@ for (kw, kb), shape in ((("zone_w1", "zone_b1"), (h_, 8 + F_)), (("zone_w2", "zo
                         (("enc_w", "enc_b"), (h_, h_)), (("mu_w", "mu_b"), (2, h_)), (("std_w", "std_b"), (2, h_))):
     t[kw], t[kb] = lin(*shape)
 env.load_mlp(t, precision=precision)
-T = 6 if short else 300 if precision == "bf16" else 40
+T = 6 if short else 300 if precision in ("bf16", "f16") else 40
 env.rollout(T, Z.POLICY_MLP_MEAN)
 tot, _ = env.rollout(T, Z.POLICY_MLP_MEAN)
 h, F, Zn = 185, 6, 25
