@@ -1,7 +1,7 @@
 // Diagnostic: where one wave of K4 (k_mlp_zone) spends a row tile.  Builds the kernel file itself with
 // -DMLP_STAMP=<wave>, runs it on random weights / rows and prints the median cycles between the stamps.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DMLP_STAMP=0 \
-//         -I include scripts/probes/k4_stamps.hip combinatorial-rl-tasks_amd/csrc/mlp_f32.hip -o gpurun_out/k4_stamps && gpurun_out/k4_stamps
+//         -I include scripts/probes/k4_stamps.hip combinatorial-rl-tasks_amd/csrc/mlp_f32.hip combinatorial-rl-tasks_amd/csrc/mlp_policy_f16.hip -o gpurun_out/k4_stamps && gpurun_out/k4_stamps
 #include "../../combinatorial-rl-tasks_amd/csrc/mlp_policy.hip"
 
 #include <algorithm>

@@ -25,7 +25,7 @@ git -C "$root" show HEAD:oracle/oracle.py > oracle/oracle.py && rm -rf oracle/bu
 csrc=combinatorial-rl-tasks_amd/csrc
 hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -Wno-pass-failed \
     -mllvm -amdgpu-mfma-vgpr-form -fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan \
-    -o combinatorial-rl-tasks_amd/lib/libzenv_hip.so $csrc/kernels.hip $csrc/mlp_policy.hip $csrc/mlp_f32.hip \
+    -o combinatorial-rl-tasks_amd/lib/libzenv_hip.so $csrc/kernels.hip $csrc/mlp_policy.hip $csrc/mlp_policy_f16.hip $csrc/mlp_f32.hip \
     $csrc/zenv_api.cpp $csrc/host_sampler.cpp 2> /dev/null
 rt=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 LD_PRELOAD="$rt" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
