@@ -1,5 +1,6 @@
-"""Random widths / zone counts / batch sizes / weight scales through the split-operand network kernel (k_mlp_zone_s3,
-both halves' kinds) against the torch float32 restatement -- a hunt for packing mistakes at odd sizes (h around the
+"""Random widths / zone counts / batch sizes / weight scales through every network kernel (the split-operand k_mlp_zone_s3,
+both halves' kinds, against the torch float32 restatement; the single-product bf16 and float16 builds of k_mlp_zone1 /
+k_mlp_head against the restatement with their rounding points) -- a hunt for packing mistakes at odd sizes (h around the
 32-feature tile edges, Z = 1, ragged batches), not a timing.  Run on the GPU box: python scripts/mlp_split_fuzz.py [cases]"""
 import os
 import sys
@@ -51,6 +52,32 @@ def run(cases=40):
             ok = finite and rel <= max(tol, mult * e32)
             bad += not ok
             line += "  %s %.1e%s" % (prec, rel, "" if ok else " FAIL")
+        # the single-product builds (k_mlp_zone1 / k_mlp_head on bf16 and on float16 operands) against the restatement
+        # with their rounding points: a packing mistake at an odd size shows as an error of order one
+        import torch
+        # (tolerance: the kernel and the restatement round at the same points, but a sum that lands within 1e-7 of a
+        # rounding boundary can fall on either side -- one 16-bit ulp in one hidden unit, amplified by the network like the
+        # float32 kernel's own noise e32 is: a few hundred times e32 for float16's ulp, eight times that for bf16's)
+        for prec, dtype, tol, mult in (("bf16", torch.bfloat16, 4e-3, 4000.0), ("f16", torch.float16, 5e-4, 500.0)):
+            try:
+                env.load_mlp(t, precision=prec)
+            except Z.ZenvError as ex:              # float16: weights whose bound leaves the range are refused at load
+                assert prec == "f16" and ex.code == Z.E_RANGE, ex
+                line += "  %s refused" % prec
+                continue
+            try:
+                out = env.mlp_forward(with_value=True)
+            except Z.ZenvError as ex:              # ... or an activation of the head at run time
+                assert prec == "f16" and ex.code == Z.E_RANGE, ex
+                line += "  %s range" % prec
+                continue
+            emu = P.forward_bf16_emulated(t, obs, zo, dtype=dtype)
+            err = [float(np.abs(a - b).max()) for a, b in zip(out, emu)]
+            rel = max(err[0], err[1], err[2] / mag, *(err[3:]))
+            ok = all(np.isfinite(a).all() for a in out) and rel <= max(tol, mult * e32)
+            bad += not ok
+            line += "  %s %.1e%s" % (prec, rel, "" if ok else " FAIL %s (|ref| up to %s)" % (
+                ["%.1e" % e for e in err], ["%.1e" % float(np.abs(b).max()) for b in emu]))
         print(line, flush=True)
         env.close()
     print("worst error as a multiple of the float32 kernel's:", worst, "| failures:", bad)
