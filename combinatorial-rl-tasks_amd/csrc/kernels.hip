@@ -1027,13 +1027,8 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
 #pragma unroll
                 for (int w = 0; w < ZW; ++w) cdw[w] = cd_decrement(cdw[w]);   // colour_match_env.py:98-100, all zones
             }
-#if defined(ZENV_EXP) && (ZENV_EXP & 16)   // diagnostic (wrong results): half of the zone pass, an upper bound on what splitting it over both waves could gain
-#define ZENV_ZPASS(zt) (((zt) + 1) / 2)
-#else
-#define ZENV_ZPASS(zt) (zt)
-#endif
 #pragma unroll
-            for (int z = 0; z < (ZT > 0 ? ZENV_ZPASS(ZT) : Z); ++z) {
+            for (int z = 0; z < (ZT > 0 ? ZT : Z); ++z) {
                 const size_t zi = (size_t)z * N + env;
                 int aux = 0;
                 float4 pr;
