@@ -69,3 +69,44 @@ def test_solver_ordered_agent_reaches_the_readmes_return_on_the_evaluation_maps(
     assert finished == len(seeds) and 24.4 <= ret <= 25.8 and 920 <= steps <= 1060, (ret, steps)
     heavy = m.mean_return(O, zenv_mod, 5.0, seeds, 0.2)[0]                  # its best setting
     assert heavy < 18.0, heavy
+
+
+def test_colour_cycle_and_cooldown_of_the_colourmatch_animation():
+    """gifs/colourmatch.gif (rendered by the reference's stack): every colour change of a zone follows the cycle the oracle
+    restates from colour_match_env.py:106-120 (Blue -> Green -> Red -> Blue), and where the robot re-triggers the zone it is
+    parked on, the two changes are a cooldown (max_cd = 150 steps) apart -- five frames of about 28 steps."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "gif_colourmatch_changes.json")) as fh:
+        d = json.load(fh)
+    seen = {(c["from"], c["to"]) for c in d["changes"]}
+    assert len(d["changes"]) >= 12 and len(seen) == 3
+    # the oracle: the robot parked on zone 0, zero action; colours read from the observation rows (RGB of ZoneEnvBase._rgb)
+    cfg = O.default_config(O.TASK_COLOUR, 6, num_steps=2000, robot_keepout=0.02, zones_keepout=0.02)
+    cfg.n_zones_locations, cfg.n_robot_locations = 1, 1
+    cfg.robot_location[0], cfg.robot_location[1] = 1.0, 1.0
+    cfg.zones_locations[0][0], cfg.zones_locations[0][1] = 1.1, 1.0          # 0.1 from the robot: inside the 0.2 radius
+    env = O.OracleEnv(cfg)
+    env.reset(7)
+
+    def colour0():
+        row = env.obs()[1][0]
+        return "RGB"[int(np.argmax(row[2:5]))]
+    cycle, steps, last = set(), [], colour0()
+    for t in range(1, 460):
+        env.step((0.0, 0.0))
+        now = colour0()
+        if now != last:
+            cycle.add((last, now))
+            steps.append(t)
+            last = now
+    assert cycle == {("B", "G"), ("G", "R"), ("R", "B")} and len(steps) == 4
+    assert set(np.diff(steps)) == {150}                 # max_cd = 150, decremented before the test: eligible again 150 steps on
+    assert seen == cycle
+    # the animation's parked robot: zone (0.87, 2.73) changes at frames 6 and 11, the robot within 0.3 of it in between
+    first = [c for c in d["changes"] if abs(c["zone_xy"][0] - 0.86) < 0.05 and abs(c["zone_xy"][1] - 2.73) < 0.05]
+    assert [c["frame"] for c in first] == [6, 11]
+    rob = np.array(d["robot_xy"][6:11])
+    assert np.abs(rob - rob[0]).max() < 0.3
+    disp = np.linalg.norm(np.diff(np.array(d["robot_xy"][:6]), axis=0), axis=1) * 0.854      # metres per frame on the way in
+    steps_per_frame = float(np.max(disp)) / 1.5 / 0.02
+    assert 120 <= 5 * steps_per_frame <= 190, steps_per_frame     # five frames = one cooldown, within a frame
