@@ -552,7 +552,8 @@ def test_split_modes_at_odd_sizes(zenv_mod):
     """scripts/mlp_split_fuzz.py: random widths (around every 32-feature tile edge, down to 1), zone counts 1-30, batch
     sizes around the 32-env group edges, weight scales 0.1-3, all three tasks, both critics -- the split-operand kernel
     against the torch float32 restatement, held to its tolerance or to a multiple of the float32 kernel's own error
-    where the weights make the activations large."""
+    where the weights make the activations large; the single-product bf16 / float16 builds against the restatement with
+    their rounding points."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location(
