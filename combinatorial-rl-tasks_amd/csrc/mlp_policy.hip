@@ -441,16 +441,17 @@ __device__ __forceinline__ ZoneRow load_zone_row(const float *__restrict__ rows,
 }
 // layer 1's B operand: lane half 0 the env's obs (k = 0..7, constant over the group's tiles), half 1 the
 // zone row (k = 8..14) and the bias slot (k = 15)
+// (branch-free: `keep` is all ones in the lanes that carry a zone row -- half 1 of a valid env -- and `obs_sel` the obs
+// fragment in half 0, zero elsewhere: one v_and_or_b32 per dword instead of two exec-masked blocks at every tile's head)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t o) { return (a & m) | o; }
 template <int F>
-__device__ __forceinline__ bf16x8 zone_frag(const ZoneRow &x, const uint4 obs_frag, bool valid, int h)
+__device__ __forceinline__ bf16x8 zone_frag(const ZoneRow &x, const uint4 obs_sel, uint32_t keep)
 {
     uint4 u;
-    u.x = pk_bf16(x.a.x, x.a.y);
-    u.y = pk_bf16(x.a.z, x.a.w);
-    u.z = pk_bf16(x.b.x, x.b.y);
-    u.w = pk_bf16(F == 7 ? x.c.y : 0.f, 1.0f);
-    if (!valid) u = make_uint4(0u, 0u, 0u, 0u);
-    if (h == 0) u = obs_frag;
+    u.x = and_or(pk_bf16(x.a.x, x.a.y), keep, obs_sel.x);
+    u.y = and_or(pk_bf16(x.a.z, x.a.w), keep, obs_sel.y);
+    u.z = and_or(pk_bf16(x.b.x, x.b.y), keep, obs_sel.z);
+    u.w = and_or(pk_bf16(F == 7 ? x.c.y : 0.f, 1.0f), keep, obs_sel.w);
     return as_frag(u);
 }
 
@@ -702,6 +703,8 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
             if (valid && !(om <= kMlpF16ObsBound) && img.range_flag) *img.range_flag = 1;
 #endif
         }
+        const uint32_t keep = (valid && h != 0) ? 0xFFFFFFFFu : 0u;
+        const uint4 obs_sel = h == 0 ? obs_frag : make_uint4(0u, 0u, 0u, 0u);
         f32x16 pool[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -721,7 +724,7 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
         bf16x8 x0n;
         f32x16 a1;
         {
-            const bf16x8 x0 = zone_frag<F>(nxt, obs_frag, valid, h);
+            const bf16x8 x0 = zone_frag<F>(nxt, obs_sel, keep);
             nxt = load_zone_row<F>(rows, min(zone_of(1), Z - 1));
 #pragma unroll
             for (int m = 0; m < NT; ++m) {
@@ -732,13 +735,13 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
                 xa[2 * m + 1] = in_agpr(xa[2 * m + 1]);
 #endif
             }
-            x0n = zone_frag<F>(nxt, obs_frag, valid, h);                           // tile 1
+            x0n = zone_frag<F>(nxt, obs_sel, keep);                           // tile 1
             nxt = load_zone_row<F>(rows, min(zone_of(2), Z - 1));
             a1 = mfma(w1f[0], x0n, zero16());
         }
         for (int t = 0; t < n_tiles; t += 2) {
             {
-                const bf16x8 x0nn = zone_frag<F>(nxt, obs_frag, valid, h);         // tile t + 2
+                const bf16x8 x0nn = zone_frag<F>(nxt, obs_sel, keep);         // tile t + 2
                 __builtin_amdgcn_sched_barrier(0);
 #if !defined(MLP_EXP) || !(MLP_EXP & 64)   // diagnostic (bit 6): no zone-row loads inside the tile loop
                 nxt = load_zone_row<F>(rows, zone_of(t + 3));
@@ -747,7 +750,7 @@ void k_mlp_zone1(MlpImages img, int N, int Z_rt, const float *__restrict__ obs, 
                 x0n = x0nn;
             }
             if (t + 1 < n_tiles) {
-                const bf16x8 x0nn = zone_frag<F>(nxt, obs_frag, valid, h);         // tile t + 3
+                const bf16x8 x0nn = zone_frag<F>(nxt, obs_sel, keep);         // tile t + 3
                 __builtin_amdgcn_sched_barrier(0);
 #if !defined(MLP_EXP) || !(MLP_EXP & 64)
                 nxt = load_zone_row<F>(rows, zone_of(t + 4));
