@@ -1,4 +1,4 @@
-"""What the reference's own PointTSP animation says about the robot's time constant.
+"""TEST INFRASTRUCTURE (not collected by pytest; uses the oracle, like everything under tests/).  What the reference's own PointTSP animation says about the robot's time constant.
 
 Input: tests/golden/gif_pointtsp_track.json (robot track + zone layout of one whole episode rendered by the real
 MuJoCo stack, extracted by tests/golden/make_gif_track.py).  CPU only, oracle constants only.  Two questions:
@@ -15,7 +15,7 @@ MuJoCo stack, extracted by tests/golden/make_gif_track.py).  CPU only, oracle co
 
 The metric scale comes from constants that ARE in the tree: zone radius 0.2 (ZoneEnvBase.py:51) against the measured
 disc size, cross-checked by the placement rule (no zone beyond 3 - 0.55, no two zones closer than 1.1).
-Run:  python scripts/gif_dynamics_evidence.py
+Run:  python tests/gif_dynamics_evidence.py
 """
 import json
 import math

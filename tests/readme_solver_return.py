@@ -1,8 +1,8 @@
-"""README.md:59-69 of the reference publishes one number that needs no trained network to approach: "Solver 25.30" --
+"""TEST INFRASTRUCTURE (not collected by pytest; uses the oracle, like everything under tests/).  README.md:59-69 of the reference publishes one number that needs no trained network to approach: "Solver 25.30" --
 PointTSP (15 zones), mean undiscounted return over the evaluation maps (seeds 1000000-1000099) of an agent that visits
 the zones in the TSP solver's order.  The maps are pinned (numpy goldens), so the oracle can play the same 100 maps:
 zones in the built-in route's order (the solver's problem restated, csrc/host_sampler.cpp route_ranks), a hand-written
-pursuit controller as the low level.  CPU only; run by hand:  python scripts/readme_solver_return.py
+pursuit controller as the low level.  CPU only; run by hand:  python tests/readme_solver_return.py
 The return of an episode is 15 + (2000 - T) / 100 for T steps, so the table's figure is a statement about T, i.e. about
 the robot's speed and time constant: DESIGN.md section 0.2."""
 import math

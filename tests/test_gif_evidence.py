@@ -1,6 +1,6 @@
 """The reference's own PointTSP animation (gifs/pointtsp.gif, a rendering by the real MuJoCo stack) against the oracle's
 model constants: DESIGN.md section 0.2.  The track was extracted once by tests/golden/make_gif_track.py (data only); the
-fit is scripts/gif_dynamics_evidence.py.  This is evidence for ONE constant (the geom density of point.xml, i.e. the
+fit is tests/gif_dynamics_evidence.py.  This is evidence for ONE constant (the geom density of point.xml, i.e. the
 time constant m / b), not a parity pin: the oracle stays "parity unpinned" for the dynamics half."""
 import importlib.util
 import os
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _mod():
     spec = importlib.util.spec_from_file_location("gif_dynamics_evidence",
-                                                  os.path.join(ROOT, "scripts", "gif_dynamics_evidence.py"))
+                                                  os.path.join(ROOT, "tests", "gif_dynamics_evidence.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m
@@ -59,9 +59,9 @@ def test_solver_ordered_agent_reaches_the_readmes_return_on_the_evaluation_maps(
     """README.md:59-69: "Solver 25.30" on PointTSP = 15 zones in about 970 steps on the maps 1000000-1000099, which ARE
     pinned here (numpy goldens).  The oracle's robot, zones in the built-in route's order under a hand-written pursuit
     controller, lands within half a point of it (24.9 over all 100 maps); the density-5 robot cannot finish half of the
-    maps inside the 2 000-step horizon (scripts/readme_solver_return.py: 15.5 at its best setting)."""
+    maps inside the 2 000-step horizon (tests/readme_solver_return.py: 15.5 at its best setting)."""
     spec = importlib.util.spec_from_file_location("readme_solver_return",
-                                                  os.path.join(ROOT, "scripts", "readme_solver_return.py"))
+                                                  os.path.join(ROOT, "tests", "readme_solver_return.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     seeds = range(1000000, 1000100, 10)
