@@ -228,7 +228,7 @@ def test_mlp_policy_actions_and_rollout(zenv_mod):
 
 @pytest.mark.parametrize("env_id,goals,precision", [("PointTSP-v1", False, "bf16"), ("PointTTSP-v1", False, "bf16"),
                                                     ("PointTSP-v0", True, "bf16"), ("PointTSP-v1", False, "f16x3"),
-                                                    ("ColourMatch-v0", False, "f32")])
+                                                    ("ColourMatch-v0", False, "f32"), ("PointTTSP-v1", False, "f16")])
 def test_collect_experiences(zenv_mod, oracle_mod, env_id, goals, precision, monkeypatch):
     """BaseAlgo.collect_experiences (base.py:131-227) on the device.  The recorded actions
     replayed through the oracle reproduce the recorded observations and rewards bit for bit (the env half);
@@ -245,7 +245,7 @@ def test_collect_experiences(zenv_mod, oracle_mod, env_id, goals, precision, mon
         env.enable_goals()
     env.reset()
     t = P.random_tensors(env.zone_feat, seed=2, critic=True)
-    if precision != "bf16":
+    if precision not in ("bf16", "f16"):
         monkeypatch.setenv("ZENV_MLP_F32_MFMA", "1")      # the matrix kernels of the float32-grade modes, also at 70 envs
     env.load_mlp(t, precision=precision)
     refs = [O.OracleEnv(oracle_config_from(O, cfg)) for _ in range(n)]
@@ -289,6 +289,10 @@ def test_collect_experiences(zenv_mod, oracle_mod, env_id, goals, precision, mon
         if precision == "bf16":
             mu, std, val = P.forward_bf16_emulated(t, *flat)
             tol_v, tol_lp = 4e-3, 0.15                     # mu / std carry the 4e-3 bf16 tolerance, divided by std
+        elif precision == "f16":                           # the float16 build of the same kernels
+            import torch
+            mu, std, val = P.forward_bf16_emulated(t, *flat, dtype=torch.float16)
+            tol_v, tol_lp = 5e-4, 0.02
         else:                                              # the float32-grade modes: the reference's own arithmetic
             mu, std, val = P.forward_fp32(t, *flat)
             tol_v, tol_lp = 1e-5, 2e-3
