@@ -32,7 +32,8 @@ struct DevParams {
     double A22, inv00, inv11;
     double inv_den;       // 1 / (A22 - mc^2 inv00): the hinge row's Schur complement when b0 == b1 (iso)
     double kvg;           // vel_kv * gear
-    int32_t iso, pad_iso;
+    int32_t iso;
+    int32_t order_fresh;  // solver-ordered variant: 1 = an episode's first observation shows its own route (opt-out, see K7)
     double hit_d2;        // largest d2 with sqrt(d2) <= zones_size
     float d2_lo, d2_hi;   // float32 prefilter shell around zones_size^2 (see kernels.hip)
     double tsr;           // time_saved_reward

@@ -2233,16 +2233,25 @@ __device__ __forceinline__ double order_goal_dist(const DevParams &p, int env, c
     const double dx = zz.x - rx, dy = zz.y - ry;
     return sqrt(dx * dx + dy * dy);
 }
-__device__ __forceinline__ void order_load_route(const DevParams &p, int env)
+// What obs_zones() makes of the route as it stands (:41-45): np.power(0.5, route.index(i)), 0 for a zone not in it
+__device__ __forceinline__ void order_emit_feature(const DevParams &p, int env)
 {
-    // reset(): generate_route(), last_dist_to_goal = dist_to_goal() (:108-113)
-    int8_t *pos = p.order_pos + (size_t)env * p.Z;
+    const int8_t *pos = p.order_pos + (size_t)env * p.Z;
     float *val = p.order_val + (size_t)env * p.Z;
+    for (int z = 0; z < p.Z; ++z) val[z] = pos[z] >= 0 ? __builtin_ldexpf(1.0f, -pos[z]) : 0.f;
+}
+// reset() (:108-113), in the reference's statement order: `init_obs = super().reset()` has ALREADY built the first
+// observation when `generate_route()` runs -- from self.route as the previous episode left it (empty after a finished
+// episode, the unvisited rest after a time-limit end; self.route = [] before the first reset, :27).  So: feature of
+// the old route first, then the new route and last_dist_to_goal = dist_to_goal().  p.order_fresh (the build's opt-out,
+// zenv_order_configure): the first observation shows the new route instead.
+__device__ __forceinline__ void order_reset_env(const DevParams &p, int env)
+{
+    int8_t *pos = p.order_pos + (size_t)env * p.Z;
+    if (!p.order_fresh) order_emit_feature(p, env);
     const int32_t *rank = p.bank_aux + (size_t)current_bank_slot(p, env) * p.Z;
-    for (int z = 0; z < p.Z; ++z) {
-        pos[z] = (int8_t)rank[z];
-        val[z] = __builtin_ldexpf(1.0f, -rank[z]);            // np.power(0.5, route.index(i))
-    }
+    for (int z = 0; z < p.Z; ++z) pos[z] = (int8_t)rank[z];
+    if (p.order_fresh) order_emit_feature(p, env);
     double rx, ry;
     env_world_pos(p, env, rx, ry);
     p.goal_last[env] = order_goal_dist(p, env, pos, rx, ry, false);
@@ -2252,7 +2261,7 @@ __global__ __launch_bounds__(256) void k_order_reset(DevParams p, const uint8_t 
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= p.N || (mask && !mask[env])) return;
-    order_load_route(p, env);
+    order_reset_env(p, env);
     p.shaped[env] = 0.0;
     p.visit_zone[env] = -1;
 }
@@ -2262,7 +2271,6 @@ __global__ __launch_bounds__(256) void k_order_step(DevParams p)
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= p.N) return;
     int8_t *pos = p.order_pos + (size_t)env * p.Z;
-    float *val = p.order_val + (size_t)env * p.Z;
     const bool done = p.done_out[env] != 0;
     const bool was_reset = done && !p.done_state[env];
     const int v = p.visit_zone[env];
@@ -2292,11 +2300,10 @@ __global__ __launch_bounds__(256) void k_order_step(DevParams p)
         p.goal_last[env] = d;
     }
     p.shaped[env] = sh;
-    if (was_reset) {
-        order_load_route(p, env);                              // the next episode's route and observation feature
-    } else {
-        for (int z = 0; z < p.Z; ++z) val[z] = pos[z] >= 0 ? __builtin_ldexpf(1.0f, -pos[z]) : 0.f;
-    }
+    // the worker's `if done: obs = env.reset()` (penv.py:8-11) goes through the same reset(): the returned observation
+    // carries the feature of the route this step left behind
+    if (was_reset) order_reset_env(p, env);
+    else order_emit_feature(p, env);
 }
 
 // =========================================================================== K1w: wave-per-env step

@@ -194,7 +194,7 @@ void derive_constants(const zenv_config &c, DevParams &p)
     p.inv00 = 1.0 / A00;
     p.inv11 = 1.0 / A11;
     p.iso = c.damping[0] == c.damping[1];
-    p.pad_iso = 0;
+    p.order_fresh = 0;
     p.inv_den = 1.0 / std::fma(-(p.mc * p.mc), p.inv00, p.A22);
     p.kvg = c.vel_kv * c.gear;
     p.hit_d2 = sqrt_threshold(c.zones_size);
@@ -267,6 +267,7 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_EXP_ADVANTAGE: return { h->exp.advantage, h->exp.obs ? N * h->exp.T * 4 : 0 };
     case ZENV_F_EXP_RETURN: return { h->exp.returnn, h->exp.obs ? N * h->exp.T * 4 : 0 };
     case ZENV_F_ORDER_VAL: return { p.order_val, p.order_val ? N * p.Z * 4 : 0 };
+    case ZENV_F_ORDER_POS: return { p.order_pos, p.order_pos ? N * p.Z : 0 };
     case ZENV_F_EXCEPTION: return { p.exception, N };
     default: return { nullptr, 0 };
     }
@@ -953,6 +954,15 @@ extern "C" int zenv_order_enable(zenv_t *h)
     HIP_TRY(hipMemsetAsync(p.order_pos, 0xFF, N * Z, h->stream));
     HIP_TRY(hipMemsetAsync(p.order_val, 0, N * Z * 4, h->stream));
     h->order_enabled = true;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_order_configure(zenv_t *h, int flags)
+{
+    if (!h) return fail(ZENV_E_ARG, "null handle");
+    if (!h->order_enabled) return fail(ZENV_E_STATE, "zenv_order_enable first");
+    if (flags & ~ZENV_ORDER_FRESH_FIRST_OBS) return fail(ZENV_E_ARG, "unknown zenv_order_configure flags 0x%x", flags);
+    h->p.order_fresh = (flags & ZENV_ORDER_FRESH_FIRST_OBS) ? 1 : 0;   // by-value kernel argument of the next launch
     return ZENV_OK;
 }
 

@@ -274,14 +274,17 @@ class TSPOrderEnv(TSPEnv):
     here); this class uses the library's own solution of the same problem (PATH_CHEAPEST_ARC + local search), or ``route_fn(robot_xyrot, zone_xy)
     -> rank[Z]`` when the caller brings a solver.
 
-    Deliberate deviation: the reference's reset() builds the first observation BEFORE generate_route() (:108-113), so
-    an episode's first obs carries the order feature of the previous episode's leftover route (all zeros after a
-    finished episode); here the first obs already shows the new episode's route."""
+    As in the reference, reset() builds the first observation BEFORE generate_route() (:108-113): an episode's first
+    obs carries the order feature of the route this object was left with (all zeros before the first episode and after
+    a finished one, the unvisited rest of the previous route after a time-limit end); from the first step on the
+    feature follows the new route, and shaped_reward uses the new route from the start.
+    ``fresh_route_in_first_obs=True`` opts out: the first obs already shows the new episode's route."""
 
-    def __init__(self, config, route_fn=None, **kw):
+    def __init__(self, config, route_fn=None, fresh_route_in_first_obs=False, **kw):
         self._route_fn = route_fn
+        self._fresh_first_obs = bool(fresh_route_in_first_obs)
         super().__init__(config, **kw)
-        self._vec.enable_order()
+        self._vec.enable_order(fresh_route_in_first_obs=self._fresh_first_obs)
 
     def build_observation_space(self):
         super().build_observation_space()
@@ -319,9 +322,8 @@ class TSPOrderEnv(TSPEnv):
     @property
     def route(self):
         """Indices of the cities still to visit, in order (TSP_order_env.py: self.route)."""
-        val = self._vec.get(nat.F_ORDER_VAL)[0]
-        idx = [i for i in range(self.num_cities) if val[i] > 0]
-        return sorted(idx, key=lambda i: -val[i])
+        pos = self._vec.get(nat.F_ORDER_POS)[0]
+        return sorted((i for i in range(self.num_cities) if pos[i] >= 0), key=lambda i: pos[i])
 
 
 class TimedTSPNextCityEnv(TSPNextCityEnv):

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _native as nat
 from .envs.wrappers import FixedSeedsWrapper, WaitWrapper, ZoneWrapper
-from .envs.zone_envs import ColourMatchNextCityEnv, TSPNextCityEnv, ZoneEnvBase
+from .envs.zone_envs import ColourMatchNextCityEnv, TSPNextCityEnv, TSPOrderEnv, TSPOrderTestEnv, ZoneEnvBase
 from .vec_env import ZoneVecEnv
 
 _RING_DEPTH = 4   # default ring of pre-sampled maps per env for envs that are not behind a FixedSeedsWrapper
@@ -51,6 +51,17 @@ class ParallelEnv:
         self.num_envs = len(envs)
         self._vec = ZoneVecEnv(cfg, self.num_envs, device=device)
         self._vec.host_io("if small")     # 16 procs: the kernel writes the results into host memory itself, no copies
+        # solver-ordered envs (TSP_order_env.py; zone-goals' TSPOrderTestEnv): routes ride in the bank, so before it
+        self._order = all(isinstance(b, TSPOrderEnv) for b in bases)
+        if not self._order and any(isinstance(b, TSPOrderEnv) for b in bases):
+            raise ValueError("mixing solver-ordered and plain envs is not supported")
+        if self._order:
+            if any(b._route_fn is not None for b in bases):
+                raise NotImplementedError("ParallelEnv batches the built-in tour; a route_fn needs ZoneVecEnv.set_bank(aux=ranks)")
+            if len({b._fresh_first_obs for b in bases}) != 1:
+                raise ValueError("all envs of a ParallelEnv must share fresh_route_in_first_obs")
+            self._vec.enable_order(fresh_route_in_first_obs=bases[0]._fresh_first_obs)
+            self._order_shaped = not any(isinstance(b, TSPOrderTestEnv) for b in bases)   # TSP_order_test_env.py:72-74
         if all(f is not None for f in fixed):
             lo, hi = fixed[0].min_seed, fixed[0].max_seed
             if any((f.min_seed, f.max_seed) != (lo, hi) for f in fixed):
@@ -147,10 +158,17 @@ class ParallelEnv:
         return self._vec
 
     # ------------------------------------------------------------------ helpers
+    def _with_order_feature(self, zo):
+        """TSPOrderEnv.obs_zones (:37-47): every row gains the order feature of the route the observation saw."""
+        val = self._vec.get(nat.F_ORDER_VAL).astype(np.float64)
+        return np.concatenate([zo, val[:, :, None]], axis=2)
+
     def _obs_list(self):
         o, zo = self._vec.step_results(None, copy=False)[:2]
         o = o.astype(np.float64)
         zo = zo.astype(np.float64)
+        if self._order:
+            zo = self._with_order_feature(zo)
         return [{"zone_obs": z, "obs": x} for z, x in zip(zo, o)]
 
     def _step(self, actions, auto_reset):
@@ -158,6 +176,8 @@ class ParallelEnv:
         o, zo, r, d, g, exc = self._vec.step_results(a, auto_reset=auto_reset, copy=False)
         o = o.astype(np.float64)            # the reference's obs are float64 (ZoneWrapper concatenates float64)
         zo = zo.astype(np.float64)
+        if self._order:
+            zo = self._with_order_feature(zo)
         P = self.num_envs
         was_finished = getattr(self, "_finished", None)
         any_done = bool(d.any())
@@ -181,6 +201,9 @@ class ParallelEnv:
             for i, (sr, ng) in enumerate(zip(shaped.tolist(), need.tolist())):
                 infos[i]["shaped_reward"] = sr
                 infos[i]["need_next_goal"] = bool(ng)
+        if self._order and self._order_shaped:
+            for i, sr in enumerate(self._vec.get(nat.F_SHAPED_REWARD).tolist()):
+                infos[i]["shaped_reward"] = sr                # TSP_order_env.py:77-81
         self._finished = None if auto_reset else (d.copy() if was_finished is None else (was_finished | d))
         obs = tuple({"zone_obs": z, "obs": x} for z, x in zip(zo, o))
         return obs, tuple(r.astype(np.float64).tolist()), tuple(d.tolist()), tuple(infos)

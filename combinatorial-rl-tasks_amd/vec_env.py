@@ -22,7 +22,7 @@ _FIELD_DTYPES = {
     nat.F_ACTIONS: np.float32, nat.F_POLICY_MU: np.float32, nat.F_POLICY_STD: np.float32,
     nat.F_POLICY_VALUE: np.float32, nat.F_SHAPED_REWARD: np.float64, nat.F_NEED_GOAL: np.uint8,
     nat.F_AVAILABLE_GOALS: np.uint32, nat.F_GOAL: np.int32, nat.F_ORDER_VAL: np.float32,
-    nat.F_EXCEPTION: np.uint8, nat.F_POLICY_VALUE_SIGMA: np.float32,
+    nat.F_EXCEPTION: np.uint8, nat.F_POLICY_VALUE_SIGMA: np.float32, nat.F_ORDER_POS: np.int8,
 }
 
 
@@ -287,14 +287,23 @@ class ZoneVecEnv:
         check(lib().zenv_set_rollout_slice(self._h, int(envs_per_launch)))
 
     # ------------------------------------------------------------------ solver-ordered variant (8(f) row 3)
-    def enable_order(self):
+    def enable_order(self, fresh_route_in_first_obs=False):
         """TSPOrderEnv semantics (TSP_order_env.py:13-113); call before build_bank / set_bank -- an episode's
-        route is the bank's aux column (built-in PATH_CHEAPEST_ARC + local-search tour, or the caller's ranks)."""
+        route is the bank's aux column (built-in PATH_CHEAPEST_ARC + local-search tour, or the caller's ranks).
+        Default = the reference's reset(): the first observation of an episode is built before generate_route()
+        (:108-113) and carries the order feature of the route the env was left with.  fresh_route_in_first_obs=True:
+        the first observation shows the new episode's route (the build's opt-out, not reference behaviour)."""
         check(lib().zenv_order_enable(self._h))
+        check(lib().zenv_order_configure(self._h, nat.ORDER_FRESH_FIRST_OBS if fresh_route_in_first_obs else 0))
 
     def order_info(self):
-        """(shaped_reward float64 [N], order feature float32 [N,Z]: 0.5^(position in the remaining route))."""
+        """(shaped_reward float64 [N], order feature float32 [N,Z] of the last observation: 0.5^(position in the route
+        that observation saw))."""
         return self.get(nat.F_SHAPED_REWARD), self.get(nat.F_ORDER_VAL)
+
+    def order_routes(self):
+        """self.route of every env as positions: int8 [N,Z], position of zone z in the remaining route, -1 = not in it."""
+        return self.get(nat.F_ORDER_POS)
 
     # ------------------------------------------------------------------ goal-conditioned variant (8(f) row 3)
     def enable_goals(self):
@@ -469,7 +478,7 @@ class ZoneVecEnv:
         N = self.num_envs
         if field == nat.F_OBS:
             return (N, nat.OBS_DIM)
-        if field == nat.F_ORDER_VAL:
+        if field in (nat.F_ORDER_VAL, nat.F_ORDER_POS):
             return (N, self.num_zones)
         if field == nat.F_ZONE_OBS:
             return (N, self.num_zones, self.zone_feat)

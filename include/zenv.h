@@ -84,7 +84,9 @@ enum {
     ZENV_F_POLICY_VALUE_SIGMA = 31, /* float32 [N]   the distributional critic's sigma (flat_model.py:57-60) */
     ZENV_F_EXCEPTION = 30,       /* uint8   [N]      info['exception'] of the env's LAST FINISHED episode: 1 = it was ended by
                                   *                    Engine.step's MujocoException path (valid once done; see zenv_step) */
-    ZENV_F_COUNT = 32
+    ZENV_F_ORDER_POS = 32,       /* int8    [N,Z]    TSPOrderEnv's self.route: position of every zone in the remaining route, -1 =
+                                  *                    not in it (visited) */
+    ZENV_F_COUNT = 33
 };
 
 /* scripted on-device action sources (the build's own; used by bench/tests) */
@@ -278,6 +280,15 @@ int zenv_solver_goals(zenv_t *h, int32_t *goals);
  * of every zone (ZENV_F_ORDER_VAL, :37-47) -- the reference's (Z,7) row is [zone_obs row (6), order value].
  * Exclusive with zenv_goal_enable; zenv_rollout() is refused on such a handle. */
 int zenv_order_enable(zenv_t *h);
+/* First observation of an episode.  Default (flags 0) = the reference's: TSPOrderEnv.reset() builds init_obs BEFORE
+ * generate_route() (TSP_order_env.py:108-113), so the observation returned by reset() -- and by ParallelEnv's auto-reset,
+ * penv.py:8-11 -- carries the order feature of the route the env object was left with: all zeros before the first
+ * episode and after a finished one, the unvisited rest of the previous route (indexed by zone number, on the NEW map's
+ * rows) after a time-limit end.  From the first step on the feature follows the new route; shaped_reward /
+ * last_dist_to_goal use the new route from the start (:112).  ZENV_ORDER_FRESH_FIRST_OBS: the first observation
+ * already shows the new episode's route (not what the reference does). */
+#define ZENV_ORDER_FRESH_FIRST_OBS 1
+int zenv_order_configure(zenv_t *h, int flags);
 /* The built-in route of a layout (host only): rank[z] = position of zone z in the tour.  The problem is the one
  * TSP_Solver.get_optim_route (main/src/utils/TSP_Solver.py:24-62) hands to OR-tools -- closed tour from the robot, arc
  * cost int64(10 x distance), first solution PATH_CHEAPEST_ARC, greedy-descent local search (relocate, exchange, 2-opt,

@@ -79,6 +79,7 @@ class Env(C.Structure):
         ("layout_restarts", C.c_int32),
         ("goal_zone", C.c_int32), ("last_visit", C.c_int32), ("last_dist", C.c_double),
         ("route", C.c_int32 * MAX_Z), ("route_len", C.c_int32), ("exception", C.c_int32),
+        ("obs_route", C.c_int32 * MAX_Z), ("obs_route_len", C.c_int32), ("pad_order", C.c_int32),
     ]
 
 
@@ -125,7 +126,8 @@ def lib():
         L.orc_rollout.restype = C.c_int64
         L.orc_set_goal.argtypes = [C.POINTER(Env), C.c_int]
         L.orc_solver_next_goal.argtypes = [C.POINTER(Env)]
-        L.orc_order_reset.argtypes = [C.POINTER(Env), C.c_void_p]
+        L.orc_reset_order.argtypes = [C.POINTER(Env), C.POINTER(Config), C.c_int64, C.c_void_p, C.c_int]
+        L.orc_order_route.argtypes = [C.POINTER(Env), C.c_void_p]
         L.orc_step_order.argtypes = [C.POINTER(Env), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.orc_order_vals.argtypes = [C.POINTER(Env), C.c_void_p]
@@ -221,10 +223,23 @@ class OracleEnv:
         return r.value, bool(d.value), bool(g.value), sh.value, bool(nd.value)
 
     # solver-ordered variant (TSP_order_env.py)
-    def order_reset(self, rank):
+    def reset_order(self, seed, rank, fresh_first_obs=False):
+        """TSPOrderEnv.reset() (TSP_order_env.py:108-113) for env.seed(seed): the first observation carries the order
+        feature of the route this object was left with (the reference builds it before generate_route()); `rank` is
+        what generate_route() then produces."""
         r = np.ascontiguousarray(rank, np.int32)
-        if lib().orc_order_reset(C.byref(self.e), r.ctypes.data) != 0:
+        rc = lib().orc_reset_order(C.byref(self.e), C.byref(self.cfg), int(seed), r.ctypes.data, int(bool(fresh_first_obs)))
+        if rc == -3:
+            raise RuntimeError("ResamplingError: Failed to sample layout of objects")
+        if rc != 0:
             raise ValueError("rank out of range")
+        return self.obs()
+
+    @property
+    def route(self):
+        r = np.empty(self.Z, np.int32)
+        n = lib().orc_order_route(C.byref(self.e), r.ctypes.data)
+        return [int(v) for v in r[:n]]
 
     def step_order(self, action):
         a = (C.c_float * 2)(float(action[0]), float(action[1]))

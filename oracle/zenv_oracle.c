@@ -565,15 +565,34 @@ static double order_dist(const orc_env *e)
     return sqrt(dx * dx + dy * dy);
 }
 
-int orc_order_reset(orc_env *e, const int32_t *rank)
+static void order_obs_sees_route(orc_env *e)
 {
-    const int Z = e->cfg.num_zones;
-    for (int z = 0; z < Z; z++) {
+    for (int i = 0; i < e->route_len; i++) e->obs_route[i] = e->route[i];
+    e->obs_route_len = e->route_len;
+}
+
+int orc_reset_order(orc_env *e, const orc_config *cfg, int64_t seed, const int32_t *rank, int fresh_first_obs)
+{
+    const int Z = cfg->num_zones;
+    if (Z < 1 || Z > ORC_MAX_Z) return -2;
+    for (int z = 0; z < Z; z++)
         if (rank[z] < 0 || rank[z] >= Z) return -1;
-        e->route[rank[z]] = z;
-    }
+    /* self.route belongs to the env object, not to the episode: it survives Engine.reset() */
+    int32_t left[ORC_MAX_Z];
+    const int n_left = e->route_len;
+    for (int i = 0; i < n_left; i++) left[i] = e->route[i];
+    /* :109-110  self.zones = [unvisited] * num_cities; init_obs = super().reset() -> ... -> obs() -> obs_zones() (:37-47)
+     * with the route above */
+    int rc = orc_reset(e, cfg, seed);
+    if (rc) return rc;
+    for (int i = 0; i < n_left; i++) e->obs_route[i] = left[i];
+    e->obs_route_len = n_left;
+    /* :111  generate_route() */
+    for (int z = 0; z < Z; z++) e->route[rank[z]] = z;
     e->route_len = Z;
-    e->last_dist = order_dist(e);                      /* :112 */
+    /* :112  last_dist_to_goal = dist_to_goal() */
+    e->last_dist = order_dist(e);
+    if (fresh_first_obs) order_obs_sees_route(e);
     return 0;
 }
 
@@ -594,6 +613,7 @@ int orc_step_order(orc_env *e, const float action[2], double *reward, int *done,
         *shaped_reward = e->last_dist - d;
         e->last_dist = d;
     }
+    order_obs_sees_route(e);                           /* Engine.step's obs() ran after set_mocaps() */
     return 0;
 }
 
@@ -601,7 +621,13 @@ void orc_order_vals(const orc_env *e, float *vals)
 {
     /* obs_zones: np.power(0.5, self.route.index(i)) if i in self.route else 0 (:41-45) */
     for (int z = 0; z < e->cfg.num_zones; z++) vals[z] = 0.f;
-    for (int i = 0; i < e->route_len; i++) vals[e->route[i]] = (float)ldexp(1.0, -i);
+    for (int i = 0; i < e->obs_route_len; i++) vals[e->obs_route[i]] = (float)ldexp(1.0, -i);
+}
+
+int orc_order_route(const orc_env *e, int32_t *route)
+{
+    for (int i = 0; i < e->route_len; i++) route[i] = e->route[i];
+    return e->route_len;
 }
 
 /* ---- goal-conditioned variant ---- */

@@ -92,6 +92,11 @@ typedef struct orc_env {
     int32_t route[ORC_MAX_Z];
     int32_t route_len;
     int32_t exception;         /* info['exception'] of the last step ([UPSTREAM] Engine.step) */
+    /* self.route as the most recent obs() call saw it.  It differs from `route` only between reset() and the first
+     * step: TSPOrderEnv.reset builds its observation BEFORE generate_route() (TSP_order_env.py:108-113) */
+    int32_t obs_route[ORC_MAX_Z];
+    int32_t obs_route_len;
+    int32_t pad_order;
 } orc_env;
 
 /* ---- numpy-legacy RandomState restatement (exposed for pinning tests) ---- */
@@ -148,10 +153,18 @@ int orc_step_goal(orc_env *e, const float action[2], double *reward, int *done, 
                   double *shaped_reward, int *need_next_goal);
 
 /* ---- solver-ordered variant: TSPOrderEnv main/envs/TSP_order_env.py:13-113 (TSP task) ----
- * orc_order_reset: after orc_reset, the route generate_route() would have produced (rank[z] = position of zone z;
- * the solver itself, OR-tools, is outside the tree) and last_dist_to_goal (:108-113).  orc_step_order: orc_step
- * plus info['shaped_reward'] (:63-75).  orc_order_vals: the 7th row feature 0.5^index, 0 when not in the route. */
-int orc_order_reset(orc_env *e, const int32_t *rank);
+ * orc_reset_order: TSPOrderEnv.reset() in the reference's statement order (:108-113) on an env object that LIVES ON
+ * across episodes (`e` must be zero-initialised before its first reset: self.route = [] of __init__, :27):
+ *   zones = unvisited; init_obs = super().reset()   <- the observation is built here, from self.route AS IT STOOD: the
+ *                                                      previous episode's leftover (empty after a finished episode)
+ *   generate_route()                                <- rank[z] = position of zone z in the new route (the solver,
+ *                                                      OR-tools, is outside the tree: the caller supplies its answer)
+ *   last_dist_to_goal = dist_to_goal()
+ * fresh_first_obs != 0: the build's opt-out -- the first observation already shows the new route.
+ * orc_step_order: orc_step plus info['shaped_reward'] (:63-75).  orc_order_vals: the 7th row feature of the most
+ * recent observation, 0.5^index in the route that obs() saw, 0 when not in it (:41-45).  orc_order_route: self.route. */
+int orc_reset_order(orc_env *e, const orc_config *cfg, int64_t seed, const int32_t *rank, int fresh_first_obs);
+int orc_order_route(const orc_env *e, int32_t *route);   /* returns its length */
 int orc_step_order(orc_env *e, const float action[2], double *reward, int *done, int *goal_met, double *shaped_reward);
 void orc_order_vals(const orc_env *e, float *vals);
 

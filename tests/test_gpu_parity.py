@@ -433,15 +433,20 @@ def test_goal_conditioned_variant_lockstep(zenv_mod, oracle_mod, env_id):
     env.close()
 
 
-def test_solver_ordered_variant_lockstep(zenv_mod, oracle_mod):
+@pytest.mark.parametrize("fresh", [False, True])
+def test_solver_ordered_variant_lockstep(zenv_mod, oracle_mod, fresh):
     """TSPOrderEnv (TSP_order_env.py:13-113) -- route per episode (the bank's aux column: the
     built-in tour for even envs, an arbitrary caller-supplied permutation for odd ones), order feature
-    0.5^(position in the remaining route), shaped reward towards the route's first zone; auto-reset on."""
+    0.5^(position in the remaining route), shaped reward towards the route's first zone; auto-reset on.
+    fresh=False is the reference's reset(): an episode's first observation -- from reset() and from the auto-reset inside
+    a step -- is built before generate_route() (:108-113) and carries the feature of the route the env was left with
+    (zeros at first, zeros after a finished episode, the leftover after a time-limit end: the short horizon here makes
+    most episodes end that way).  fresh=True: the build's opt-out."""
     Z, O = zenv_mod, oracle_mod
     n, T, nz = 120, 300, 15
     cfg = Z.config_for_id("PointTSP-v0", num_steps=140)
     env = Z.ZoneVecEnv(cfg, n)
-    env.enable_order()
+    env.enable_order(fresh_route_in_first_obs=fresh)
     rs = np.random.RandomState(3)
     robots, zones, ranks = [], [], []
     for i in range(n):
@@ -453,19 +458,22 @@ def test_solver_ordered_variant_lockstep(zenv_mod, oracle_mod):
     env.reset()
     refs = [O.OracleEnv(oracle_config_from(O, cfg)) for _ in range(n)]
     for i, e in enumerate(refs):
-        e.reset(50 + i)
+        e.reset_order(50 + i, ranks[i], fresh_first_obs=fresh)
         assert np.allclose(e.layout[1], zones[i], atol=0, rtol=0)
-        e.order_reset(ranks[i])
     sh, val = env.order_info()
     assert np.array_equal(val, np.stack([e.order_vals() for e in refs])) and not sh.any()
+    assert val.any() == fresh                                  # the reference's very first obs: self.route = [] (:27)
+    pos = env.order_routes()
+    assert all([int(z) for z in np.argsort(pos[i])] == refs[i].route for i in range(n))
     # the built-in tour visits every zone once and is never longer than the plain nearest-neighbour tour
     r0 = ranks[0]
     assert sorted(r0) == list(range(nz))
-    n_visits = n_resets = 0
+    n_visits = n_resets = n_stale = 0
     for t in range(T):
         o, zo = env.observations()
-        # steer to the first zone of the remaining route (order feature == 1), with noise
-        tgt_idx = np.argmax(val, axis=1)
+        # steer to the first zone of the remaining route, with noise
+        pos = env.order_routes()
+        tgt_idx = np.argmax(pos == 0, axis=1)
         d = zo[np.arange(n), tgt_idx, :2] * 3.0 - o[:, 1:3] * 3.0
         ang = np.arctan2(d[:, 1], d[:, 0]) - np.arctan2(o[:, 4], o[:, 3])
         ang = (ang + np.pi) % (2 * np.pi) - np.pi
@@ -474,16 +482,21 @@ def test_solver_ordered_variant_lockstep(zenv_mod, oracle_mod):
         env.step(a, auto_reset=True)
         _, _, r, dn, _ = env.results()
         sh, val = env.order_info()
+        pos = env.order_routes()
         for i, e in enumerate(refs):
             r_ref, d_ref, _, sh_ref = e.step_order(a[i])
             assert (r[i], dn[i]) == (np.float32(r_ref), d_ref) and sh[i] == sh_ref, (t, i, sh[i], sh_ref)
             n_visits += r_ref >= 1.0
             if d_ref:
-                e.reset(50 + i)
-                e.order_reset(ranks[i])
+                left = e.route
+                e.reset_order(50 + i, ranks[i], fresh_first_obs=fresh)     # penv.py:8-11: `if done: obs = env.reset()`
                 n_resets += 1
+                if not fresh and left:
+                    n_stale += 1
+                    assert e.order_vals()[left[0]] == 1.0 and e.route != left
+            assert [int(z) for z in np.argsort(pos[i]) if pos[i][z] >= 0] == e.route, (t, i)
         assert np.array_equal(val, np.stack([e.order_vals() for e in refs])), t
-    assert n_visits > n and n_resets > n
+    assert n_visits > n and n_resets > n and (fresh or n_stale > n // 2)
     with pytest.raises(Z.ZenvError):
         env.enable_goals()                                    # one variant per handle
     env.close()

@@ -460,11 +460,11 @@ def test_solver_ordered_semantics_and_route_heuristic(oracle_mod, zenv_mod):
     O, Z = oracle_mod, zenv_mod
     cfg = O.default_config(O.TASK_TSP, 5, num_steps=400)
     e = O.OracleEnv(cfg)
-    e.reset(1000003)
-    robot, zones = e.layout
     rank = np.array([2, 0, 4, 1, 3], np.int32)                # route = [1, 3, 0, 4, 2]
-    e.order_reset(rank)
+    e.reset_order(1000003, rank, fresh_first_obs=True)        # (the reference's own first obs: next test)
+    robot, zones = e.layout
     assert list(e.order_vals()) == [0.25, 1.0, 0.0625, 0.5, 0.125]            # :41-45: 0.5 ** route.index(i)
+    assert e.route == [1, 3, 0, 4, 2]
     assert e.e.last_dist == math.hypot(zones[1][0] - robot[0], zones[1][1] - robot[1])   # :112
     total, visits = 0.0, []
     for t in range(400):
@@ -512,6 +512,87 @@ def test_solver_ordered_semantics_and_route_heuristic(oracle_mod, zenv_mod):
         assert got <= 1.05 * best
         hits += got == best
     assert hits >= 10
+
+
+def _steer(o, zo, tgt):
+    g = zo[tgt, :2] * 3.0 - o[1:3] * 3.0
+    ang = (math.atan2(g[1], g[0]) - math.atan2(o[4], o[3]) + math.pi) % (2 * math.pi) - math.pi
+    return [1.0 if abs(ang) < 0.6 else 0.0, max(-1.0, min(1.0, 2 * ang))]
+
+
+def test_order_env_first_observation_is_built_before_generate_route(oracle_mod):
+    """TSPOrderEnv.reset() (TSP_order_env.py:108-113) returns `init_obs = super().reset()`, built BEFORE
+    `self.generate_route()`: obs_zones (:37-47) sees self.route as the env object was left with it.  Truth table written
+    from the source, with a plain Python list playing self.route:
+      (0) before the first episode self.route = [] (:27)                      -> first obs: all zeros
+      (a) episode 1 finished (every city visited, route emptied by :90)         -> episode 2's first obs: all zeros
+      (b) episode 1 ended by the time limit with cities left                    -> episode 2's first obs: 0.5 ** index in
+          the LEFTOVER route, by zone number, on the new map's rows
+    and in every case the route proper, last_dist_to_goal (:112) and every later observation are the new episode's."""
+    O = oracle_mod
+    Zn = 5
+
+    def feature(route):                                        # :41-45
+        return [0.5 ** route.index(i) if i in route else 0.0 for i in range(Zn)]
+
+    rank1 = np.array([2, 0, 4, 1, 3], np.int32)
+    rank2 = np.array([4, 3, 2, 1, 0], np.int32)
+    # ---- (0) + (a): a finished episode
+    cfg = O.default_config(O.TASK_TSP, Zn, num_steps=2000)
+    e = O.OracleEnv(cfg)
+    e.reset_order(1000003, rank1)
+    route = []                                                 # self.route = [] (:27) is what init_obs saw ...
+    assert list(e.order_vals()) == feature(route) == [0.0] * Zn
+    route = list(np.argsort(rank1))                            # ... then generate_route() (:111)
+    assert e.route == route == [1, 3, 0, 4, 2]
+    robot, zones = e.layout
+    assert e.e.last_dist == math.hypot(zones[1][0] - robot[0], zones[1][1] - robot[1])   # :112, the NEW route's first city
+    done, first_step = False, True
+    while not done:
+        o, zo = e.obs()
+        r, done, gm, sh = e.step_order(_steer(o, zo, route[0]))
+        if r >= 1.0:
+            route.remove(e.e.last_visit)                       # :90
+        assert list(e.order_vals()) == feature(route)          # from the first step on: the route proper
+        assert first_step is False or e.order_vals().max() == 1.0
+        first_step = False
+    assert gm and route == [] and e.route == []
+    e.reset_order(1000004, rank2)                              # the worker's `if done: obs = env.reset()` (penv.py:8-11)
+    assert list(e.order_vals()) == [0.0] * Zn                  # (a)
+    assert e.route == [4, 3, 2, 1, 0]
+    e.step_order([0.0, 0.0])
+    assert list(e.order_vals()) == feature([4, 3, 2, 1, 0])
+    # ---- (b): the time limit ends episode 1 after two visits
+    cfg = O.default_config(O.TASK_TSP, Zn, num_steps=2000)
+    e = O.OracleEnv(cfg)
+    e.reset_order(1000003, rank1)
+    route = list(np.argsort(rank1))
+    n_visits = 0
+    for t in range(2000):
+        o, zo = e.obs()
+        a = _steer(o, zo, route[0]) if n_visits < 2 else [0.0, 0.0]    # two cities, then stand still until the limit
+        r, done, gm, sh = e.step_order(a)
+        if r >= 1.0:
+            route.remove(e.e.last_visit)
+            n_visits += 1
+        if done:
+            break
+    assert done and not gm and e.e.steps == 2000 and route == [0, 4, 2]
+    e.reset_order(1000004, rank2)
+    assert list(e.order_vals()) == feature([0, 4, 2]) == [1.0, 0.0, 0.25, 0.0, 0.5]     # (b): the leftover, by zone number
+    assert e.route == [4, 3, 2, 1, 0]
+    robot, zones = e.layout                                    # the new map
+    assert e.e.last_dist == math.hypot(zones[4][0] - robot[0], zones[4][1] - robot[1])
+    o, zo = e.obs()
+    _, _, _, sh = e.step_order(_steer(o, zo, 4))
+    assert list(e.order_vals()) == feature([4, 3, 2, 1, 0])
+    # shaped_reward of the first step is progress towards the NEW route's first city from the reset pose (:68-71)
+    o2, _ = e.obs()
+    d_after = math.hypot(zones[4][0] - 3.0 * float(o2[1]), zones[4][1] - 3.0 * float(o2[2]))
+    assert abs(sh - (math.hypot(zones[4][0] - robot[0], zones[4][1] - robot[1]) - d_after)) < 1e-6
+    # ---- the build's opt-out: the first observation already shows the new route
+    e.reset_order(1000005, rank1, fresh_first_obs=True)
+    assert list(e.order_vals()) == feature([1, 3, 0, 4, 2])
 
 
 def test_oracle_regression_vectors(oracle_mod):
