@@ -24,6 +24,7 @@ ROLLOUT_ASYNC = 4
 ROLLOUT_CHUNK = 256
 COMM_ID_BYTES = 128
 ORDER_FRESH_FIRST_OBS = 1
+CHUNK_NO_RESET, CHUNK_RESET_EVERY, CHUNK_RESET_LAST = 0, 1, 2
 
 E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE, E_RANGE = -1, -2, -3, -4, -5, -6
 
@@ -31,7 +32,8 @@ E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE, E_RANGE = -1, -2, -3, -4, -5, -6
  F_LAST_LEN, F_EPISODES, F_VISIT_COUNT, F_SEED, F_ACTIONS, F_POLICY_MU, F_POLICY_STD, F_POLICY_VALUE,
  F_SHAPED_REWARD, F_NEED_GOAL, F_AVAILABLE_GOALS, F_GOAL,
  F_EXP_OBS, F_EXP_ZONE_OBS, F_EXP_ACTION, F_EXP_LOG_PROB, F_EXP_VALUE, F_EXP_REWARD, F_EXP_MASK,
- F_EXP_ADVANTAGE, F_EXP_RETURN, F_ORDER_VAL, F_EXCEPTION, F_POLICY_VALUE_SIGMA, F_ORDER_POS) = range(33)
+ F_EXP_ADVANTAGE, F_EXP_RETURN, F_ORDER_VAL, F_EXCEPTION, F_POLICY_VALUE_SIGMA, F_ORDER_POS,
+ F_CHUNK_REWARD, F_CHUNK_DONE) = range(35)
 (RESULT_OBS, RESULT_REWARD, RESULT_DONE, RESULT_GOAL_MET, RESULT_EXCEPTION, RESULT_ZONE_OBS) = range(6)
 N_RESULTS = 6
 
@@ -106,6 +108,7 @@ _PROTOTYPES = {
     "zenv_schedule_fixed_seeds": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int64]),
     "zenv_reset": (C.c_int, [_H, C.c_void_p]),
     "zenv_step": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
+    "zenv_step_many": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "zenv_policy": (C.c_int, [_H, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "zenv_rollout": (C.c_int, [_H, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                C.POINTER(C.c_float), C.POINTER(C.c_float)]),

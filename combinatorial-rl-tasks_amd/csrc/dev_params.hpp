@@ -72,6 +72,7 @@ struct DevParams {
     int64_t *seed;
     // schedule
     int32_t *slot_first, *episode_idx;
+    int32_t *next_slot;   // [N] sequential / ring schedules: bank slot of the env's NEXT episode (see slot_after, kernels.hip)
     int32_t *reset_hint;  // [N] bank slot an env may reset into at the next step (-1: none): prefetch hint, not state
     uint64_t *pcg;        // [N][4] state_hi,state_lo,inc_hi,inc_lo
     uint32_t *pcg_buf;    // [N][2] has_u32,u32

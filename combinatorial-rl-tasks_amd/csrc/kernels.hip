@@ -184,11 +184,36 @@ __device__ __forceinline__ int seq_slot(const P &p, int first, int k)
     return (int)(s % (long long)p.bank_size);
 }
 
+// The slot after `slot` in env's schedule, without a division: sequential walks the bank by sched_stride (< bank_size,
+// one conditional subtraction), ring walks round its own `depth` slots.  Kept per env in p.next_slot (state), so that
+// the step kernels know the slot of an env's NEXT episode from one 4-byte load: seq_slot()'s 64-bit modulo by a run-time
+// divisor used to sit on the zone wave's path of every step in which some env of the tile was close to its end (the
+// reset-prefetch hint) -- ~150 instructions.  Invariant: next_slot[env] == seq_slot(slot_first[env], episode_idx[env])
+// (k_sched_sync re-establishes it when the host changes the bank or the schedule).
 template <typename P>
-__device__ __forceinline__ int next_bank_slot(const P &p, int env, int k, int first)
+__device__ __forceinline__ int slot_after(const P &p, int env, int slot)
+{
+    if (p.sched_mode == SCHED_RING) {
+        const int first = p.slot_first[env];
+        const int n = slot + 1;
+        return n >= first + p.sched_stride ? first : n;
+    }
+    const int n = slot + p.sched_stride;
+    return n >= p.bank_size ? n - p.bank_size : n;
+}
+
+// Bank slot of env's next episode (and advance the schedule).  k = its episode index, nslot = p.next_slot[env], passed
+// in when the caller has already loaded them; nslot comes back advanced.
+template <typename P>
+__device__ __forceinline__ int next_bank_slot(const P &p, int env, int k, int &nslot)
 {
     p.episode_idx[env] = k + 1;
-    if (p.sched_mode != SCHED_FIXED_SEEDS) return seq_slot(p, first, k);
+    if (p.sched_mode != SCHED_FIXED_SEEDS) {
+        const int slot = nslot;
+        nslot = slot_after(p, env, slot);
+        p.next_slot[env] = nslot;
+        return slot;
+    }
     // wrappers.py:20-23: rng.integers(min_seed, max_seed + 1) -- Lemire on 32-bit draws
     const uint64_t rng = (uint64_t)(p.seed_max - p.seed_min);
     if (rng == 0) return 0;
@@ -207,7 +232,8 @@ __device__ __forceinline__ int next_bank_slot(const P &p, int env, int k, int fi
 template <typename P>
 __device__ __forceinline__ int next_bank_slot(const P &p, int env)
 {
-    return next_bank_slot(p, env, p.episode_idx[env], p.slot_first[env]);
+    int nslot = p.next_slot[env];
+    return next_bank_slot(p, env, p.episode_idx[env], nslot);
 }
 
 // bit i of x -> bit 2i of the result
@@ -940,7 +966,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         int auxr[ZR];
         constexpr int ZW = ZT > 0 ? (ZT + 7) / 8 : 1;
         uint64_t cdw[ZW];   // ColourMatch: the env's cooldown bytes, eight zones per word
-        int epi_idx = 0, slot_first = 0;
+        int nslot = 0, epi_idx = 0;   // bank slot (sequential / ring schedules) and index of this env's next episode
         float2 act = make_float2(0.f, 0.f);
         {
             // ---- issue every load of this env first.  No branch around them: a lane beyond the batch (the last tile
@@ -984,8 +1010,8 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 __builtin_amdgcn_sched_barrier(0);
             }
             // only needed at the very end (reset / prefetch): requested behind the zone loads
-            epi_idx = p.episode_idx[envl];     // the bank slot of a reset is known before it happens
-            slot_first = p.slot_first[envl];
+            nslot = p.next_slot[envl];         // the bank slot of a reset is known before it happens
+            epi_idx = p.episode_idx[envl];
         }
 
         float rew_out = 0.f;
@@ -1178,7 +1204,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         // of the launch's critical path (round 3 stamps; a prefetch at the END of the previous launch, as rounds 1-2
         // had it, only reaches the Infinity Cache: the L2s are invalidated between launches).
         int hint = -1;
-        if (ends_soon && auto_reset && p.sched_mode != SCHED_FIXED_SEEDS) hint = seq_slot(p, slot_first, epi_idx);
+        if (ends_soon && auto_reset && p.sched_mode != SCHED_FIXED_SEEDS) hint = nslot;
 
         ZSTAMP(15);
         // ---- auto-reset (penv.py:8-11), wave-cooperative: for each finished env of the tile,
@@ -1189,7 +1215,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         if (pending) {
             ZSTAMP(5);
             int my_slot = 0;
-            if (need_reset) my_slot = next_bank_slot(p, env, epi_idx, slot_first);
+            if (need_reset) my_slot = next_bank_slot(p, env, epi_idx, nslot);
             while (pending) {
                 const int j = __ffsll((long long)pending) - 1;   // wave-uniform
                 pending &= pending - 1;
@@ -1657,9 +1683,16 @@ __device__ __forceinline__ float2 greedy_action_regs(const float4 *zp, const int
     return a;
 }
 
-template <int TASK, int ZT>
+// EXT = true: the action-chunk form (zenv_step_many) -- the actions of the launch's steps come from a caller-supplied
+// buffer io.actions [n_steps][N] instead of a scripted policy (a_{t+1} is requested at the top of step t and waited
+// for right behind the physics, before the step's own stores are issued, so the wait never drains them); a NaN action
+// takes Engine.step's exception branch as in k_step_lane; every step's reward / done is also recorded time-major in
+// io.reward / io.done.  auto_reset: 0 never (step_no_reset: a finished env idles as WaitWrapper's no-op), 1 every step
+// (step), 2 only in the launch's LAST step -- skill_len - 1 step_no_reset calls, then one step
+// (main/src/torch_ac/algos/_hier_policy_opt.py:68-71, hier_base.py:179-183).
+template <int TASK, int ZT, bool EXT>
 __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, int tile0)
+void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, int tile0, ChunkIO io)
 {
     static_assert(ZT > 0 && ZT <= 30, "zone arrays live in registers; bit 31 / 63 of the step word are flags");
     using SE = typename StaticEnt<TASK>::type;
@@ -1746,7 +1779,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
     bool frozen = false;
     double ep_ret = 0.0;
     double hs = 0.0, hc = 1.0;     // sin / cos of half the hinge angle, carried from obs to the next step's physics
-    int epi_idx = 0, slot_first = 0, vcount = 0;
+    int epi_idx = 0, nslot = 0, vcount = 0;
     float2 act = make_float2(0.f, 0.f);
     float4 zp[ZH];
     int auxr[ZT];
@@ -1763,7 +1796,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         e.q0 = qa.x; e.q1 = qa.y; e.q2 = qb.x;
         e.v0 = qb.y; e.v1 = qc.x; e.v2 = qc.y;
         e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
-        act = reinterpret_cast<const float2 *>(p.actions)[env];
+        act = EXT ? io.actions[env] : reinterpret_cast<const float2 *>(p.actions)[env];
         det_sincos_inl(0.5 * e.q2, hs, hc);
         frozen = p.done_state[env] != 0;
         e.steps = p.steps[env];
@@ -1776,7 +1809,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         ep_ret = p.ep_return[env];
         vcount = p.visit_count[env];
         epi_idx = p.episode_idx[env];
-        slot_first = p.slot_first[env];
+        nslot = p.next_slot[env];
 #pragma unroll
         for (int h = 0; h < ZH; ++h) zp[h] = p.zpf[(size_t)h * N + env];
 #pragma unroll
@@ -1823,10 +1856,19 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
     // the last tile) on harmless zero state -- and only the global stores and the rare events (rim test, episode end,
     // reset, frozen env) sit behind exec masks.
     const bool fs10 = p.frameskip == ZENV_SUBSTEP_UNROLL;
+    const float2 *act_src = EXT ? io.actions + (valid ? env : 0) : nullptr;   // walks down the [n_steps][N] buffer
+    float *rec_rew = EXT ? io.reward + (valid ? env : 0) : nullptr;
+    uint8_t *rec_done = EXT ? io.done + (valid ? env : 0) : nullptr;
     for (int t = 0; t < n_steps; ++t) {
         StepPolicy polt = pol;
         polt.step_index = pol.step_index + (uint32_t)t;
         const bool live = valid && !frozen;
+        const bool ar_t = auto_reset == 1 || (auto_reset == 2 && t == n_steps - 1);
+        float2 act_next = act;
+        if (EXT && t + 1 < n_steps) {
+            act_src += N;
+            act_next = *act_src;         // a_{t+1}: in flight underneath this step's zone pass and physics
+        }
         if (t == (n_steps >> 1)) ZSTAMP(0);
         const int k = e.steps + 1;
         double rx, ry;
@@ -1880,12 +1922,14 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
             }
         }
         const bool timed_out = TASK == ZENV_TASK_TIMED_TSP && (expired & ~e.vis & full) != 0u;
-        // ---- reward / goal / termination (Engine.step order).  No exception path here (see k_step_lane): this
-        // kernel's actions come from the scripted on-device policies only, which are finite by construction.
+        // ---- reward / goal / termination (Engine.step order).  The scripted on-device policies are finite by
+        // construction; a caller's action (EXT) may hold a NaN: Engine.step's MujocoException branch, as in k_step_lane
+        // -- reward_exception, done, no reward() / goal test, the joint state mj_resetData leaves (below).
+        const bool exc = EXT && !(act.x == act.x && act.y == act.y);
         double r = 0.0;
         bool goal = false;
         if (kColour) {
-            if (first >= 0) {
+            if (first >= 0 && !exc) {
                 const int nd = hamming_to_goal(e.colpack, Z);
                 r = (double)(e.goal_dist - nd);
                 e.goal_dist = nd;
@@ -1895,22 +1939,26 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
             r = first >= 0 ? 1.0 : 0.0;
             goal = (e.vis & full) == full;
         }
+        if (exc) {
+            r = p.reward_exc;
+            goal = false;
+        }
         if (goal) r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
         e.steps = k;
-        const bool done = goal || k >= p.num_steps || (TASK == ZENV_TASK_TIMED_TSP && timed_out);
+        const bool done = goal || exc || k >= p.num_steps || (TASK == ZENV_TASK_TIMED_TSP && timed_out);
         ep_ret = ep_ret + r;
         const float rew_out = live ? (float)r : 0.f;                   // a frozen env reports reward 0, done 1
         const uint8_t done_out = (!live || done) ? 1 : 0, goal_out = (live && goal) ? 1 : 0;
         // (a frozen env -- finished earlier under step_no_reset -- comes back at the first auto-reset step: the worker's
         // `if done: obs = env.reset()` after WaitWrapper's no-op, penv.py:8-11, wrappers.py:34-45)
-        const bool need_reset = valid && auto_reset && (frozen || done);
+        const bool need_reset = valid && ar_t && (frozen || done);
         // (an env auto-reset in this step reports the finished episode's count; a frozen one keeps its last)
         vcount = live ? (kColour ? e.goal_dist : (int)__popc(e.vis)) : vcount;
         if (live && done) {
             pc.last_return[env] = ep_ret;
             pc.last_len[env] = k;
             pc.episodes[env] += 1;
-            pc.exception[env] = 0;
+            pc.exception[env] = exc ? 1 : 0;
         }
         uint64_t dword = !live ? kDynZero
                          : kColour ? e.colpack
@@ -1925,6 +1973,15 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 2)   // diagnostic: bit 1 drops the physics
             physics_step(p, e, c0, c1, hs, hc, fs10);
 #endif
+            if (EXT) {
+                if (exc) {                    // what mj_resetData leaves: qpos = qpos0, qvel = 0
+                    e.q0 = e.q1 = e.q2 = 0.0;
+                    e.v0 = e.v1 = e.v2 = 0.0;
+                }
+                // a_{t+1} has had the whole physics to arrive; take it HERE, before this step's stores are issued
+                asm volatile("" : "+v"(act_next.x), "+v"(act_next.y)::"memory");
+                act = act_next;
+            }
             if (t == (n_steps >> 1)) ZSTAMP(2);
             emit_obs8(p, e, o, hs, hc);
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 4)   // diagnostic: bit 2 drops the action source
@@ -1941,7 +1998,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
             for (int i = 0; i < 8; ++i) o[i] = 0.f;
             if (pol.policy >= 0) act = make_float2(0.f, 0.f);
         }
-        if (live && done && !auto_reset) {
+        if (live && done && !ar_t) {
             // finished, no auto-reset: frozen from the next step on.  Its registers go back to the state arrays NOW --
             // from here on the lane only idles through the steps on them (nothing of a frozen lane is written back).
             pc.done_state[env] = 1;
@@ -1958,7 +2015,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
             lds_ctr_wait(ctr + 1, t);     // flush(t-1) has read the static entries about to change
             int my_slot = 0;
             if (need_reset) {
-                my_slot = next_bank_slot(pc, env, epi_idx, slot_first);
+                my_slot = next_bank_slot(pc, env, epi_idx, nslot);
                 epi_idx += 1;
             }
             while (pending) {
@@ -2033,7 +2090,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
                     ep_ret = 0.0;
                     hs = 0.0;
                     hc = 1.0;
-                    act = next_act;
+                    if (!EXT) act = next_act;
                     dword = kColour ? colpack : (uint64_t)vis0;   // only the pre-visited zones, step count 0
                     pc.seed[env] = pc.bank_seed[slot];
                     store_obs8(p, env, of);
@@ -2074,15 +2131,23 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
             p.reward[env] = rew_out;
             p.done_out[env] = done_out;
             p.goal_met[env] = goal_out;
+            if (EXT) {
+                *rec_rew = rew_out;
+                *rec_done = done_out;
+            }
         }
 #endif
+        if (EXT) {
+            rec_rew += N;
+            rec_done += N;
+        }
         if (t == (n_steps >> 1)) ZSTAMP(5);
     }
 
     // ---- the registers go back to the state arrays (a frozen env's did when it froze, or never left them)
     if (valid) {
         if (!frozen) write_back(e, ep_ret);
-        if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = act;
+        if (!EXT && pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = act;
     }
 }
 
@@ -2606,6 +2671,16 @@ __global__ __launch_bounds__(64) void k_bank_scatter(DevParams p, const int32_t 
     for (int i = lane; i < Z; i += 64) const_cast<int32_t *>(p.bank_aux)[(size_t)slot * Z + i] = ra[i];
 }
 
+// =========================================================================== schedule sync
+// next_slot[env] = seq_slot(slot_first[env], episode_idx[env]): the invariant of slot_after(), re-established after the
+// host changed the schedule or swapped the bank for one of another size (the modulo lives here, off every step path).
+__global__ __launch_bounds__(256) void k_sched_sync(DevParams p)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.N) return;
+    p.next_slot[env] = p.sched_mode == SCHED_FIXED_SEEDS ? 0 : seq_slot(p, p.slot_first[env], p.episode_idx[env]);
+}
+
 // =========================================================================== gather prep
 // The send buffer of the job's one collective (zenv_allgather): field [N] -> 4-byte elements, float64 narrowed to
 // float32 ("ncclAllGather of float ep_return[N/G]").
@@ -2656,6 +2731,12 @@ hipError_t launch_bank_scatter(const DevParams &p, const int32_t *slots, const v
 {
     hipLaunchKernelGGL(k_bank_scatter, dim3(count), dim3(64), 0, s, p, slots, static_cast<const unsigned char *>(staging),
                        rec_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_sched_sync(const DevParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sched_sync, dim3((p.N + 255) / 256), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -2753,15 +2834,15 @@ bool rollout_kernel_available(const DevParams &p)
     return p.kernel == ZENV_KERNEL_LANE_PER_ENV && (p.Z == 5 || p.Z == 6 || p.Z == 10 || p.Z == 15 || p.Z == 20 || p.Z == 25);
 }
 
-template <int TASK>
+template <int TASK, bool EXT>
 static void launch_rollout_task(const DevParams &p, int n_steps, int auto_reset, const StepPolicy &pol, hipStream_t s,
-                                hipEvent_t ev_start, hipEvent_t ev_stop, int tile0, int n_tiles)
+                                hipEvent_t ev_start, hipEvent_t ev_stop, int tile0, int n_tiles, const ChunkIO &io)
 {
     const dim3 grid(n_tiles), block(2 * kWave);
     const size_t lds = rollout_lds_bytes(p);
-#define ZENV_LAUNCH(ZT)                                                                                       \
-    hipExtLaunchKernelGGL((k_rollout_lane<TASK, ZT>), grid, block, lds, s, ev_start, ev_stop, 0, p, n_steps, \
-                          auto_reset, pol, tile0)
+#define ZENV_LAUNCH(ZT)                                                                                            \
+    hipExtLaunchKernelGGL((k_rollout_lane<TASK, ZT, EXT>), grid, block, lds, s, ev_start, ev_stop, 0, p, n_steps, \
+                          auto_reset, pol, tile0, io)
     switch (p.Z) {
     case 5: ZENV_LAUNCH(5); break;
     case 6: ZENV_LAUNCH(6); break;
@@ -2781,10 +2862,27 @@ hipError_t launch_rollout(const DevParams &p, int n_steps, int auto_reset, const
     if (!rollout_kernel_available(p)) return hipErrorInvalidValue;
     if (n_tiles < 0) n_tiles = n_blocks(p.N) - tile0;
     if (tile0 < 0 || n_tiles < 1 || tile0 + n_tiles > n_blocks(p.N)) return hipErrorInvalidValue;
+    const ChunkIO none{ nullptr, nullptr, nullptr };
     switch (p.task) {
-    case ZENV_TASK_TSP: launch_rollout_task<ZENV_TASK_TSP>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop, tile0, n_tiles); break;
-    case ZENV_TASK_TIMED_TSP: launch_rollout_task<ZENV_TASK_TIMED_TSP>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop, tile0, n_tiles); break;
-    default: launch_rollout_task<ZENV_TASK_COLOUR_MATCH>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop, tile0, n_tiles); break;
+    case ZENV_TASK_TSP: launch_rollout_task<ZENV_TASK_TSP, false>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop, tile0, n_tiles, none); break;
+    case ZENV_TASK_TIMED_TSP: launch_rollout_task<ZENV_TASK_TIMED_TSP, false>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop, tile0, n_tiles, none); break;
+    default: launch_rollout_task<ZENV_TASK_COLOUR_MATCH, false>(p, n_steps, auto_reset, pol, s, ev_start, ev_stop, tile0, n_tiles, none); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout_actions(const DevParams &p, int n_steps, int reset_mode, const ChunkIO &io, hipStream_t s,
+                                  hipEvent_t ev_start, hipEvent_t ev_stop, int tile0, int n_tiles)
+{
+    if (!rollout_kernel_available(p) || !io.actions || !io.reward || !io.done) return hipErrorInvalidValue;
+    if (n_tiles < 0) n_tiles = n_blocks(p.N) - tile0;
+    if (tile0 < 0 || n_tiles < 1 || tile0 + n_tiles > n_blocks(p.N) || n_steps < 1) return hipErrorInvalidValue;
+    if (reset_mode < 0 || reset_mode > 2) return hipErrorInvalidValue;
+    const StepPolicy pol = no_policy();
+    switch (p.task) {
+    case ZENV_TASK_TSP: launch_rollout_task<ZENV_TASK_TSP, true>(p, n_steps, reset_mode, pol, s, ev_start, ev_stop, tile0, n_tiles, io); break;
+    case ZENV_TASK_TIMED_TSP: launch_rollout_task<ZENV_TASK_TIMED_TSP, true>(p, n_steps, reset_mode, pol, s, ev_start, ev_stop, tile0, n_tiles, io); break;
+    default: launch_rollout_task<ZENV_TASK_COLOUR_MATCH, true>(p, n_steps, reset_mode, pol, s, ev_start, ev_stop, tile0, n_tiles, io); break;
     }
     return hipGetLastError();
 }

@@ -30,6 +30,18 @@ bool rollout_kernel_available(const DevParams &p);
 int rollout_tiles(const DevParams &p);
 hipError_t launch_rollout(const DevParams &p, int n_steps, int auto_reset, const StepPolicy &pol, hipStream_t s,
                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int tile0 = 0, int n_tiles = -1);
+// The action-chunk form of the persistent kernel (zenv_step_many): n_steps steps of caller-supplied actions
+// io.actions [n_steps][N] (device), every step's reward / done recorded time-major in io.reward / io.done.
+// reset_mode: 0 never, 1 every step, 2 only in the launch's last step.
+struct ChunkIO {
+    const float2 *actions;
+    float *reward;
+    uint8_t *done;
+};
+hipError_t launch_rollout_actions(const DevParams &p, int n_steps, int reset_mode, const ChunkIO &io, hipStream_t s,
+                                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int tile0 = 0, int n_tiles = -1);
+// next_slot[env] = seq_slot(slot_first[env], episode_idx[env]) after the host changed the schedule or the bank's size
+hipError_t launch_sched_sync(const DevParams &p, hipStream_t s);
 hipError_t launch_reset(const DevParams &p, const uint8_t *mask, hipStream_t s);
 // goal-conditioned variant: set goals (new_goal[N], -1 = keep; *bad counts rejected ones) / per-step shaping
 hipError_t launch_goal_set(const DevParams &p, const int32_t *new_goal, int32_t *bad, hipStream_t s);

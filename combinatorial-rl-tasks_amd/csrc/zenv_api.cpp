@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -117,6 +118,12 @@ struct zenv {
     int comm_rank = 0, comm_world = 0;
     void *comm_send = nullptr, *comm_recv = nullptr;   // [N] and [world * N] 4-byte elements
     double *comm_scalar = nullptr;                      // device scratch of the barrier / max-reduce
+    // zenv_step_many: the chunk's actions on the device (when they came from the host) and its time-major records
+    void *chunk_mem = nullptr;
+    size_t chunk_cap = 0;           // steps * envs the allocation holds
+    float *chunk_actions = nullptr, *chunk_reward = nullptr;
+    uint8_t *chunk_done = nullptr;
+    int chunk_steps = 0;            // steps of the last zenv_step_many (extent of ZENV_F_CHUNK_*)
 };
 
 namespace {
@@ -268,6 +275,8 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_EXP_RETURN: return { h->exp.returnn, h->exp.obs ? N * h->exp.T * 4 : 0 };
     case ZENV_F_ORDER_VAL: return { p.order_val, p.order_val ? N * p.Z * 4 : 0 };
     case ZENV_F_ORDER_POS: return { p.order_pos, p.order_pos ? N * p.Z : 0 };
+    case ZENV_F_CHUNK_REWARD: return { h->chunk_reward, h->chunk_reward ? N * h->chunk_steps * 4 : 0 };
+    case ZENV_F_CHUNK_DONE: return { h->chunk_done, h->chunk_done ? N * h->chunk_steps : 0 };
     case ZENV_F_EXCEPTION: return { p.exception, N };
     default: return { nullptr, 0 };
     }
@@ -478,7 +487,7 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
     want(h, p.ep_return, N, true); want(h, p.last_return, N, true);
     want(h, p.last_len, N, true); want(h, p.episodes, N, true); want(h, p.visit_count, N, true);
     want(h, p.seed, N, true);
-    want(h, p.slot_first, N, true); want(h, p.episode_idx, N, true);
+    want(h, p.slot_first, N, true); want(h, p.episode_idx, N, true); want(h, p.next_slot, N, true);
     want(h, p.pcg, 4 * N, true); want(h, p.pcg_buf, 2 * N, true);
     want(h, p.actions, 2 * N, true);
     {   // results slab, in ZENV_RESULT_* order
@@ -547,6 +556,7 @@ extern "C" int zenv_destroy(zenv_t *h)
         if (m) (void)hipFree(m);
     if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_self) (void)hipFree(h->d_self);
+    if (h->chunk_mem) (void)hipFree(h->chunk_mem);
     if (h->refill_host) (void)hipHostFree(h->refill_host);
     if (h->mlp_range_flag) (void)hipHostFree(h->mlp_range_flag);
     if (h->refill_dev) (void)hipFree(h->refill_dev);
@@ -593,6 +603,7 @@ static int upload_bank(zenv *h, const std::vector<double> &robot4, const std::ve
     // allocate and fill the new bank first; the handle switches to it only when all of it is on the device (a failure
     // half way leaves the old bank -- and bank_ready -- exactly as they were)
     const size_t S = seeds.size();
+    const int32_t S_old = h->p.bank_size;
     const size_t bytes[5] = { robot4.size() * sizeof(double), zone.size() * sizeof(double), aux.size() * sizeof(int32_t),
                               S * sizeof(int64_t), S * 3 * sizeof(float4) };
     const void *src[5] = { robot4.data(), zone.data(), aux.data(), seeds.data(), nullptr };
@@ -621,6 +632,13 @@ static int upload_bank(zenv *h, const std::vector<double> &robot4, const std::ve
     h->bank_ready = true;
     if (h->p.sched_mode == SCHED_FIXED_SEEDS && h->p.seed_max - h->p.seed_min + 1 != (int64_t)S)
         h->sched_ready = false;  // that schedule draws slots of the bank it was made for: the next reset starts a default one
+    if (h->sched_ready && h->p.sched_mode == SCHED_SEQUENTIAL) {
+        // a sequential schedule carries over to a bank of another size: (first + k stride) mod the NEW size
+        h->p.sched_stride %= (int32_t)S;
+        HIP_TRY(launch_sched_sync(h->p, h->stream));
+    } else if (h->sched_ready && h->p.sched_mode == SCHED_RING && (int32_t)S != S_old) {
+        h->sched_ready = false;  // a ring's slots belong to the bank it was laid out over
+    }
     return ZENV_OK;
 }
 
@@ -812,6 +830,7 @@ extern "C" int zenv_schedule_sequential(zenv_t *h, const int32_t *first, int32_t
     HIP_TRY(hipMemsetAsync(h->p.episode_idx, 0, h->n_env * sizeof(int32_t), h->stream));   // on the handle's stream: the null stream does not order with it
     h->p.sched_mode = SCHED_SEQUENTIAL;
     h->p.sched_stride = stride % S;
+    HIP_TRY(launch_sched_sync(h->p, h->stream));      // next_slot = first (episode 0)
     h->sched_ready = true;
     return ZENV_OK;
 }
@@ -832,6 +851,7 @@ extern "C" int zenv_schedule_ring(zenv_t *h, const int32_t *first, int32_t depth
     HIP_TRY(hipMemsetAsync(h->p.episode_idx, 0, h->n_env * sizeof(int32_t), h->stream));   // on the handle's stream: the null stream does not order with it
     h->p.sched_mode = SCHED_RING;
     h->p.sched_stride = depth;
+    HIP_TRY(launch_sched_sync(h->p, h->stream));
     h->sched_ready = true;
     return ZENV_OK;
 }
@@ -859,6 +879,7 @@ extern "C" int zenv_schedule_fixed_seeds(zenv_t *h, const uint64_t *rng_seeds, i
     h->p.sched_mode = SCHED_FIXED_SEEDS;
     h->p.seed_min = min_seed;
     h->p.seed_max = max_seed;
+    HIP_TRY(launch_sched_sync(h->p, h->stream));
     h->sched_ready = true;
     return ZENV_OK;
 }
@@ -1327,6 +1348,100 @@ static int ensure_self(zenv_t *h)
     return ZENV_OK;
 }
 
+// A ring schedule is only as deep as its `depth` slots per env, and only the HOST refills them (zenv_bank_update), between
+// calls: an env ends at most one episode per step, so a call of up to `depth` auto-resetting steps cannot outrun its
+// ring; a longer one could wrap onto maps it has already played -- silently.  Refused instead.
+static int ring_guard(const zenv *h, int steps, int auto_reset_every_step)
+{
+    if (h->p.sched_mode == SCHED_RING && auto_reset_every_step && steps > h->p.sched_stride)
+        return fail(ZENV_E_STATE, "a ring schedule of depth %d is refilled by the host between calls: %d auto-resetting "
+                    "steps in one call could replay maps (use calls of at most `depth` steps with zenv_bank_update in "
+                    "between, a deeper ring, or a sequential schedule)", h->p.sched_stride, steps);
+    return ZENV_OK;
+}
+
+// ============================================================================ action chunks
+// K steps of caller-supplied actions.  With the persistent kernel available (lane layout, a compiled zone count, no
+// goal / order post-kernels) a chunk is one launch per ZENV_ROLLOUT_CHUNK steps and slice; otherwise it is the plain
+// sequence of single-step launches -- same results either way (tests/test_gpu_chunk.py).
+static int chunk_reserve(zenv *h, int steps, bool need_action_copy)
+{
+    const size_t N = (size_t)h->n_env, cells = (size_t)steps * N;
+    if (cells > h->chunk_cap) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->chunk_mem) (void)hipFree(h->chunk_mem);
+        h->chunk_mem = nullptr;
+        h->chunk_actions = h->chunk_reward = nullptr;
+        h->chunk_done = nullptr;
+        h->chunk_cap = 0;
+        HIP_TRY(hipMalloc(&h->chunk_mem, cells * (8 + 4 + 1) + 256));
+        h->chunk_actions = static_cast<float *>(h->chunk_mem);                    // [K][N][2] float32
+        h->chunk_reward = h->chunk_actions + 2 * cells;                           // [K][N] float32
+        h->chunk_done = reinterpret_cast<uint8_t *>(h->chunk_reward + cells);     // [K][N] uint8
+        h->chunk_cap = cells;
+    } else {
+        // the records of a shorter chunk sit at the front of the same allocation, re-laid-out for this call's K
+        const size_t cap = h->chunk_cap;
+        h->chunk_reward = h->chunk_actions + 2 * cap;
+        h->chunk_done = reinterpret_cast<uint8_t *>(h->chunk_reward + cap);
+    }
+    (void)need_action_copy;
+    return ZENV_OK;
+}
+
+extern "C" int zenv_step_many(zenv_t *h, const float *actions, int actions_on_device, int n_steps, int reset_mode)
+{
+    if (!h || !actions) return fail(ZENV_E_ARG, "null argument");
+    if (!h->was_reset) return fail(ZENV_E_STATE, "Environment must be reset before stepping");
+    if (n_steps < 1) return fail(ZENV_E_ARG, "n_steps must be >= 1");
+    if (reset_mode != ZENV_CHUNK_NO_RESET && reset_mode != ZENV_CHUNK_RESET_EVERY && reset_mode != ZENV_CHUNK_RESET_LAST)
+        return fail(ZENV_E_ARG, "unknown reset mode %d", reset_mode);
+    if ((int64_t)n_steps * h->n_env > ((int64_t)1 << 31))
+        return fail(ZENV_E_ARG, "%d steps x %d envs: split the chunk (the time-major records are indexed with 32 bits)", n_steps, h->n_env);
+    if (int rr = ring_guard(h, n_steps, reset_mode == ZENV_CHUNK_RESET_EVERY)) return rr;
+    int rc = use_device(h);
+    if (rc) return rc;
+    h->act_tag.valid = false;
+    rc = chunk_reserve(h, n_steps, !actions_on_device);
+    if (rc) return rc;
+    const size_t N = (size_t)h->n_env;
+    const float *d_act = actions;
+    if (!actions_on_device) {
+        HIP_TRY(hipMemcpyAsync(h->chunk_actions, actions, sizeof(float) * 2 * N * (size_t)n_steps, hipMemcpyHostToDevice, h->stream));
+        d_act = h->chunk_actions;
+    }
+    h->chunk_steps = n_steps;
+    const bool persistent = rollout_kernel_available(h->p) && !h->goal_enabled && !h->order_enabled;
+    if (persistent) {
+        rc = ensure_self(h);
+        if (rc) return rc;
+        const int all_tiles = rollout_tiles(h->p);
+        const int slice = h->rollout_slice_tiles > 0 ? std::min(h->rollout_slice_tiles, all_tiles) : all_tiles;
+        for (int t = 0; t < n_steps; t += kRolloutChunk) {
+            const int k = std::min(kRolloutChunk, n_steps - t);
+            const bool last = t + k == n_steps;
+            const int mode = reset_mode == ZENV_CHUNK_RESET_EVERY ? 1 : (reset_mode == ZENV_CHUNK_RESET_LAST && last ? 2 : 0);
+            const ChunkIO io{ reinterpret_cast<const float2 *>(d_act) + (size_t)t * N, h->chunk_reward + (size_t)t * N,
+                              h->chunk_done + (size_t)t * N };
+            for (int tile0 = 0; tile0 < all_tiles; tile0 += slice)
+                HIP_TRY(launch_rollout_actions(h->p, k, mode, io, h->stream, nullptr, nullptr, tile0,
+                                               std::min(slice, all_tiles - tile0)));
+            h->step_count += k;
+        }
+        return ZENV_OK;
+    }
+    for (int t = 0; t < n_steps; ++t) {
+        const int ar = reset_mode == ZENV_CHUNK_RESET_EVERY || (reset_mode == ZENV_CHUNK_RESET_LAST && t == n_steps - 1);
+        HIP_TRY(launch_step(h->p, d_act + 2 * N * (size_t)t, ar, no_policy(), h->stream));
+        if (h->goal_enabled) HIP_TRY(launch_goal_step(h->p, h->stream));
+        if (h->order_enabled) HIP_TRY(launch_order_step(h->p, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->chunk_reward + (size_t)t * N, h->p.reward, N * sizeof(float), hipMemcpyDefault, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->chunk_done + (size_t)t * N, h->p.done_out, N, hipMemcpyDefault, h->stream));
+        h->step_count += 1;
+    }
+    return ZENV_OK;
+}
+
 extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_seed, uint64_t env_index0,
                             int auto_reset, int flags, int event_stride, float *ms_total, float *ms_step_kernel_avg)
 {
@@ -1337,6 +1452,7 @@ extern "C" int zenv_rollout(zenv_t *h, int steps, int policy, uint64_t policy_se
     if (policy_is_mlp(policy) && !h->mlp_ready) return fail(ZENV_E_STATE, "zenv_mlp_load first");
     if (h->goal_enabled || h->order_enabled)
         return fail(ZENV_E_STATE, "goal-conditioned / solver-ordered envs are stepped with zenv_step");
+    if (int rr = ring_guard(h, steps, auto_reset)) return rr;
     int rc = use_device(h);
     if (rc) return rc;
     // the actor network is its own launch sequence: policy, then step, every step
@@ -1616,32 +1732,48 @@ struct RcclApi {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
     std::string path;
+    std::string load_error;   // the loader's message when no copy could be opened
 };
+
+void rccl_load(RcclApi &api);
+RcclApi g_rccl;
 
 RcclApi *rccl_api()
 {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.lib ? &api : nullptr;
-    tried = true;
+    static std::once_flag once;          // two handles may set up communicators from different threads
+    std::call_once(once, [] { rccl_load(g_rccl); });
+    return g_rccl.lib ? &g_rccl : nullptr;
+}
+
+void rccl_load(RcclApi &api)
+{
     const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
     void *lib = nullptr;
     for (const char *n : names)                       // a copy that is already mapped wins (torch's bundled one)
         if (!lib && (lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) api.path = std::string(n) + " (already loaded)";
     if (const char *e = std::getenv("ZENV_RCCL_PATH"))
         if (!lib && (lib = dlopen(e, RTLD_NOW | RTLD_LOCAL))) api.path = e;
-    for (const char *n : names)
-        if (!lib && (lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) api.path = n;
-    if (!lib) return nullptr;
+    for (const char *n : names) {
+        if (lib) break;
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) {
+            api.path = n;
+        } else if (const char *e = dlerror()) {         // dlerror() clears itself: read once, keep the text
+            api.load_error = e;
+        }
+    }
+    if (!lib) return;
 #define ZENV_SYM(name) api.name = reinterpret_cast<decltype(api.name)>(dlsym(lib, "nccl" #name))
     ZENV_SYM(GetUniqueId); ZENV_SYM(CommInitRank); ZENV_SYM(CommDestroy); ZENV_SYM(AllGather); ZENV_SYM(AllReduce);
     ZENV_SYM(GetErrorString); ZENV_SYM(GetVersion);
 #undef ZENV_SYM
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllReduce || !api.GetErrorString)
-        return nullptr;
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllReduce || !api.GetErrorString) {
+        api.load_error = api.path + " lacks an nccl* entry point this library binds";
+        return;
+    }
     api.lib = lib;
-    return &api;
 }
+
+const char *rccl_load_error() { return g_rccl.load_error.empty() ? "no loader message" : g_rccl.load_error.c_str(); }
 
 #define RCCL_TRY(api, expr)                                                                                   \
     do {                                                                                                      \
@@ -1657,7 +1789,7 @@ extern "C" int zenv_comm_unique_id(void *id_out)
     if (!id_out) return fail(ZENV_E_ARG, "null argument");
     static_assert(sizeof(ncclUniqueId) == ZENV_COMM_ID_BYTES, "ZENV_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
     RcclApi *api = rccl_api();
-    if (!api) return fail(ZENV_E_HIP, "librccl not found (%s)", dlerror() ? dlerror() : "no loader message");
+    if (!api) return fail(ZENV_E_HIP, "librccl not found (%s)", rccl_load_error());
     ncclUniqueId id;
     RCCL_TRY(api, api->GetUniqueId(&id));
     std::memcpy(id_out, &id, sizeof(id));
@@ -1670,7 +1802,7 @@ extern "C" int zenv_comm_init(zenv_t *h, int rank, int world, const void *unique
     if (world < 1 || rank < 0 || rank >= world) return fail(ZENV_E_ARG, "rank %d outside [0,%d)", rank, world);
     if (h->comm) return fail(ZENV_E_STATE, "the handle already has a communicator");
     RcclApi *api = rccl_api();
-    if (!api) return fail(ZENV_E_HIP, "librccl not found");
+    if (!api) return fail(ZENV_E_HIP, "librccl not found (%s)", rccl_load_error());
     int rc = use_device(h);
     if (rc) return rc;
     ncclUniqueId id;
@@ -1679,9 +1811,13 @@ extern "C" int zenv_comm_init(zenv_t *h, int rank, int world, const void *unique
     h->comm_rank = rank;
     h->comm_world = world;
     const size_t N = (size_t)h->n_env;
-    HIP_TRY(hipMalloc(&h->comm_send, N * 4));
-    HIP_TRY(hipMalloc(&h->comm_recv, N * 4 * (size_t)world));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->comm_scalar), 2 * sizeof(double)));
+    hipError_t err = hipMalloc(&h->comm_send, N * 4);
+    if (err == hipSuccess) err = hipMalloc(&h->comm_recv, N * 4 * (size_t)world);
+    if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void **>(&h->comm_scalar), 2 * sizeof(double));
+    if (err != hipSuccess) {
+        (void)zenv_comm_destroy(h);      // no half-built communicator: the next allgather would launch on null buffers
+        return fail(ZENV_E_HIP, "zenv_comm_init: hipMalloc: %s", hipGetErrorString(err));
+    }
     return ZENV_OK;
 }
 
@@ -1718,14 +1854,21 @@ extern "C" int zenv_allgather(zenv_t *h, int field, void *dst, int dst_on_device
 {
     if (!h || !dst) return fail(ZENV_E_ARG, "null argument");
     if (!h->comm) return fail(ZENV_E_STATE, "zenv_comm_init first");
+    // the documented per-env figures only: float64 narrowed to float32, float32 and int32 as they are (a float2 action
+    // or an int64 seed is N * 8 bytes too, and would be gathered as garbage)
+    const bool as_f64 = field == ZENV_F_LAST_RETURN || field == ZENV_F_EP_RETURN;
+    const bool as_f32 = field == ZENV_F_REWARD;
+    const bool as_i32 = field == ZENV_F_EPISODES || field == ZENV_F_LAST_LEN || field == ZENV_F_VISIT_COUNT || field == ZENV_F_EP_LEN;
+    if (!as_f64 && !as_f32 && !as_i32)
+        return fail(ZENV_E_ARG, "field %d is not gathered: LAST_RETURN, EP_RETURN, REWARD, EPISODES, LAST_LEN, VISIT_COUNT, EP_LEN are", field);
     const FieldInfo f = field_info(h, field);
     const int64_t N = h->n_env;
-    if (!f.ptr || (f.bytes != N * 4 && f.bytes != N * 8))
-        return fail(ZENV_E_ARG, "field %d is not one 4- or 8-byte figure per env", field);
+    if (!f.ptr || f.bytes != N * (as_f64 ? 8 : 4)) return fail(ZENV_E_ARG, "field %d has an unexpected extent", field);
+    if (!h->comm_send || !h->comm_recv) return fail(ZENV_E_STATE, "the communicator has no buffers (zenv_comm_init failed)");
     RcclApi *api = rccl_api();
     int rc = use_device(h);
     if (rc) return rc;
-    const bool is_f32 = f.bytes == N * 8 || field == ZENV_F_REWARD;
+    const bool is_f32 = as_f64 || as_f32;
     HIP_TRY(launch_gather_prep(f.ptr, (int)(f.bytes / N), h->comm_send, h->n_env, h->stream));
     RCCL_TRY(api, api->AllGather(h->comm_send, h->comm_recv, (size_t)N, is_f32 ? ncclFloat32 : ncclInt32, h->comm, h->stream));
     HIP_TRY(hipMemcpyAsync(dst, h->comm_recv, (size_t)N * 4 * (size_t)h->comm_world,

@@ -115,6 +115,46 @@ class ParallelEnv:
     def step_no_reset(self, actions):
         return self._step(actions, False)
 
+    def step_chunk(self, actions, reset="last"):
+        """K steps of pre-computed actions (K, P, 2) in ONE persistent launch (ZoneVecEnv.step_many).  reset="last" is the
+        fixed-length-skill loop of _hier_policy_opt.py:68-71 -- K - 1 x step_no_reset, then one step; "never" / "every" are
+        K x step_no_reset / K x step.  Returns (obs, rewards (K,P) float64, dones (K,P) bool, infos): obs and infos are
+        what the chunk's LAST call returned, rewards / dones every call's."""
+        a = np.asarray(actions, np.float32)
+        K = a.shape[0]
+        a = a.reshape(K, self.num_envs, 2)
+        if self._goals or self._order:
+            raise NotImplementedError("goal-conditioned / solver-ordered envs report per-step info: use step()")
+        if reset == "every" and self._plain_depth is not None and K > self._plain_depth:
+            raise ValueError(f"a ring of {self._plain_depth} maps per env allows {self._plain_depth} auto-resetting steps per "
+                             "chunk (episodes_per_env); use reset='last' or a deeper ring")
+        was_finished = getattr(self, "_finished", None)
+        self._vec.step_many(a, reset=reset)
+        rew, done = self._vec.chunk_results()
+        o, zo, r, d, g, exc = self._vec.step_results(None, copy=False)
+        o = o.astype(np.float64)
+        zo = zo.astype(np.float64)
+        if self._plain_depth is not None and reset != "never":
+            # maps taken from the rings: one per done flag of an auto-resetting call (every call / the last one)
+            taken = done.sum(0) if reset == "every" else done[-1].astype(np.int64)
+            for _ in range(int(taken.max()) if taken.size else 0):
+                idx = np.flatnonzero(taken > 0)
+                self._refill(idx)
+                taken[idx] -= 1
+        infos = [{"cost": 0} for _ in range(self.num_envs)]
+        finished_before_last = done[:-1].any(0) if K > 1 and reset != "every" else np.zeros(self.num_envs, bool)
+        if was_finished is not None:
+            finished_before_last |= was_finished
+        for i in np.flatnonzero(finished_before_last):
+            infos[i] = {}                                     # WaitWrapper no-op: info = {}
+        for i in np.flatnonzero(g):
+            infos[i]["goal_met"] = True
+        for i in np.flatnonzero(exc & d & ~finished_before_last):
+            infos[i] = {"exception": True}
+        self._finished = None if reset != "never" else (done.any(0) if was_finished is None else (was_finished | done.any(0)))
+        obs = tuple({"zone_obs": z, "obs": x} for z, x in zip(zo, o))
+        return obs, rew.astype(np.float64), done, tuple(infos)
+
     def render(self):
         raise NotImplementedError
 

@@ -250,6 +250,33 @@ class ZoneVecEnv:
             raise ValueError(f"actions must have shape ({self.num_envs}, 2)")
         check(lib().zenv_step(self._h, a.ctypes.data, 0, int(bool(auto_reset))))
 
+    _RESET_MODES = {"never": nat.CHUNK_NO_RESET, "every": nat.CHUNK_RESET_EVERY, "last": nat.CHUNK_RESET_LAST}
+
+    def step_many(self, actions, reset="every", actions_ptr=None):
+        """An action chunk (zenv_step_many): K steps of caller-supplied actions, one launch of the persistent kernel per
+        256 steps.  actions: (K, N, 2) float32 (host), or actions_ptr = (device address, K) for a device buffer.
+        reset: "every" (K x step), "never" (K x step_no_reset) or "last" (K - 1 x step_no_reset, then one step: the
+        fixed-length-skill loop, _hier_policy_opt.py:68-71).  Asynchronous like step(); afterwards observations() /
+        results() hold the last step, chunk_results() every step's reward and done flag."""
+        mode = self._RESET_MODES[reset]
+        if actions_ptr is not None:
+            ptr, k = actions_ptr
+            check(lib().zenv_step_many(self._h, C.c_void_p(int(ptr)), 1, int(k), mode))
+            return
+        a = np.ascontiguousarray(actions, np.float32)
+        if a.ndim != 3 or a.shape[1:] != (self.num_envs, 2) or a.shape[0] < 1:
+            raise ValueError(f"actions must have shape (K, {self.num_envs}, 2)")
+        check(lib().zenv_step_many(self._h, a.ctypes.data, 0, int(a.shape[0]), mode))
+
+    def chunk_results(self):
+        """(reward float32 (K,N), done bool (K,N)) of the last step_many(), time-major."""
+        k = lib().zenv_field_bytes(self._h, nat.F_CHUNK_DONE) // self.num_envs
+        r = np.empty((k, self.num_envs), np.float32)
+        d = np.empty((k, self.num_envs), np.uint8)
+        check(lib().zenv_get(self._h, nat.F_CHUNK_REWARD, r.ctypes.data, 0))
+        check(lib().zenv_get(self._h, nat.F_CHUNK_DONE, d.ctypes.data, 0))
+        return r, d.astype(bool)
+
     def step_device(self, actions_ptr, auto_reset=True):
         """actions_ptr: integer device address of a float32 [N,2] buffer (zero-copy policies)."""
         check(lib().zenv_step(self._h, C.c_void_p(int(actions_ptr)), 1, int(bool(auto_reset))))

@@ -86,7 +86,10 @@ enum {
                                   *                    Engine.step's MujocoException path (valid once done; see zenv_step) */
     ZENV_F_ORDER_POS = 32,       /* int8    [N,Z]    TSPOrderEnv's self.route: position of every zone in the remaining route, -1 =
                                   *                    not in it (visited) */
-    ZENV_F_COUNT = 33
+    /* time-major records of the last zenv_step_many(): every step of the chunk */
+    ZENV_F_CHUNK_REWARD = 33,    /* float32 [K,N] */
+    ZENV_F_CHUNK_DONE = 34,      /* uint8   [K,N] */
+    ZENV_F_COUNT = 35
 };
 
 /* scripted on-device action sources (the build's own; used by bench/tests) */
@@ -223,6 +226,21 @@ int zenv_reset(zenv_t *h, const uint8_t *mask);
  * (np.clip keeps a NaN): that step ends the episode with reward_exception, no goal test, joint state zeroed,
  * ZENV_F_EXCEPTION = 1.  The zone visit of that step's first set_mocaps() still counts (it ran before sim.step()). */
 int zenv_step(zenv_t *h, const float *actions, int actions_on_device, int auto_reset);
+/* An action chunk: n_steps steps of caller-supplied actions [n_steps][N][2] (host, or device memory of the handle's
+ * device) -- the same results as n_steps zenv_step() calls, as ONE launch of the persistent kernel per
+ * ZENV_ROLLOUT_CHUNK steps (env state in registers, a_{t+1} prefetched under step t; zone counts 5, 6, 10, 15, 20, 25 in
+ * the lane layout -- other handles run the single-step launches).  Asynchronous on the handle's stream like zenv_step.
+ *   ZENV_CHUNK_NO_RESET     n_steps x step_no_reset: a finished env idles as WaitWrapper's no-op (wrappers.py:34-45)
+ *   ZENV_CHUNK_RESET_EVERY  n_steps x step (penv.py:52-59)
+ *   ZENV_CHUNK_RESET_LAST   n_steps - 1 x step_no_reset, then one step: the fixed-length-skill loop of
+ *                           main/src/torch_ac/algos/_hier_policy_opt.py:68-71 / hier_base.py:179-183 -- an env that
+ *                           finishes inside the chunk waits (zero obs, reward 0, done) and comes back at the boundary
+ * A NaN action takes Engine.step's exception branch as in zenv_step.  Afterwards obs / zone_obs / reward / done /
+ * goal_met hold the LAST step's results; every step's reward and done flag is in ZENV_F_CHUNK_REWARD / _DONE
+ * ([n_steps][N], valid until the next zenv_step_many).  On a ring schedule RESET_EVERY is limited to `depth` steps
+ * per call (ZENV_E_STATE beyond: the host refills the ring between calls). */
+enum { ZENV_CHUNK_NO_RESET = 0, ZENV_CHUNK_RESET_EVERY = 1, ZENV_CHUNK_RESET_LAST = 2 };
+int zenv_step_many(zenv_t *h, const float *actions, int actions_on_device, int n_steps, int reset_mode);
 /* Scripted action source -> internal action buffer (or dst_device if non-NULL). */
 int zenv_policy(zenv_t *h, int policy, uint64_t policy_seed, uint64_t env_index0,
                 float *dst_device);
