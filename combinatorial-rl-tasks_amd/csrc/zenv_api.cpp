@@ -1409,6 +1409,10 @@ extern "C" int zenv_step_many(zenv_t *h, const float *actions, int actions_on_de
     if (!actions_on_device) {
         HIP_TRY(hipMemcpyAsync(h->chunk_actions, actions, sizeof(float) * 2 * N * (size_t)n_steps, hipMemcpyHostToDevice, h->stream));
         d_act = h->chunk_actions;
+        // like n_steps zenv_step() calls with host actions, the handle's action buffer ends up holding the last step's
+        if (!h->host_io_actions)
+            HIP_TRY(hipMemcpyAsync(h->p.actions, h->chunk_actions + 2 * N * (size_t)(n_steps - 1), sizeof(float) * 2 * N,
+                                   hipMemcpyDeviceToDevice, h->stream));
     }
     h->chunk_steps = n_steps;
     const bool persistent = rollout_kernel_available(h->p) && !h->goal_enabled && !h->order_enabled;
