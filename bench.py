@@ -66,8 +66,8 @@ BEYOND_LLC_BANK = 262144                        # maps of the sweep: env i repla
 
 # Environment variables that change WHAT is measured (a diagnostic variant of the library, another launch shape,
 # another kernel): recorded in aux.env_overrides; the run is refused unless --experiment / --override is given.
-# (ZENV_BENCH_*, ZENV_CPU_THREADS, ZENV_RDZV_DIR, ZENV_RCCL_PATH, ZENV_FUZZ_CASES steer the harness, not the kernels.)
-HARNESS_ENV = ("ZENV_BENCH_", "ZENV_CPU_THREADS", "ZENV_RDZV_DIR", "ZENV_RCCL_PATH", "ZENV_FUZZ_CASES")
+# (ZENV_BENCH_*, ZENV_CPU_THREADS, ZENV_RDZV_*, ZENV_RCCL_PATH, ZENV_FUZZ_CASES steer the harness, not the kernels.)
+HARNESS_ENV = ("ZENV_BENCH_", "ZENV_CPU_THREADS", "ZENV_RDZV_", "ZENV_RCCL_PATH", "ZENV_FUZZ_CASES")
 KERNEL_SOURCES = ("kernels.hip", "kernels.hpp", "dev_params.hpp", "det_math.hpp")   # what the PMC record depends on
 
 
@@ -228,6 +228,9 @@ def main():
                     help="persistent mode: begin/end events on every dispatch of the TIMED region (hipExtLaunchKernel; "
                          "costs ~17 us of wall per call -- scripts/launch_overhead.py) instead of the two events recorded "
                          "on the stream right before and after its launches; the steady-state side run always has them")
+    ap.add_argument("--print-rank-env", action="store_true",
+                    help="diagnostic: print this rank's launch environment (RANK, WORLD_SIZE, rendezvous directory ...) as "
+                         "one JSON line and exit -- what tests/test_bench_contract.py checks the self-spawn path with")
     args = ap.parse_args()
     if args.unfused:
         args.mode = "unfused"
@@ -241,9 +244,21 @@ def main():
     # a file lock and is a no-op when lib/ is newer than csrc/ and was built with the same flags.
     import __graft_entry__ as entry
     entry.build()
+    if args.print_rank_env and (world > 1 or args.gpus == 1):
+        from combinatorial_rl_tasks_amd.sharding import FileRendezvous
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "ppid": os.getppid(),
+                          "master": [os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")],
+                          "rdzv_dir": FileRendezvous.default_directory(),
+                          "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
+        return None
     if world != args.gpus:
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # a bare `python bench.py --gpus N`: be the launcher -- N fresh rank processes (never a re-exec: this
+            # process has not touched the GPU and does not from here on), one rendezvous directory, one nonce
+            raise SystemExit(spawn_ranks(args.gpus))
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+            raise SystemExit("bench.py: RANK is set but WORLD_SIZE is 1: launch with `python bench.py --gpus N` (it starts "
+                             "its own ranks) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
         args.gpus = world
 
     import combinatorial_rl_tasks_amd as Z
@@ -262,6 +277,10 @@ def main():
     n_dev = native.lib().zenv_device_count()
     if rehearsal and n_dev > 0:
         local_rank = local_rank % n_dev
+    elif distributed and local_rank >= n_dev:
+        raise SystemExit(f"bench.py: rank {rank} (local rank {local_rank}) has no device: {n_dev} HIP device(s) visible, "
+                         f"{world} rank(s) asked for -- one process per GPU.  (ZENV_BENCH_REHEARSAL=host rehearses the "
+                         "launch line on fewer GPUs than ranks, ranks sharing the cards.)")
 
     task, zones, keepout = WORKLOADS[args.workload]
     n_env = args.envs_per_gpu
@@ -339,6 +358,7 @@ def main():
                           for b in rdzv.all_gather("elapsed", np.float64(elapsed).tobytes()))
         else:
             elapsed = env.comm_max(elapsed)
+    rccl_ranks = int(getattr(env, "comm_world", 0)) if distributed and not rehearsal else 0
     collective = ("none (single process)" if not distributed else
                   "host rendezvous (rehearsal: ranks share a GPU)" if rehearsal else
                   f"rccl ncclAllGather (native), {env.comm_library}")
@@ -389,6 +409,8 @@ def main():
             steady_state(env, task, zones, policy, shard.env_index0, args.mode, pmc, lib_chunk, slice_envs=slice_envs)
         per_step = per_step_rate(env, task, zones, policy, shard.env_index0, args.workload) \
             if (args.mode == "persistent" and side and not args.no_per_step) else None
+        chunked = action_chunk_rate(env, task, zones, lib_chunk) \
+            if (args.mode == "persistent" and side and not args.no_per_step) else None
         mlp = None if (args.no_mlp or not side) else mlp_policy_rate(env, zones)
         host_rt = None if (args.no_mlp or not side) else host_roundtrip_rate(env)
         sweep = side and not args.no_sweep and args.workload == "PointTSP-25" and n_env == 65536 and \
@@ -437,7 +459,7 @@ def main():
                        "parallelism": f"env-shard x{world}, all-gather(ep_return) after rollout"},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "aux": {"collective": collective, "host_side": "python + ctypes over the C ABI (no PyTorch imported)"
+            "aux": {"collective": collective, "rccl_ranks": rccl_ranks, "host_side": "python + ctypes over the C ABI (no PyTorch imported)"
                     if sys.modules.get("torch") is None else "python + ctypes over the C ABI (torch present in the process)",
                     "env_overrides": exp, "traffic_stale": traffic_is_stale(),
                     "settle_steps_untimed": args.settle, "hip_event_ms_total": round(ms_total, 3),
@@ -445,6 +467,7 @@ def main():
                     "mean_last_return_all_ranks": float(np.mean(returns[returns != 0]))
                     if (returns != 0).any() else 0.0,
                     "parity_spot_check": spot, "steady_state": steady, "per_step_launch_mode": per_step,
+                    "action_chunk": chunked,
                     "workloads": workloads, "beyond_llc": beyond,
                     "mlp_policy": mlp, "host_policy_roundtrip_pcie_inclusive": host_rt},
         }
@@ -454,6 +477,49 @@ def main():
     if distributed:
         rdzv.close()
     return out
+
+
+def spawn_ranks(n, timeout=None):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this same command line -- fresh
+    children (subprocess: fork + exec from a process that never initialised the GPU), RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment as torch.distributed.run would set them, ONE rendezvous directory and attempt nonce for
+    the RCCL unique id.  Returns the exit code: 0 when every rank exited 0; when one fails the others are ended (they
+    would wait for it in ncclCommInitRank or at the rendezvous)."""
+    import secrets
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    rdzv_root = tempfile.mkdtemp(prefix="zenv_bench_")
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                ZENV_RDZV_DIR=rdzv_root, ZENV_RDZV_NONCE=secrets.token_hex(8), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    try:
+        for r in range(n):
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                          env=dict(base, RANK=str(r), LOCAL_RANK=str(r))))
+        t0, rc = time.monotonic(), 0
+        while any(p.poll() is None for p in procs):
+            bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+            if bad or (timeout and time.monotonic() - t0 > timeout):
+                rc = bad[0] if bad else 124
+                break
+            time.sleep(0.05)
+        rc = rc or next((p.returncode for p in procs if p.returncode), 0)
+        return rc
+    finally:
+        for p in procs:                      # exactly the processes started here
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+        import shutil
+        shutil.rmtree(rdzv_root, ignore_errors=True)
 
 
 def replay_bank(env, n_env, maps, env_index0=0):
@@ -604,6 +670,51 @@ def cpu_baseline(cfg, task, zones, keepout, policy):
                       f"{dt:.2f}s wall",
             "one_core_value": round(r1["total_steps"] / dt1, 1),
             "one_core_sample": f"1024 envs x 1000 steps on 1 thread, {dt1:.2f}s wall"}
+
+
+def action_chunk_rate(env, task, zones, lib_chunk, reps=24, skill_len=10):
+    """Side measurement (never `value`): the same envs driven by EXTERNALLY supplied actions in chunks (zenv_step_many:
+    k_rollout_lane's action-buffer form) -- what a consumer with pre-computed or open-loop action sequences gets instead
+    of one k_step_lane launch per step.  The [K][N][2] action buffer is resident in HBM before the timed region (uploaded
+    once, replayed through its device pointer); actions: full throttle with uniform steering.  Timed: `reps` back-to-back
+    chunks between two stream synchronisations (host wall clock: a chunk is >= 1 ms of GPU time).  Algorithmic bytes per
+    env-step = the persistent kernel's (outputs of every step, state once per launch) + the action read (8) + the
+    time-major reward / done records (5).  Also the fixed-length-skill shape: chunks of `skill_len` steps that reset at
+    the boundary (_hier_policy_opt.py:68-71), where the launch is amortised over 10 steps only."""
+    try:
+        from combinatorial_rl_tasks_amd import _native as nat
+        n = env.num_envs
+        rs = np.random.RandomState(11)
+        out = {}
+        for name, K, reset, r in (("full_launch", lib_chunk, "every", reps), ("skill_len_10", skill_len, "last", 40 * reps)):
+            a = np.empty((K, n, 2), np.float32)
+            a[..., 0] = 1.0
+            a[..., 1] = rs.uniform(-1, 1, (K, n))
+            env.step_many(a, reset=reset)                          # uploads the buffer (untimed) and warms the kernel
+            ptr = (env.device_ptr(nat.F_CHUNK_ACTIONS), K)
+            for _ in range(3):
+                env.step_many(None, reset=reset, actions_ptr=ptr)
+            env.sync()
+            t0 = time.perf_counter()
+            for _ in range(r):
+                env.step_many(None, reset=reset, actions_ptr=ptr)
+            env.sync()
+            dt = time.perf_counter() - t0
+            steps = r * K
+            k_step_s = dt / steps
+            alg = algorithmic_bytes(task, zones, K) + 8 + 5
+            ach = alg * n / k_step_s / 1e9
+            out[name] = {"kernel": "k_rollout_lane<EXT>", "steps_per_launch": K, "reset": reset, "chunks_timed": r,
+                         "us_per_step": round(k_step_s * 1e6, 3), "env_steps_per_s": round(n * steps / dt, 1),
+                         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                      "algorithmic_bytes_per_env_step": round(alg, 1),
+                                      "llc_resident": bool(output_bytes_per_step(task, zones, n) <= LLC_BYTES)},
+                         "timing": "host wall clock between two stream synchronisations around the back-to-back chunks"}
+        out["episodes_finished"] = int(env.get(nat.F_EPISODES).sum())
+        return out
+    except Exception as ex:  # the bench line must still print
+        return f"error: {ex}"
 
 
 def per_step_rate(env, task, zones, policy, env_index0, workload, steps=2000, warm=2000):

@@ -33,7 +33,7 @@ E_ARG, E_HIP, E_STATE, E_LAYOUT, E_DONE, E_RANGE = -1, -2, -3, -4, -5, -6
  F_SHAPED_REWARD, F_NEED_GOAL, F_AVAILABLE_GOALS, F_GOAL,
  F_EXP_OBS, F_EXP_ZONE_OBS, F_EXP_ACTION, F_EXP_LOG_PROB, F_EXP_VALUE, F_EXP_REWARD, F_EXP_MASK,
  F_EXP_ADVANTAGE, F_EXP_RETURN, F_ORDER_VAL, F_EXCEPTION, F_POLICY_VALUE_SIGMA, F_ORDER_POS,
- F_CHUNK_REWARD, F_CHUNK_DONE) = range(35)
+ F_CHUNK_REWARD, F_CHUNK_DONE, F_CHUNK_ACTIONS) = range(36)
 (RESULT_OBS, RESULT_REWARD, RESULT_DONE, RESULT_GOAL_MET, RESULT_EXCEPTION, RESULT_ZONE_OBS) = range(6)
 N_RESULTS = 6
 

@@ -277,6 +277,7 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_ORDER_POS: return { p.order_pos, p.order_pos ? N * p.Z : 0 };
     case ZENV_F_CHUNK_REWARD: return { h->chunk_reward, h->chunk_reward ? N * h->chunk_steps * 4 : 0 };
     case ZENV_F_CHUNK_DONE: return { h->chunk_done, h->chunk_done ? N * h->chunk_steps : 0 };
+    case ZENV_F_CHUNK_ACTIONS: return { h->chunk_actions, h->chunk_actions ? N * h->chunk_steps * 8 : 0 };
     case ZENV_F_EXCEPTION: return { p.exception, N };
     default: return { nullptr, 0 };
     }
@@ -297,7 +298,7 @@ extern "C" const char *zenv_build_flags(void) { return ZENV_BUILD_FLAGS; }
 
 extern "C" const char *zenv_version(void)
 {
-    static const std::string v = std::string("zenv-hip 0.3 (gfx950)") +
+    static const std::string v = std::string("zenv-hip 0.4 (gfx950)") +
                                  (ZENV_BUILD_FLAGS[0] ? std::string(" [variant: ") + ZENV_BUILD_FLAGS + "]" : std::string());
     return v.c_str();
 }

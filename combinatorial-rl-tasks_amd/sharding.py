@@ -24,16 +24,38 @@ class FileRendezvous:
     """Rank-0-to-all broadcast, all-gather and barrier of small host byte strings through files of one directory.
 
     Not a data path: it moves the 128-byte RCCL unique id (and, in rehearsals without RCCL, the gathered returns).
-    Every exchange has a name; a name is used once per job."""
+    Every exchange has a name; a name is used once per job.  File `<name>.<r>` is written by rank r only.
+
+    One directory per ATTEMPT of a launch: the launcher agent's pid + start time + MASTER_PORT name the launch, a nonce
+    names the attempt (ZENV_RDZV_NONCE from a launcher that sets one -- bench.py's own spawner does --, else
+    TORCHELASTIC_RUN_ID / TORCHELASTIC_RESTART_COUNT, which torchrun changes when it restarts its workers): a rank of a
+    restarted job never reads the RCCL unique id a crashed attempt left behind.  On open every rank also removes the
+    files it owns itself from whatever the directory held."""
 
     def __init__(self, rank, world, directory=None, timeout=300.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         self.dir = directory or self.default_directory()
         os.makedirs(self.dir, exist_ok=True)
+        suffix = f".{self.rank}"
+        for f in os.listdir(self.dir):                      # leftovers of an earlier user of this directory
+            if f.endswith(suffix) or f.endswith(suffix + ".tmp"):
+                try:
+                    os.remove(os.path.join(self.dir, f))
+                except OSError:
+                    pass
+
+    @staticmethod
+    def attempt_nonce():
+        e = os.environ
+        if e.get("ZENV_RDZV_NONCE"):
+            return e["ZENV_RDZV_NONCE"]
+        parts = [e.get("TORCHELASTIC_RUN_ID", ""), e.get("TORCHELASTIC_RESTART_COUNT", "")]
+        return "-".join("".join(c if c.isalnum() else "_" for c in p) for p in parts if p)
 
     @staticmethod
     def default_directory():
-        """One directory per launch: the launcher agent (the parent of every rank) named by pid and start time."""
+        """The launch: the launcher agent (the parent of every rank) by pid and start time, + the port; the attempt: a
+        nonce (see the class docstring)."""
         ppid = os.getppid()
         start = "0"
         try:
@@ -42,7 +64,9 @@ class FileRendezvous:
         except (OSError, IndexError):
             pass
         port = os.environ.get("MASTER_PORT", "0")
-        return os.path.join(os.environ.get("ZENV_RDZV_DIR", "/tmp"), f"zenv_rdzv_{ppid}_{start}_{port}")
+        nonce = FileRendezvous.attempt_nonce()
+        return os.path.join(os.environ.get("ZENV_RDZV_DIR", "/tmp"),
+                            f"zenv_rdzv_{ppid}_{start}_{port}" + (f"_{nonce}" if nonce else ""))
 
     def _path(self, name, rank):
         return os.path.join(self.dir, f"{name}.{rank}")
@@ -55,12 +79,16 @@ class FileRendezvous:
 
     def _get(self, name, rank):
         path, t0 = self._path(name, rank), time.monotonic()
-        while not os.path.exists(path):
+        while True:
+            try:
+                with open(path, "rb") as f:                 # (no exists()-then-open window)
+                    return f.read()
+            except FileNotFoundError:
+                pass
             if time.monotonic() - t0 > self.timeout:
-                raise TimeoutError(f"rendezvous: rank {rank} never wrote {name!r} in {self.dir}")
+                raise TimeoutError(f"rendezvous: rank {rank} never wrote {name!r} in {self.dir} "
+                                   f"(waited {self.timeout:.0f} s; is every rank of the job running?)")
             time.sleep(0.002)
-        with open(path, "rb") as f:
-            return f.read()
 
     def broadcast(self, name, data=None):
         """rank 0 passes `data` (bytes); every rank returns it."""
@@ -76,20 +104,27 @@ class FileRendezvous:
     def barrier(self, name):
         self.all_gather(name, b"1")
 
-    def close(self, name="close"):
-        """Everybody is done with the directory; rank 0 removes it."""
+    def close(self, name="close", linger=10.0):
+        """Everybody is done with the directory; rank 0 removes it -- once every other rank has said that it has read
+        all it is going to read (a `left` marker behind its own barrier), or after `linger` seconds: a rank that is
+        still polling never finds its files gone, and a rank that died cannot keep rank 0 here."""
         self.barrier(name)
-        if self.rank == 0:
-            time.sleep(0.05)                                # let the pollers see the last files
-            for f in os.listdir(self.dir):
-                try:
-                    os.remove(os.path.join(self.dir, f))
-                except OSError:
-                    pass
+        if self.rank != 0:
+            self._put(name + "_left", b"1")
+            return
+        t0 = time.monotonic()
+        for r in range(1, self.world):
+            while not os.path.exists(self._path(name + "_left", r)) and time.monotonic() - t0 < linger:
+                time.sleep(0.002)
+        for f in os.listdir(self.dir):
             try:
-                os.rmdir(self.dir)
+                os.remove(os.path.join(self.dir, f))
             except OSError:
                 pass
+        try:
+            os.rmdir(self.dir)
+        except OSError:
+            pass
 
 
 class EnvShard:
@@ -149,7 +184,10 @@ class EnvShard:
             import torch.distributed as dist
             if dist.is_initialized():
                 import torch
-                return self.all_gather(torch.from_numpy(local)).numpy()
+                t = torch.from_numpy(local)
+                if dist.get_backend() == "nccl":            # RCCL gathers device tensors only
+                    t = t.to(f"cuda:{getattr(env, 'device', 0)}")
+                return self.all_gather(t).cpu().numpy()
         except ImportError:
             pass
         return local

@@ -89,7 +89,9 @@ enum {
     /* time-major records of the last zenv_step_many(): every step of the chunk */
     ZENV_F_CHUNK_REWARD = 33,    /* float32 [K,N] */
     ZENV_F_CHUNK_DONE = 34,      /* uint8   [K,N] */
-    ZENV_F_COUNT = 35
+    ZENV_F_CHUNK_ACTIONS = 35,   /* float32 [K,N,2]  the device copy of the last chunk whose actions came from the host (a caller that
+                                  *                    replays it passes zenv_device_ptr() of this field back, actions_on_device = 1) */
+    ZENV_F_COUNT = 36
 };
 
 /* scripted on-device action sources (the build's own; used by bench/tests) */

@@ -141,3 +141,27 @@ def test_build_stamp_tracks_the_flag_set(monkeypatch, zenv_mod):
     assert B._up_to_date()                                    # the session fixture built the plain library
     monkeypatch.setenv("ZENV_EXTRA_FLAGS", "-DZENV_EXP=1")
     assert B.extra_flags() == "-DZENV_EXP=1" and not B._up_to_date()
+
+
+def test_bare_gpus_n_spawns_its_own_ranks(zenv_mod):
+    """`python bench.py --gpus N` without a launcher starts N fresh rank processes itself -- RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them, ONE rendezvous directory (with an attempt
+    nonce) for all of them -- instead of dying at argument parsing.  (CPU: the ranks only print their launch environment.)"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "ZENV_RDZV_DIR",
+                                                             "ZENV_RDZV_NONCE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--print-rank-env"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ranks = sorted((json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")), key=lambda d: d["rank"])
+    assert [d["rank"] for d in ranks] == [0, 1, 2] == [d["local_rank"] for d in ranks]
+    assert all(d["world"] == 3 and d["ipc_legacy"] == "0" and d["master"][0] == "127.0.0.1" for d in ranks)
+    assert len({d["rdzv_dir"] for d in ranks}) == 1 and len({d["ppid"] for d in ranks}) == 1
+    assert len({tuple(d["master"]) for d in ranks}) == 1
+    assert not os.path.exists(os.path.dirname(ranks[0]["rdzv_dir"]))      # the launcher cleaned up behind its ranks
+    # without devices for its ranks (this container has none) the job ends at once, with a reason, and a non-zero code
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    if zenv_mod._native.lib().zenv_device_count() < 2:
+        assert r.returncode != 0 and "has no device" in r.stderr and "one process per GPU" in r.stderr

@@ -76,6 +76,49 @@ def test_two_rank_launch_line_on_one_gpu(zenv_mod):
     assert two["aux"]["parity_spot_check"] == "bit-identical"
 
 
+def test_two_rank_self_spawn_on_one_gpu(zenv_mod):
+    """The bare command `python bench.py --gpus 2` (no launcher): bench.py starts its two ranks itself (fresh children, one
+    rendezvous directory) -- here on one GPU under ZENV_BENCH_REHEARSAL=host; same figures as one process over all envs."""
+    env = dict(os.environ)
+    env.update({"HSA_ENABLE_IPC_MODE_LEGACY": "0", "ZENV_BENCH_REHEARSAL": "host"})
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "ZENV_RDZV_DIR", "ZENV_RDZV_NONCE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs-per-gpu", "4096", "--steps", "512",
+           "--warmup", "8", "--workload", "ColourMatch-6", "--no-cpu-baseline", "--no-mlp", "--no-steady", "--no-settle", "--no-sweep"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"rc {r.returncode}\nstdout: {r.stdout[-2000:]}\nstderr: {r.stderr[-4000:]}"
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    two = json.loads(lines[0])
+    one = _bench({}, "--envs-per-gpu", "8192")
+    assert two["n_gpus"] == 2 and two["aux"]["rccl_ranks"] == 0 and two["aux"]["collective"].startswith("host rendezvous")
+    assert two["aux"]["mean_last_return_all_ranks"] == one["aux"]["mean_last_return_all_ranks"] != 0.0
+    assert two["aux"]["parity_spot_check"] == "bit-identical"
+    # no rehearsal switch, one GPU, two ranks: refused at once with the reason (RCCL would refuse two ranks per device)
+    env.pop("ZENV_BENCH_REHEARSAL")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    if zenv_mod._native.lib().zenv_device_count() < 2:
+        assert r.returncode != 0 and "has no device" in r.stderr
+
+
+def test_two_rank_native_rccl_when_two_devices_exist(zenv_mod):
+    """ncclCommInitRank with world = 2 through the self-spawn path -- only where the box has two GPUs (the round's test
+    boxes have one: skipped there; the driver's 8-GPU node runs the same code)."""
+    if zenv_mod._native.lib().zenv_device_count() < 2:
+        pytest.skip("needs 2 HIP devices")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "ZENV_RDZV_DIR", "ZENV_RDZV_NONCE", "ZENV_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs-per-gpu", "4096", "--steps", "512",
+           "--warmup", "8", "--workload", "ColourMatch-6", "--no-cpu-baseline", "--no-mlp", "--no-steady", "--no-settle", "--no-sweep"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"rc {r.returncode}\nstdout: {r.stdout[-2000:]}\nstderr: {r.stderr[-4000:]}"
+    two = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    one = _bench({}, "--envs-per-gpu", "8192")
+    assert two["aux"]["rccl_ranks"] == 2 and two["aux"]["collective"].startswith("rccl ncclAllGather (native)")
+    assert two["aux"]["mean_last_return_all_ranks"] == one["aux"]["mean_last_return_all_ranks"] != 0.0
+
+
 def test_native_allgather_through_the_c_abi(zenv_mod):
     """zenv_comm_unique_id / zenv_comm_init / zenv_allgather / zenv_comm_barrier / zenv_comm_allreduce_max in a fresh
     child (a 1-rank communicator): the gathered float32 returns and int32 episode counts are the local ones."""

@@ -99,11 +99,64 @@ def test_file_rendezvous_three_ranks(tmp_path):
     assert not os.path.exists(d)          # rank 0 removed it
 
 
-def test_rendezvous_directory_is_per_launch(monkeypatch):
+def test_rendezvous_directory_is_per_launch_and_per_attempt(monkeypatch):
     from combinatorial_rl_tasks_amd.sharding import FileRendezvous
+    for k in ("ZENV_RDZV_NONCE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"):
+        monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("MASTER_PORT", "29999")
     d = FileRendezvous.default_directory()
     assert str(os.getppid()) in d and d.endswith("_29999")
+    # a restarted attempt of the same launch (torchrun re-spawns its workers under the same agent) gets its own directory
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    d0 = FileRendezvous.default_directory()
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    d1 = FileRendezvous.default_directory()
+    assert d0 != d1 and d0.startswith(d) and d1.endswith("_none-1")
+    monkeypatch.setenv("ZENV_RDZV_NONCE", "abc123")            # a launcher's own nonce wins
+    assert FileRendezvous.default_directory().endswith("_abc123")
+
+
+def test_rendezvous_ignores_its_own_stale_files_and_closes_without_a_race(tmp_path):
+    """(1) a rank removes what an earlier user left under ITS name when it opens the directory, and a read
+    never falls into an exists()/open() window; (2) close(): rank 0 removes the directory only after every other rank
+    has left its marker -- or after `linger` when a rank never shows up."""
+    import threading
+    import time
+    from combinatorial_rl_tasks_amd.sharding import FileRendezvous
+    d = tmp_path / "r"
+    d.mkdir()
+    (d / "rccl_unique_id.0").write_bytes(b"stale")             # a crashed attempt's leftovers
+    (d / "fence1.1").write_bytes(b"1")
+    r0 = FileRendezvous(0, 2, directory=str(d), timeout=5)
+    assert not (d / "rccl_unique_id.0").exists() and (d / "fence1.1").exists()
+    r1 = FileRendezvous(1, 2, directory=str(d), timeout=5)
+    assert not (d / "fence1.1").exists()
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault("uid", r1.broadcast("rccl_unique_id")))
+    t.start()
+    time.sleep(0.05)
+    r0.broadcast("rccl_unique_id", b"fresh")
+    t.join(5)
+    assert got["uid"] == b"fresh"
+    # close: rank 1 is slow to come; rank 0 must still be there (and the files with it) until rank 1 has left
+    order = []
+
+    def slow_rank1():
+        time.sleep(0.3)
+        r1.close()
+        order.append("rank1 left")
+    t = threading.Thread(target=slow_rank1)
+    t.start()
+    r0.close()
+    order.append("rank0 removed")
+    t.join(5)
+    assert order == ["rank1 left", "rank0 removed"] and not d.exists()
+    # a rank that never comes cannot hold rank 0 for longer than the barrier's timeout + linger
+    d2 = tmp_path / "r2"
+    lone = FileRendezvous(0, 2, directory=str(d2), timeout=0.2)
+    with pytest.raises(TimeoutError):
+        lone.close(linger=0.1)
 
 
 def test_single_rank_gather_is_identity():
