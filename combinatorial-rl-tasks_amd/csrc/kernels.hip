@@ -1713,6 +1713,17 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
 #else
     constexpr bool kStreamFirst = TASK == ZENV_TASK_TIMED_TSP ? ZT * F >= 100 : (ZT * F >= 80 && ZT * F < 120);
 #endif
+    // Which wave issues the per-env results of a step (obs, reward, done, goal_met, visit count: six store instructions).
+    // The waves of a CU share one vector-memory pipeline, and under the row stream's saturation an instruction of the
+    // env wave waits at issue behind the stream waves' 1 KiB stores: handed over through LDS and issued by the stream
+    // wave, they cost the env wave nothing.  Same-box A/B of the two forms, us per step: ColourMatch-6 2.69 / 2.65,
+    // PointTSP-15 3.74 / 3.60, PointTSP-25 5.26 / 5.19, TimedTSP-25 6.47 / 6.40 (env wave / stream wave); in the
+    // action-chunk form (EXT), whose env wave would issue ten vector-memory instructions per step, TimedTSP-25 8.6 / 7.5.
+#ifdef ZENV_STREAM_STORES
+    constexpr bool kStreamStores = ZENV_STREAM_STORES != 0;
+#else
+    constexpr bool kStreamStores = true;
+#endif
     const int lane = threadIdx.x & (kWave - 1);
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
     const int env0 = ((int)blockIdx.x + tile0) * kWave;   // tile0: first tile of this launch's slice of the batch
@@ -1727,6 +1738,10 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
     int *ctr = reinterpret_cast<int *>(cdw + (kColour ? 2 * kWave * (ZB / 4) : 0));
     float4 *coltab = reinterpret_cast<float4 *>(ctr + 4);               // ColourMatch: [4] (R, G, B, A) by colour code
     float *cdtab = reinterpret_cast<float *>(coltab + 4);                // ColourMatch: [256] cooldown / max_cd
+    // The env wave's per-env results of a step, handed to the stream wave like the step words (double-buffered): the
+    // 8-float obs as the tile's [128] float4 (its 2 KiB of p.obs, in order) and one float4 (reward, flags, visit count, -)
+    float4 *obs_pub = reinterpret_cast<float4 *>(kColour ? reinterpret_cast<char *>(cdtab + 256) : reinterpret_cast<char *>(ctr + 4));   // [2][128]
+    float4 *misc_pub = obs_pub + 2 * 2 * kWave;                                                                                         // [2][64]
     const RowTables rt{ coltab, cdtab };
     if (kColour) {                                                       // both waves fill, before the launch's barrier
         for (int i = threadIdx.x; i < 256; i += 2 * kWave)
@@ -1750,6 +1765,30 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
             lds_ctr_wait(ctr + 0, t + 1);                 // published(t)
             if (t == (n_steps >> 1)) ZSTAMP(9);
             const int b = t & 1;
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 8)   // diagnostic: bit 3 drops the per-env results of a step
+            if (kStreamStores) {
+                // the env wave's results of step t: obs as two 1 KiB bursts, then reward / done / goal_met / visit count
+                // (and, EXT, the chunk's time-major records)
+                const float4 o0 = obs_pub[b * 2 * kWave + lane], o1 = obs_pub[b * 2 * kWave + kWave + lane];
+                const float4 m = misc_pub[b * kWave + lane];
+                float4 *od = reinterpret_cast<float4 *>(p.obs + (size_t)env0 * 8);
+                if (lane < 2 * n_blk) od[lane] = o0;
+                if (kWave + lane < 2 * n_blk) od[kWave + lane] = o1;
+                if (lane < n_blk) {
+                    const int fl = __float_as_int(m.y);
+                    p.reward[env] = m.x;
+                    p.done_out[env] = (uint8_t)(fl & 1);
+                    p.goal_met[env] = (uint8_t)((fl >> 1) & 1);
+                    p.visit_count[env] = __float_as_int(m.z);
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 16)  // diagnostic: bit 4 drops the time-major reward / done records
+                    if (EXT) {
+                        (io.reward + (size_t)t * (size_t)N)[env] = m.x;
+                        (io.done + (size_t)t * (size_t)N)[env] = (uint8_t)(fl & 1);
+                    }
+#endif
+                }
+            }
+#endif
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 1)   // diagnostic builds only: ZENV_EXP bit 0 drops the flush
             const uint8_t *cdb = reinterpret_cast<const uint8_t *>(cdw + b * kWave * (ZB / 4));
             if (__builtin_amdgcn_readfirstlane(*(lds_vint *)(ctr + 2 + b)))   // some env of the tile is frozen
@@ -1856,20 +1895,29 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
     // the last tile) on harmless zero state -- and only the global stores and the rare events (rim test, episode end,
     // reset, frozen env) sit behind exec masks.
     const bool fs10 = p.frameskip == ZENV_SUBSTEP_UNROLL;
-    const float2 *act_src = EXT ? io.actions + (valid ? env : 0) : nullptr;   // walks down the [n_steps][N] buffer
-    float *rec_rew = EXT ? io.reward + (valid ? env : 0) : nullptr;
-    uint8_t *rec_done = EXT ? io.done + (valid ? env : 0) : nullptr;
+    // (EXT: the chunk's rows are addressed as wave-uniform row pointer + env -- scalar registers and the global
+    // instructions' SADDR form; per-lane 64-bit pointers walking down the buffers cost the 25-zone kernels, which sit at
+    // the 256-register limit, eight more registers and with them scratch spills inside the step loop)
+    const int envl = min(env, N - 1);
     for (int t = 0; t < n_steps; ++t) {
         StepPolicy polt = pol;
         polt.step_index = pol.step_index + (uint32_t)t;
         const bool live = valid && !frozen;
         const bool ar_t = auto_reset == 1 || (auto_reset == 2 && t == n_steps - 1);
+        // EXT: a_{t+1} is requested now and taken at the END of the step -- the env wave's ONLY vector-memory instruction of
+        // a step (everything it produces goes to the stream wave through LDS), so the wait is for this load alone, and it
+        // has the whole step to arrive.  Where the row stream saturates the store path that is still not enough: on
+        // TimedTSP-25 the fetch costs 1.0-1.8 us per step (the same kernel with a_0 held: 6.3 us, with the fetch 7.5-8.3;
+        // PointTSP-25, PointTSP-15, ColourMatch-6: within 5 % of the scripted kernel).  Tried and without effect there:
+        // LDS-DMA with a polled landing pad instead of a counted wait, the load at the stream wave's issue priority, the
+        // env wave first in priority (action chunks)
         float2 act_next = act;
+#if !defined(ZENV_EXP) || !(ZENV_EXP & 32)      // diagnostic: bit 5 drops the action fetch (a_0 is held for the whole launch)
         if (EXT && t + 1 < n_steps) {
-            act_src += N;
-            act_next = *act_src;         // a_{t+1}: in flight underneath this step's zone pass and physics
+            act_next = (io.actions + (size_t)(t + 1) * (size_t)N)[envl];
+            asm volatile("" ::: "memory");      // issued HERE: the scheduler may not sink the load towards its use
         }
-        if (t == (n_steps >> 1)) ZSTAMP(0);
+#endif
         const int k = e.steps + 1;
         double rx, ry;
         world_pos(e, rx, ry);          // set_mocaps() sees the PRE-physics pose
@@ -1978,16 +2026,13 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
                     e.q0 = e.q1 = e.q2 = 0.0;
                     e.v0 = e.v1 = e.v2 = 0.0;
                 }
-                // a_{t+1} has had the whole physics to arrive; take it HERE, before this step's stores are issued
-                asm volatile("" : "+v"(act_next.x), "+v"(act_next.y)::"memory");
-                act = act_next;
             }
             if (t == (n_steps >> 1)) ZSTAMP(2);
             emit_obs8(p, e, o, hs, hc);
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 4)   // diagnostic: bit 2 drops the action source
-            if (pol.policy == ZENV_POLICY_UNIFORM)
+            if (!EXT && pol.policy == ZENV_POLICY_UNIFORM)
                 act = uniform_action(polt.env_index0 + (uint64_t)env, polt.step_index, polt.seed);
-            else if (pol.policy == ZENV_POLICY_GREEDY)
+            else if (!EXT && pol.policy == ZENV_POLICY_GREEDY)
                 act = greedy_action_regs<TASK, ZT>(zp, auxr, e.vis, e.colpack, o[1], o[2], o[3], o[4]);
 #endif
         }
@@ -2005,9 +2050,6 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
             write_back(e, ep_ret);
             frozen = true;
         }
-#if !defined(ZENV_EXP) || !(ZENV_EXP & 8)   // diagnostic: bit 3 drops the env wave's per-step global stores
-        if (valid && !need_reset) store_obs8(p, env, o);
-#endif
 
         // ---- auto-reset (penv.py:8-11), wave-cooperative: lane z <-> zone z of the finished env
         unsigned long long pending = __ballot(need_reset);
@@ -2065,7 +2107,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
                 float of[8];                    // first obs + first greedy action of the episode: derived bank rows
                 const float4 f2 = load_bank_first(pc, slot, of);
                 float2 next_act = make_float2(f2.x, f2.y);
-                if (pol.policy == ZENV_POLICY_UNIFORM)
+                if (!EXT && pol.policy == ZENV_POLICY_UNIFORM)
                     next_act = uniform_action(polt.env_index0 + (uint64_t)env_j, polt.step_index, polt.seed);
                 wave_lds_fence();   // lane j reads back what its neighbours wrote
 #pragma unroll
@@ -2093,7 +2135,8 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
                     if (!EXT) act = next_act;
                     dword = kColour ? colpack : (uint64_t)vis0;   // only the pre-visited zones, step count 0
                     pc.seed[env] = pc.bank_seed[slot];
-                    store_obs8(p, env, of);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = of[i];      // the new episode's first obs is what this step returns
                     if (frozen) {
                         pc.done_state[env] = 0;
                         frozen = false;
@@ -2109,6 +2152,12 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         {
             const int b = t & 1;
             dynw[b * kWave + lane] = dword;
+            if (kStreamStores) {
+                obs_pub[b * 2 * kWave + 2 * lane] = make_float4(o[0], o[1], o[2], o[3]);
+                obs_pub[b * 2 * kWave + 2 * lane + 1] = make_float4(o[4], o[5], o[6], o[7]);
+                misc_pub[b * kWave + lane] = make_float4(rew_out, __int_as_float((int)done_out | ((int)goal_out << 1)),
+                                                         __int_as_float(vcount), 0.f);
+            }
             if (kColour) {
 #pragma unroll
                 for (int w = 0; w < ZB / 4; ++w) {
@@ -2126,20 +2175,17 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         }
         lds_ctr_set(ctr + 0, t + 1);                      // published(t)
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 8)
-        if (valid) {
+        if (!kStreamStores && valid) {
+            store_obs8(p, env, o);
             p.visit_count[env] = vcount;
             p.reward[env] = rew_out;
             p.done_out[env] = done_out;
             p.goal_met[env] = goal_out;
-            if (EXT) {
-                *rec_rew = rew_out;
-                *rec_done = done_out;
-            }
         }
 #endif
         if (EXT) {
-            rec_rew += N;
-            rec_done += N;
+            asm volatile("" : "+v"(act_next.x), "+v"(act_next.y)::"memory");
+            act = act_next;
         }
         if (t == (n_steps >> 1)) ZSTAMP(5);
     }
@@ -2826,8 +2872,9 @@ static inline size_t rollout_lds_bytes(const DevParams &p)
            + 2 * kWave * sizeof(uint64_t)                                          // per-step words
            + (p.task == ZENV_TASK_COLOUR_MATCH ? 2 * (size_t)kWave * ZB : 0)       // cooldown bytes
            + 4 * sizeof(int)                                                       // counters
-           + (p.task == ZENV_TASK_COLOUR_MATCH ? 4 * sizeof(float4) + 256 * sizeof(float) : 0);   // row tables
-}
+           + (p.task == ZENV_TASK_COLOUR_MATCH ? 4 * sizeof(float4) + 256 * sizeof(float) : 0)    // row tables
+           + 2 * (2 * kWave + kWave) * sizeof(float4);                             // published obs + (reward, flags, count)
+}   // (allocated for every kernel; the ones whose env wave issues its own stores leave it unused)
 
 bool rollout_kernel_available(const DevParams &p)
 {
