@@ -836,10 +836,13 @@ def host_roundtrip_rate(env, steps=24):
         return f"error: {ex}"
 
 
-def mlp_policy_rate(env, zones, steps=300):
-    """Side measurement (never `value`): the same envs stepped with the reference's actor network
-    (ZoneEnvModel + PolicyNetwork, h = 185, random weights) as the on-device policy -- two bf16 MFMA
-    kernels + the per-step env kernel per step."""
+def mlp_policy_rate(env, zones, steps=200):
+    """Side measurement (never `value`): the same envs stepped with the reference's actor network (ZoneEnvModel +
+    PolicyNetwork, h = 185, random weights) as the on-device policy: network kernels + the
+    per-step env kernel per step.  The reference's modules are torch float32, so the figure that stands for "the
+    reference's network" is the REFERENCE-GRADE one -- ZENV_MLP_F16X3, mu / std / value within 3e-6 of torch float32
+    (tests/test_gpu_mlp.py), what load_mlp() takes by default -- with the plain float32 mode beside it.  The bf16 / f16
+    kernels compute in narrower arithmetic than the reference (within 4e-2 / 1e-3): reported as reduced precision."""
     try:
         import combinatorial_rl_tasks_amd as Z
         F, h = env.zone_feat, 185
@@ -855,30 +858,38 @@ def mlp_policy_rate(env, zones, steps=300):
             key = {"zone": ("zone_w1", "zone_b1"), "zone2": ("zone_w2", "zone_b2"), "zone3": ("zone_w3", "zone_b3")}.get(
                 name, (name + "_w", name + "_b"))
             t[key[0]], t[key[1]] = w, b
-        env.load_mlp(t)
-        env.rollout(steps, Z.POLICY_MLP_SAMPLE, policy_seed=1)
-        ms, _ = env.rollout(steps, Z.POLICY_MLP_SAMPLE, policy_seed=1)
         n = env.num_envs
         flop = n * (zones * 2 * ((8 + F) * h + h * h) + 2 * (h * h + (8 + h) * h + h * h + 4 * h))
-        us = ms / steps * 1e3
-        # the float32 mode of the same network (ZENV_MLP_F32: the reference's arithmetic, for evaluation)
-        env.load_mlp(t, precision="f32")
-        env.rollout(5, Z.POLICY_MLP_SAMPLE, policy_seed=1)
-        ms32, _ = env.rollout(20, Z.POLICY_MLP_SAMPLE, policy_seed=1)
-        # the float32-grade modes on the 16-bit matrix instruction (hi / lo split operands, three products per k-step):
-        # ZENV_MLP_F16X3 within 3e-6 of torch float32, ZENV_MLP_BF16X3 within 2e-5
-        split = {}
-        # ... and ZENV_MLP_F16: the bf16 kernels compiled for float16 operands (an eighth of bf16's rounding error)
-        for prec, k in (("f16x3", 40), ("bf16x3", 40), ("f16", 200)):
+
+        def rate(prec, k):
             env.load_mlp(t, precision=prec)
-            env.rollout(max(5, k // 4), Z.POLICY_MLP_SAMPLE, policy_seed=1)
-            msx, _ = env.rollout(k, Z.POLICY_MLP_SAMPLE, policy_seed=1)
-            split[prec + "_mode_us_per_step"] = round(msx / k * 1e3, 1)
+            env.rollout(max(8, k // 4), Z.POLICY_MLP_SAMPLE, policy_seed=1)
+            ms, _ = env.rollout(k, Z.POLICY_MLP_SAMPLE, policy_seed=1)
+            return ms / k * 1e3
+        env.load_mlp(t)                                   # the default: reference grade
+        default_mode = env.mlp_precision
+        us_ref = rate("f16x3", steps)
+        us_f32 = rate("f32", 24)
+        us_bf16x3 = rate("bf16x3", 40)
+        us_bf16 = rate("bf16", 300)
+        us_f16 = rate("f16", 200)
         env.load_mlp(t)
-        return {"us_per_step": round(us, 1), "f32_mode_us_per_step": round(ms32 / 20 * 1e3, 1), **split,
-                "env_steps_per_s": round(n * steps / (ms * 1e-3), 1),
-                "network_gflop_per_step": round(flop / 1e9, 1), "dtype": "bf16 MFMA, f32 accumulate",
-                "network_tflops_incl_env_step": round(flop / (us * 1e-6) / 1e12, 1), "mfma_peak_tflops": 2500.0,
+        return {"reference_grade_us_per_step": round(us_ref, 1),
+                "reference_grade_env_steps_per_s": round(n / (us_ref * 1e-6), 1),
+                "reference_grade_mode": "ZENV_MLP_F16X3: hi/lo split float16 operands, 3 products per k-step, float32 "
+                                        "accumulation -- mu / std / value within 3e-6 of torch float32",
+                "load_mlp_default": default_mode,
+                "f32_mode_us_per_step": round(us_f32, 1), "f32_mode_env_steps_per_s": round(n / (us_f32 * 1e-6), 1),
+                "bf16x3_mode_us_per_step": round(us_bf16x3, 1),
+                "network_gflop_per_step": round(flop / 1e9, 1),
+                "reference_grade_tflops_3_products": round(3 * flop / (us_ref * 1e-6) / 1e12, 1),
+                "reduced_precision": {
+                    "note": "narrower arithmetic than the reference's float32 modules (opt-in; not the reference's network)",
+                    "bf16_us_per_step": round(us_bf16, 1), "bf16_env_steps_per_s": round(n / (us_bf16 * 1e-6), 1),
+                    "bf16_tolerance_vs_torch_f32": 4e-2, "f16_us_per_step": round(us_f16, 1),
+                    "f16_tolerance_vs_torch_f32": 1e-3,
+                    "bf16_network_tflops_incl_env_step": round(flop / (us_bf16 * 1e-6) / 1e12, 1)},
+                "mfma_peak_tflops": 2500.0,
                 # a bare v_mfma_f32_32x32x16_bf16 chain on every SIMD with random operands: the power controller
                 # holds 1.71 GHz (scripts/probes/mfma_clock.hip), i.e. this, not the spec figure, is reachable
                 "mfma_sustained_random_operands_tflops": 1647.0}

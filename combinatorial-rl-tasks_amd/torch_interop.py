@@ -63,11 +63,13 @@ class TorchZoneEnv:
         self.env.reset(mask)
         return {"obs": self.obs, "zone_obs": self.zone_obs}
 
-    def load_state_dict(self, state_dict):
+    def load_state_dict(self, state_dict, precision="auto"):
         """Put an ACModel state_dict (main/src/flat_model.py:24-52 names; torch tensors on any device) into the
-        device actor-critic that ``collect`` and the ``POLICY_MLP_*`` action sources run."""
+        device actor-critic that ``collect`` and the ``POLICY_MLP_*`` action sources run.  precision: see
+        ``ZoneVecEnv.load_mlp`` -- the default is float32-grade (the reference's modules are float32); "bf16" is the
+        fast reduced-precision mode."""
         from .vec_env import mlp_tensors_from_state_dict
-        self.env.load_mlp(mlp_tensors_from_state_dict(state_dict))
+        self.env.load_mlp(mlp_tensors_from_state_dict(state_dict), precision=precision)
 
     def collect(self, frames_per_proc, policy_seed=1, env_index0=0, discount=0.99, gae_lambda=0.95):
         """collect_experiences (torch_ac/algos/base.py:131-227) on the device; returns exps.* as float32 CUDA

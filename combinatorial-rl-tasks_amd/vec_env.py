@@ -362,17 +362,33 @@ class ZoneVecEnv:
         return (arrays[0].copy(), arrays[1].astype(bool), arrays[2].copy(), arrays[3].copy())
 
     # ------------------------------------------------------------------ actor network
-    def load_mlp(self, tensors, precision="bf16"):
+    def load_mlp(self, tensors, precision="auto"):
         """The reference's ZoneEnvModel + actor (env_model.py:48-79, policy_network.py:12-53) for the
         device policies POLICY_MLP_MEAN / POLICY_MLP_SAMPLE.  tensors: dict of float32 arrays named as in
         ``_native.MLP_TENSORS`` (see ``mlp_tensors_from_state_dict``), state_dict layout [out][in].
-        precision "bf16": bf16 MFMA kernels (fastest; mu / std within 4e-2 of torch float32); "f32": float32 throughout
-        (8x slower; within 1e-5 of torch float32); "f16x3" / "bf16x3": the 16-bit matrix instruction on hi / lo split
-        operands, three products per k-step -- "f16x3" within 3e-6 of torch float32 at 0.30 of "f32"'s time, "bf16x3"
-        within 2e-5 at 0.35.  "f16x3" is bound to float16's range: a weight >= 32 768 is refused here and an input /
-        activation >= 65 520 raises ZenvError(E_RANGE) at the next call that waits for the device.  "f16": the bf16
-        kernels with float16 operands -- 5 % slower, an eighth of the rounding error (within 1e-3 of torch float32);
-        float16's range is guaranteed by a bound on the zone layers at load plus run-time checks (E_RANGE otherwise)."""
+
+        precision -- the default keeps the reference's float32 arithmetic (its modules are torch float32):
+          "auto" (default)  "f16x3", or "f32" when the weights leave float16's range (ZENV_E_RANGE at load); the mode
+                            taken is in ``self.mlp_precision``
+          "f16x3"           the 16-bit matrix instruction on hi / lo split float16 operands, three products per k-step:
+                            mu / std / value within 3e-6 of torch float32 at 0.30 of "f32"'s time.  float16's range applies:
+                            a weight >= 32 768 is refused here, an input / activation >= 65 520 raises
+                            ZenvError(E_RANGE) at the next call that waits for the device (then load with "f32")
+          "f32"             float32 throughout (f32 MFMA / FMA): within 1e-5 of torch float32
+          "bf16x3"          the split with bfloat16 halves: within 2e-5 at 0.35 of "f32"'s time, float32's RANGE -- for
+                            networks "f16x3" refuses when 1e-5 is not needed
+        Reduced precision, opt-in (narrower arithmetic than the reference's -- for throughput experiments, not parity):
+          "bf16"            bf16 MFMA kernels, 8x faster than "f32"; mu / std within 4e-2 of torch float32 by contract
+          "f16"             the same kernels on float16 operands: within 1e-3; float16's range guaranteed by a bound on the
+                            zone layers at load plus run-time checks (E_RANGE otherwise)."""
+        if precision == "auto":
+            try:
+                self.load_mlp(tensors, precision="f16x3")
+            except ZenvError as e:
+                if e.code != nat.E_RANGE:
+                    raise
+                self.load_mlp(tensors, precision="f32")
+            return
         F = self.zone_feat
         h = int(np.asarray(tensors["zone_b1"]).shape[0])
         want = {"zone_w1": (h, 8 + F), "zone_b1": (h,), "zone_w2": (h, h), "zone_b2": (h,), "zone_w3": (h, h),
@@ -394,6 +410,7 @@ class ZoneVecEnv:
             keep[name] = a
             setattr(w, name, a.ctypes.data)
         check(lib().zenv_mlp_load(self._h, C.byref(w)))
+        self.mlp_precision = precision
 
     def mlp_forward(self, with_value=False):
         """(mu, std) float32 [N,2] of the actor's Normal for the current observations; with_value: also

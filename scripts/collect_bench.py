@@ -23,7 +23,7 @@ for (kw, kb), shape in ((("zone_w1", "zone_b1"), (h, 8 + F)), (("zone_w2", "zone
                         (("comb_w", "comb_b"), (h, 8 + h)), (("enc_w", "enc_b"), (h, h)), (("mu_w", "mu_b"), (2, h)),
                         (("std_w", "std_b"), (2, h)), (("critic_w1", "critic_b1"), (h, h)), (("critic_w2", "critic_b2"), (1, h))):
     t[kw], t[kb] = lin(*shape)
-env.load_mlp(t)
+env.load_mlp(t, precision="bf16")
 L = nat.lib()
 for _ in range(2):
     nat.check(L.zenv_collect(env._h, T, 1, 0, 0.99, 0.95)); env.sync()

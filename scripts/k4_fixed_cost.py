@@ -10,7 +10,7 @@ n = 65536
 for zones in (1, 5, 13, 25):
     cfg = Z.default_config(0, zones, zones_keepout=0.30)
     env = Z.ZoneVecEnv(cfg, n); env.build_bank(1, n, n_threads=16); env.reset()
-    env.load_mlp(P.random_tensors(6, seed=1))
+    env.load_mlp(P.random_tensors(6, seed=1), precision="bf16")
     for _ in range(5):
         env.policy(Z.POLICY_MLP_MEAN)
     env.sync()

@@ -20,7 +20,7 @@ def weights(F, h=185, seed=0):
 
 def make(n, first):
     cfg = Z.default_config(0, 25, zones_keepout=0.40)
-    env = Z.ZoneVecEnv(cfg, n); env.build_bank(1 + first, n, n_threads=16); env.reset(); env.load_mlp(weights(6))
+    env = Z.ZoneVecEnv(cfg, n); env.build_bank(1 + first, n, n_threads=16); env.reset(); env.load_mlp(weights(6), precision="bf16")
     env.rollout(300, Z.POLICY_MLP_MEAN)
     return env
 

@@ -22,7 +22,7 @@ for env_id, num_steps in (("PointTSP-v0", 90), ("PointTTSP-v0", 90), ("ColourMat
     env.schedule_sequential()                 # a reset replays the env's own map, like OracleBatch
     env.reset()
     w = P.random_tensors(env.zone_feat, seed=4, critic=True)
-    env.load_mlp(w)
+    env.load_mlp(w, precision="bf16")
     ob = OracleBatch(O, oracle_config_from(O, cfg), range(31, 31 + n))
     ob.reset()
     prev_mask = np.ones(n, np.float32)

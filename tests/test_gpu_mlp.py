@@ -31,7 +31,7 @@ def test_mlp_forward_matches_torch(zenv_mod, env_id, n, steps, layout, monkeypat
     monkeypatch.setenv("ZENV_MLP_LAYOUT", layout)
     env = _env_with_obs(Z, env_id, n, steps)
     t = P.random_tensors(env.zone_feat, h=185, seed=5)
-    env.load_mlp(t)
+    env.load_mlp(t, precision="bf16")
     mu, std = env.mlp_forward()
     obs, zo = env.observations()
     mu_e, std_e = P.forward_bf16_emulated(t, obs, zo)
@@ -50,7 +50,7 @@ def test_mlp_layouts_agree_and_the_default_follows_the_batch_size(zenv_mod, monk
     Z = zenv_mod
     for env_id, n, over in (("PointTSP-v0", 1000, {}), ("ColourMatch-v0", 97, {}), ("PointTSP-v0", 70, {"num_zones": 3})):
         env = _env_with_obs(Z, env_id, n, 20, **over)
-        env.load_mlp(P.random_tensors(env.zone_feat, seed=2))
+        env.load_mlp(P.random_tensors(env.zone_feat, seed=2), precision="bf16")
         out = {}
         for layout in ("split", "32", "64", None):
             if layout is None:
@@ -71,7 +71,7 @@ def test_mlp_value_head(zenv_mod):
     Z = zenv_mod
     env = _env_with_obs(Z, "PointTSP-v0", 300, 30)
     t = P.random_tensors(6, seed=5, critic=True)
-    env.load_mlp(t)
+    env.load_mlp(t, precision="bf16")
     mu, std, val = env.mlp_forward(with_value=True)
     obs, zo = env.observations()
     mu_e, std_e, val_e = P.forward_bf16_emulated(t, obs, zo)
@@ -80,7 +80,7 @@ def test_mlp_value_head(zenv_mod):
     assert np.abs(val - val_e).max() < 4e-3 and np.abs(val - val_r).max() < 4e-2
     assert np.abs(mu - mu_e).max() < 4e-3 and np.abs(std - std_e).max() < 4e-3
     t2 = {k: v for k, v in t.items() if not k.startswith("critic")}
-    env.load_mlp(t2)                                    # reload without a critic
+    env.load_mlp(t2, precision="bf16")                                    # reload without a critic
     mu2, std2 = env.mlp_forward()
     assert np.array_equal(mu, mu2) and np.array_equal(std, std2)
     with pytest.raises(ValueError):
@@ -132,7 +132,7 @@ def test_distributional_critic_on_the_mfma_path(zenv_mod):
     Z = zenv_mod
     env = _env_with_obs(Z, "PointTSP-v0", 300, 30)
     t = P.random_tensors(6, seed=8, distributional=True)
-    env.load_mlp(t)
+    env.load_mlp(t, precision="bf16")
     mu, std, val, sig = env.mlp_forward(with_value=True)
     obs, zo = env.observations()
     mu_e, std_e, val_e, sig_e = P.forward_bf16_emulated(t, obs, zo)
@@ -143,7 +143,7 @@ def test_distributional_critic_on_the_mfma_path(zenv_mod):
     # half a distributional critic is refused
     bad = {k: v for k, v in t.items() if k != "critic_sigma_b"}
     with pytest.raises((Z.ZenvError, KeyError)):
-        env.load_mlp(bad)
+        env.load_mlp(bad, precision="bf16")
     env.close()
 
 
@@ -182,7 +182,7 @@ def test_mlp_other_widths_and_zone_counts(zenv_mod):
         env.reset()
         env.rollout(15, Z.POLICY_UNIFORM)
         t = P.random_tensors(env.zone_feat, h=h, seed=zones)
-        env.load_mlp(t)
+        env.load_mlp(t, precision="bf16")
         mu, std = env.mlp_forward()
         obs, zo = env.observations()
         mu_e, std_e = P.forward_bf16_emulated(t, obs, zo)
@@ -190,7 +190,7 @@ def test_mlp_other_widths_and_zone_counts(zenv_mod):
         env.close()
     with pytest.raises(Z.ZenvError):
         env = Z.ZoneVecEnv(Z.default_config(0, 5), 4)
-        env.load_mlp(P.random_tensors(6, h=192))                   # no room for the bias slot
+        env.load_mlp(P.random_tensors(6, h=192), precision="bf16")                   # no room for the bias slot
 
 
 def test_mlp_policy_actions_and_rollout(zenv_mod):
@@ -201,7 +201,7 @@ def test_mlp_policy_actions_and_rollout(zenv_mod):
     n = 4096
     env = _env_with_obs(Z, "PointTSP-v0", n, 5)
     t = P.random_tensors(6, seed=1)
-    env.load_mlp(t)
+    env.load_mlp(t, precision="bf16")
     mu, std = env.mlp_forward()
     env.policy(Z.POLICY_MLP_MEAN)
     assert np.array_equal(env.get(Z.F_ACTIONS), mu)
