@@ -672,46 +672,78 @@ def cpu_baseline(cfg, task, zones, keepout, policy):
             "one_core_sample": f"1024 envs x 1000 steps on 1 thread, {dt1:.2f}s wall"}
 
 
-def action_chunk_rate(env, task, zones, lib_chunk, reps=24, skill_len=10):
+def action_chunk_rate(env, task, zones, lib_chunk, n_steps=2048, skill_len=10):
     """Side measurement (never `value`): the same envs driven by EXTERNALLY supplied actions in chunks (zenv_step_many:
     k_rollout_lane's action-buffer form) -- what a consumer with pre-computed or open-loop action sequences gets instead
-    of one k_step_lane launch per step.  The [K][N][2] action buffer is resident in HBM before the timed region (uploaded
-    once, replayed through its device pointer); actions: full throttle with uniform steering.  Timed: `reps` back-to-back
-    chunks between two stream synchronisations (host wall clock: a chunk is >= 1 ms of GPU time).  Algorithmic bytes per
-    env-step = the persistent kernel's (outputs of every step, state once per launch) + the action read (8) + the
-    time-major reward / done records (5).  Also the fixed-length-skill shape: chunks of `skill_len` steps that reset at
-    the boundary (_hier_policy_opt.py:68-71), where the launch is amortised over 10 steps only."""
+    of one k_step_lane launch per step.
+
+    Like for like with the headline kernel: the actions are the scripted greedy policy's own.  From a snapshot S0 the
+    envs are stepped `n_steps` times with one k_step_lane launch per step, every a_t copied (device to device) into an
+    [n_steps][N][2] buffer resident in HBM; the snapshot is restored and the buffer replayed through zenv_step_many -- the
+    same trajectories, auto-resets included, as ceil(n_steps / 256) launches -- and the replay's observations, episode
+    counts and returns must equal the recorded run's bit for bit (`replay_matches`).  Timed: that one replay between two
+    stream synchronisations (>= 10 ms of GPU time), right behind ~20 ms of a bare store stream so that it does not start
+    on the boost clock of an idle GPU.  Algorithmic bytes per env-step = the persistent kernel's (outputs of every step,
+    state once per launch) + the action read (8) + the time-major reward / done records (5).  Beside it the
+    fixed-length-skill shape: the same buffer in chunks of `skill_len` steps that reset at the boundary
+    (_hier_policy_opt.py:68-71), a launch every 10 steps."""
     try:
+        import combinatorial_rl_tasks_amd as Z
         from combinatorial_rl_tasks_amd import _native as nat
-        n = env.num_envs
-        rs = np.random.RandomState(11)
+        from combinatorial_rl_tasks_amd.vec_env import probe_store_stream
+        n, K = env.num_envs, int(n_steps)
+        F = 6 if task == 0 else 7
+        env.step_many(np.zeros((K, n, 2), np.float32), reset="every")      # allocates the chunk buffers (untimed)
+        ptr = env.device_ptr(nat.F_CHUNK_ACTIONS)
+        env.rollout(SETTLE_STEPS // 2, Z.POLICY_GREEDY)
+        env.policy(Z.POLICY_GREEDY)                                         # a_0 of the recording
+        s0 = env.get_state()
+        for t in range(K):
+            env.get_into_device(nat.F_ACTIONS, ptr + 8 * n * t)
+            env.rollout(1, Z.POLICY_GREEDY, mode="per_step")               # leaves a_{t+1} in the action buffer
+        want = [env.get(f).copy() for f in (nat.F_OBS, nat.F_ZONE_OBS, nat.F_EPISODES, nat.F_LAST_RETURN, nat.F_EP_LEN)]
+        ep_rec = int(want[2].sum())
+
+        def warm():
+            probe_store_stream((n + 63) // 64, 64 * zones * F * 4, steps=max(64, int(20e3 / 6)), cache_policy=16, reps=1,
+                               device=env.device)
         out = {}
-        for name, K, reset, r in (("full_launch", lib_chunk, "every", reps), ("skill_len_10", skill_len, "last", 40 * reps)):
-            a = np.empty((K, n, 2), np.float32)
-            a[..., 0] = 1.0
-            a[..., 1] = rs.uniform(-1, 1, (K, n))
-            env.step_many(a, reset=reset)                          # uploads the buffer (untimed) and warms the kernel
-            ptr = (env.device_ptr(nat.F_CHUNK_ACTIONS), K)
-            for _ in range(3):
-                env.step_many(None, reset=reset, actions_ptr=ptr)
-            env.sync()
-            t0 = time.perf_counter()
-            for _ in range(r):
-                env.step_many(None, reset=reset, actions_ptr=ptr)
-            env.sync()
-            dt = time.perf_counter() - t0
-            steps = r * K
-            k_step_s = dt / steps
-            alg = algorithmic_bytes(task, zones, K) + 8 + 5
-            ach = alg * n / k_step_s / 1e9
-            out[name] = {"kernel": "k_rollout_lane<EXT>", "steps_per_launch": K, "reset": reset, "chunks_timed": r,
-                         "us_per_step": round(k_step_s * 1e6, 3), "env_steps_per_s": round(n * steps / dt, 1),
-                         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                      "algorithmic_bytes_per_env_step": round(alg, 1),
-                                      "llc_resident": bool(output_bytes_per_step(task, zones, n) <= LLC_BYTES)},
-                         "timing": "host wall clock between two stream synchronisations around the back-to-back chunks"}
-        out["episodes_finished"] = int(env.get(nat.F_EPISODES).sum())
+        env.set_state(s0)
+        ep0 = int(env.get(nat.F_EPISODES).sum())
+        warm()
+        env.sync()
+        t0 = time.perf_counter()
+        env.step_many(None, reset="every", actions_ptr=(ptr, K))
+        env.sync()
+        dt = time.perf_counter() - t0
+        got = [env.get(f) for f in (nat.F_OBS, nat.F_ZONE_OBS, nat.F_EPISODES, nat.F_LAST_RETURN, nat.F_EP_LEN)]
+        match = all(np.array_equal(a, b) for a, b in zip(got, want))
+
+        def block(k_launch, steps, dt, reset):
+            alg = algorithmic_bytes(task, zones, k_launch) + 8 + 5
+            ach = alg * n * steps / dt / 1e9
+            return {"kernel": "k_rollout_lane<EXT>", "steps_per_launch": k_launch, "reset": reset, "steps_timed": steps,
+                    "us_per_step": round(dt / steps * 1e6, 3), "env_steps_per_s": round(n * steps / dt, 1),
+                    "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                 "algorithmic_bytes_per_env_step": round(alg, 1),
+                                 "llc_resident": bool(output_bytes_per_step(task, zones, n) <= LLC_BYTES)}}
+        out["full_launch"] = block(lib_chunk, K, dt, "every")
+        out["full_launch"].update({"replay_matches": "bit-identical" if match else "MISMATCH",
+                                   "episodes_ended_in_replay": ep_rec - ep0,
+                                   "actions": "the scripted greedy policy's, recorded step by step from the same snapshot"})
+        # the fixed-length-skill shape on the same buffer (trajectories differ from the recording: finished envs wait)
+        env.set_state(s0)
+        warm()
+        env.sync()
+        n_chunks = K // skill_len
+        t0 = time.perf_counter()
+        for c in range(n_chunks):
+            env.step_many(None, reset="last", actions_ptr=(ptr + 8 * n * skill_len * c, skill_len))
+        env.sync()
+        dt10 = time.perf_counter() - t0
+        out[f"skill_len_{skill_len}"] = block(skill_len, n_chunks * skill_len, dt10, "last")
+        out["timing"] = "host wall clock between two stream synchronisations around the replay"
         return out
     except Exception as ex:  # the bench line must still print
         return f"error: {ex}"
