@@ -110,3 +110,97 @@ def test_colour_cycle_and_cooldown_of_the_colourmatch_animation():
     disp = np.linalg.norm(np.diff(np.array(d["robot_xy"][:6]), axis=0), axis=1) * 0.854      # metres per frame on the way in
     steps_per_frame = float(np.max(disp)) / 1.5 / 0.02
     assert 120 <= 5 * steps_per_frame <= 190, steps_per_frame     # five frames = one cooldown, within a frame
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: what the renderings can still pin -- the robot's nose (heading) in both animations and the
+# zone fade of the TimedTSP one.  Extracted once by tests/golden/make_gif_heading.py (data only).
+
+def _heading(name):
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", name)) as fh:
+        return json.load(fh)
+
+
+def _axis_diff(a, b):
+    return (a - b + np.pi / 2) % np.pi - np.pi / 2
+
+
+def test_camera_model_behind_the_heading_fit_reproduces_the_zone_discs():
+    """The pinhole camera recovered from the floor (focal length from |r1| = |r2|, metric scale from the zone radius 0.2,
+    ZoneEnvBase.py:51) projects a disc of that radius onto every zone blob: widths within 10 %, heights (the foreshortened
+    direction, which depends on the recovered tilt) within 20 %."""
+    for name, tol_w, tol_h in (("gif_pointtsp_heading.json", 0.08, 0.12), ("gif_timedtsp_heading.json", 0.17, 0.19)):
+        d = _heading(name)
+        c = np.array(d["zone_disc_check"], float)
+        assert len(c) >= 13 and 400 < d["focal_px"] < 560 and 0.8 < d["metres_per_floor_unit"] < 0.9
+        assert np.abs(c[:, 0] / c[:, 1] - 1).max() < tol_w and np.abs(c[:, 2] / c[:, 3] - 1).max() < tol_h, name
+
+
+def test_robot_nose_follows_the_motion_and_what_the_heading_cannot_resolve():
+    """The Point robot's silhouette (sphere r = 0.1 + the 'pointarrow' box, xmls/point.xml) fitted per frame.  What the
+    fit supports: the nose AXIS lies along the direction of motion (the robot is driven along its body x axis -- the
+    motor's gear '0.3 0 0 0 0 0' on the body-fixed site) in the large majority of frames, in both episodes.
+    What it does not: the axis is good to about +-25 degrees (median deviation from the track's own direction), its SIGN is
+    unreliable when the nose points away from the camera, and a frame is 0.32-0.5 s -- two orders of magnitude above the
+    hinge's servo time and of the order of the 0.35 s a full-rate quarter turn takes: the turn-in dynamics
+    and the 3 rad/s plateau cannot be read off these pictures, only that nothing contradicts them."""
+    for name in ("gif_pointtsp_heading.json", "gif_timedtsp_heading.json"):
+        rob = [r for r in _heading(name)["robot"] if r]
+        assert len(rob) == 60 and np.median([r["iou"] for r in rob]) > 0.55
+        xy = np.array([[r["x"], r["y"]] for r in rob])
+        psi = np.array([r["heading"] for r in rob])
+        vel = np.diff(xy, axis=0)
+        speed = np.hypot(vel[:, 0], vel[:, 1])
+        moving = speed > 0.15                                   # metres per frame
+        dev = np.degrees(np.abs(_axis_diff(psi[:-1], np.arctan2(vel[:, 1], vel[:, 0]))))[moving]
+        assert moving.sum() >= 50 and (dev < 35).mean() > 0.65 and 15 < np.median(dev) < 32, (name, np.median(dev))
+    # the model-based position agrees with the blob-centroid track of round 3 (make_gif_track.py) to the robot's own size
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "gif_pointtsp_track.json")) as fh:
+        tr = json.load(fh)
+    d = _heading("gif_pointtsp_heading.json")
+    fit = np.array([[r["x"], r["y"]] for r in d["robot"]])
+    cen = np.array(tr["robot_xy"]) * d["metres_per_floor_unit"]
+    off = fit[:56] - cen[:56]
+    assert np.hypot(*(off - off.mean(0)).T).max() < 0.12 and np.hypot(*off.mean(0)) < 0.15
+
+
+def test_timed_tsp_animation_fades_every_unvisited_zone_at_one_rate_and_visited_zones_stay_yellow():
+    """TTSP_env.py:23-27,46-60 as RENDERED by the reference: an unvisited zone's colour is (1 - t, t, t) with
+    t = (tmax - steps) / max_steps -- so in the animation every unvisited zone's red channel rises, and its green falls,
+    LINEARLY and at the SAME rate for all zones (one clock, `steps`), whatever its own deadline; a visited zone turns
+    Yellow (zone_times = 1, :26) and never fades again.  The common rate is the animation's time base: with the zone that
+    is still unvisited in the last frame alive throughout, steps per frame < 2000 / 59, and the time base the robot's
+    speed plateau gives (terminal speed 1.5 m/s, the normaliser of ZoneEnvBase.py:223) lies below that bound."""
+    d = _heading("gif_timedtsp_heading.json")
+    zones = d["zones"]
+    assert len(zones) == 13                                     # two of the 15 start near t = 0.5: grey on a grey floor
+    slopes_r, slopes_g, visit = [], [], []
+    for z in zones:
+        rgb = np.array(z["rgb"])
+        r, g, b = rgb.T
+        yellow = (g - b) > 60
+        fv = int(np.argmax(yellow)) if yellow.any() else None
+        visit.append(fv)
+        if fv is not None:
+            assert yellow[fv + 1:].all() and np.abs(r[fv + 2:] - g[fv + 2:]).max() < 6      # Yellow from its visit on
+        ok = (~yellow) & (r > 150) & (r < 205) & (np.abs(g - b) < 8)                        # inside the display's linear range
+        idx = np.nonzero(ok)[0]
+        if fv is not None:
+            idx = idx[idx < fv - 2]                                                         # (the red robot is on the zone)
+        if len(idx) >= 9:
+            pr, pg = np.polyfit(idx, r[idx], 1), np.polyfit(idx, g[idx], 1)
+            assert np.abs(np.polyval(pr, idx) - r[idx]).max() < 5.0                          # linear in time (palette steps)
+            slopes_r.append(pr[0])
+            slopes_g.append(pg[0])
+    slopes_r, slopes_g = np.array(slopes_r), np.array(slopes_g)
+    assert len(slopes_r) >= 10 and (slopes_r > 0).all() and (slopes_g < 0).all()
+    assert slopes_r.std() / slopes_r.mean() < 0.08                                           # ONE rate: 1.27 +- 0.07 per frame
+    assert sum(v is None for v in visit) == 1 and sorted(v for v in visit if v is not None)[0] >= 3
+    # time base: the speed plateau (90th percentile of the per-frame displacement) against the alive bound
+    rob = [r for r in d["robot"] if r]
+    xy = np.array([[r["x"], r["y"]] for r in rob])
+    plateau = np.percentile(np.hypot(*np.diff(xy, axis=0).T), 90)
+    steps_per_frame = plateau / (1.5 * 0.02)
+    assert 15 < steps_per_frame < 2000 / 59 and 60 * steps_per_frame <= 2000 * 1.02
