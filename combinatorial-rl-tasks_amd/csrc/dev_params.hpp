@@ -6,9 +6,10 @@
 //   frame    fa,fb [N] double2          float64   (x0,y0) (bq0,bq3) episode-static placement
 //   zones    zxy[Z][N] double2          float64   zone centres (x,y), zone-major
 // (pairs so that every access is 16 B per lane = 1 KiB per wave instruction)
-//   TSP/TTSP vis[N] u32 bitmask; tmax[Z][N] i32 (TimedTSP)
-//   Colour   colpack[N] u64 (2 bits/zone), cooldown u64 [ceil(Z/8)][N] (a byte per zone), goal_dist[N] i32
-//   counters steps[N] i32, done_state[N] u8, ep_return[N] f64, episodes/last_len[N] i32 ...
+//   hot      hota[N] (ep_return, steps, visited mask | goal_dist), hotc[N] (colours, cooldown bytes of zones 0..7;
+//            ColourMatch), sched[N] (next slot, episode index, reset hint, done state): 16-byte records, see below
+//   TTSP     tmax[Z][N] i32
+//   counters last_return[N] f64, episodes / last_len / visit_count[N] i32 ...
 // Outputs are row-major exactly as the reference consumer reads them
 // (main/src/utils/format.py:25-29): obs [N][8] f32, zone_obs [N][Z][F] f32.
 #pragma once
@@ -17,6 +18,25 @@
 #include <hip/hip_runtime_api.h>   // double2
 
 namespace zenvk {
+
+// The per-env scalars every step reads and writes, as 16-byte records (struct-of-arrays over the env index, one
+// dwordx4 per lane): a step kernel loads and stores three records where it used ten 1- to 8-byte arrays -- fewer
+// instructions on the two lone waves of a tile, fewer live pointers, and every access a full-width one.
+struct __attribute__((aligned(16))) HotA {
+    double ep_return;      // undiscounted return of the running episode
+    int32_t steps;         // steps of the running episode
+    uint32_t vis;          // TSP / TimedTSP: visited bitmask (starts as vis0); ColourMatch: goal_dist
+};
+struct __attribute__((aligned(16))) HotC {     // ColourMatch only
+    uint64_t colpack;      // 2-bit colours
+    uint64_t cd0;          // cooldown bytes of zones 0..7 (zones 8.. in DevParams::cooldown)
+};
+struct __attribute__((aligned(16))) Sched {
+    int32_t next_slot;     // sequential / ring schedules: bank slot of the env's NEXT episode (slot_after, kernels.hip)
+    int32_t episode_idx;   // episodes started so far
+    int32_t reset_hint;    // bank slot the env may reset into at the next step (-1: none): prefetch hint, not state
+    uint32_t done_state;   // 1 = finished and left alone by step_no_reset (WaitWrapper's no-op until an auto-reset step)
+};
 
 struct DevParams {
     // sizes / task
@@ -46,14 +66,13 @@ struct DevParams {
     double2 *fa, *fb;        // (x0,y0) (bq0,bq3)
     double2 *zxy;            // [Z][N] (zone x, zone y): exact centres (rim test, resets)
     float4 *zpf;             // [ceil(Z/2)][N] float32 (x/3, y/3) of zones 2h and 2h+1
-    uint32_t *vis;
+    HotA *hota;              // [N]
+    HotC *hotc;              // [N] (ColourMatch)
+    Sched *sched;            // [N]
     int32_t *tmax;
-    uint64_t *colpack;
-    uint8_t *cooldown;       // ColourMatch: one byte per zone, eight zones of an env per 64-bit word: u64 [ceil(Z/8)][N]
-    int32_t *goal_dist;
-    int32_t *steps;
-    uint8_t *done_state;
-    double *ep_return, *last_return;
+    uint8_t *cooldown;       // ColourMatch, zones 8 and up: one byte per zone, eight zones of an env per 64-bit word:
+                             // u64 [ceil(Z/8) - 1][N] (word w of an env = zones 8w .. 8w+7; word 0 is HotC::cd0)
+    double *last_return;
     int32_t *last_len, *episodes, *visit_count;
     // goal-conditioned variant (TSP_next_city_env.py), null unless zenv_goal_enable(): the zone visited this
     // step (-1: none) and the post-physics world position of an env whose episode ended in this step
@@ -71,9 +90,7 @@ struct DevParams {
     float *order_val;       // [N][Z]
     int64_t *seed;
     // schedule
-    int32_t *slot_first, *episode_idx;
-    int32_t *next_slot;   // [N] sequential / ring schedules: bank slot of the env's NEXT episode (see slot_after, kernels.hip)
-    int32_t *reset_hint;  // [N] bank slot an env may reset into at the next step (-1: none): prefetch hint, not state
+    int32_t *slot_first;
     uint64_t *pcg;        // [N][4] state_hi,state_lo,inc_hi,inc_lo
     uint32_t *pcg_buf;    // [N][2] has_u32,u32
     // bank

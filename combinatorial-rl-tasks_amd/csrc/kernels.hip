@@ -53,11 +53,6 @@ constexpr int kWave = 64;
 // Rows per flush chunk of the 6-float rows (RPC * 6 floats must be whole float4: 2 or 4).  4 halves the number of
 // expand -> slab -> store iterations of a 25-zone tile (13 -> 7), which is what made PointTSP-25 flush slower per byte
 // than TimedTSP-25's 7-float rows.
-// experiment switch (round 3): the zone wave's small per-env stores behind the row flush instead of before the
-// rendezvous -- measured slower (the pointers stay live across the flush: more SGPR spill code), so 0
-#ifndef ZENV_STORES_AFTER_FLUSH
-#define ZENV_STORES_AFTER_FLUSH 0
-#endif
 #ifndef ZENV_RPC6
 #define ZENV_RPC6 4
 #endif
@@ -120,14 +115,15 @@ __device__ __forceinline__ int hamming_to_goal(uint64_t colpack, int Z)
 // cooldowns are one 8-byte load and one 8-byte store per step (Z <= 8) instead of Z byte-wide read-modify-writes of
 // half-empty cache lines (round 2: u8 [Z][N], PMC traffic 1.28x the algorithmic bytes on ColourMatch-6).
 template <typename P>
-__device__ __forceinline__ uint8_t *cd_byte(const P &p, int z, int env)
-{
-    return p.cooldown + (((size_t)(z >> 3) * p.N + env) << 3) + (z & 7);
-}
-template <typename P>
 __device__ __forceinline__ uint64_t *cd_word(const P &p, int w, int env)
 {
-    return reinterpret_cast<uint64_t *>(p.cooldown) + (size_t)w * p.N + env;
+    if (w == 0) return &p.hotc[env].cd0;
+    return reinterpret_cast<uint64_t *>(p.cooldown) + (size_t)(w - 1) * p.N + env;
+}
+template <typename P>
+__device__ __forceinline__ uint8_t *cd_byte(const P &p, int z, int env)
+{
+    return reinterpret_cast<uint8_t *>(cd_word(p, z >> 3, env)) + (z & 7);
 }
 // every non-zero byte of w minus one (colour_match_env.py:98-100 for eight zones at once; no borrow crosses a byte)
 __device__ __forceinline__ uint64_t cd_decrement(uint64_t w)
@@ -202,16 +198,16 @@ __device__ __forceinline__ int slot_after(const P &p, int env, int slot)
     return n >= p.bank_size ? n - p.bank_size : n;
 }
 
-// Bank slot of env's next episode (and advance the schedule).  k = its episode index, nslot = p.next_slot[env], passed
+// Bank slot of env's next episode (and advance the schedule).  k = its episode index, nslot = p.sched[env].next_slot, passed
 // in when the caller has already loaded them; nslot comes back advanced.
 template <typename P>
 __device__ __forceinline__ int next_bank_slot(const P &p, int env, int k, int &nslot)
 {
-    p.episode_idx[env] = k + 1;
+    p.sched[env].episode_idx = k + 1;
     if (p.sched_mode != SCHED_FIXED_SEEDS) {
         const int slot = nslot;
         nslot = slot_after(p, env, slot);
-        p.next_slot[env] = nslot;
+        p.sched[env].next_slot = nslot;
         return slot;
     }
     // wrappers.py:20-23: rng.integers(min_seed, max_seed + 1) -- Lemire on 32-bit draws
@@ -229,11 +225,27 @@ __device__ __forceinline__ int next_bank_slot(const P &p, int env, int k, int &n
     }
     return (int)(m >> 32);
 }
+// The same on a register copy of the env's schedule record (k_step_lane stores the record whole at its end).
+template <typename P>
+__device__ __forceinline__ int next_bank_slot_rec(const P &p, int env, Sched &sc)
+{
+    const int k = sc.episode_idx;
+    sc.episode_idx = k + 1;
+    if (p.sched_mode != SCHED_FIXED_SEEDS) {
+        const int slot = sc.next_slot;
+        sc.next_slot = slot_after(p, env, slot);
+        return slot;
+    }
+    int unused = 0;
+    const int slot = next_bank_slot(p, env, k, unused);     // draws from the env's PCG64 stream (its own arrays)
+    sc.episode_idx = k + 1;
+    return slot;
+}
 template <typename P>
 __device__ __forceinline__ int next_bank_slot(const P &p, int env)
 {
-    int nslot = p.next_slot[env];
-    return next_bank_slot(p, env, p.episode_idx[env], nslot);
+    int nslot = p.sched[env].next_slot;
+    return next_bank_slot(p, env, p.sched[env].episode_idx, nslot);
 }
 
 // bit i of x -> bit 2i of the result
@@ -464,12 +476,12 @@ __device__ __forceinline__ void store_frame(const P &p, int env, const EnvRegs &
 template <typename P>
 __device__ __forceinline__ void store_counters(const P &p, int env, int task, const EnvRegs &e)
 {
-    p.steps[env] = e.steps;
+    p.hota[env].steps = e.steps;
     if (task == ZENV_TASK_COLOUR_MATCH) {
-        p.colpack[env] = e.colpack;
-        p.goal_dist[env] = e.goal_dist;
+        p.hotc[env].colpack = e.colpack;
+        p.hota[env].vis = e.goal_dist;
     } else {
-        p.vis[env] = e.vis;
+        p.hota[env].vis = e.vis;
     }
 }
 
@@ -943,6 +955,8 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
     float4 *stage = lds4 + kWave * Z;                     // [64*G]  flush staging slab
     int *xmode = reinterpret_cast<int *>(stage + kWave * G);   // zone wave -> physics wave
     int *xstep = xmode + kWave;
+    double2 *xpose = reinterpret_cast<double2 *>(xstep + kWave);   // physics wave -> zone wave: pre-physics world position
+    int *xexc = reinterpret_cast<int *>(xpose + kWave);            //                           and "the action holds a NaN"
     float4 *my_ents = ents + lane * Z;
 
     EnvRegs e;
@@ -966,33 +980,33 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         int auxr[ZR];
         constexpr int ZW = ZT > 0 ? (ZT + 7) / 8 : 1;
         uint64_t cdw[ZW];   // ColourMatch: the env's cooldown bytes, eight zones per word
-        int nslot = 0, epi_idx = 0;   // bank slot (sequential / ring schedules) and index of this env's next episode
-        float2 act = make_float2(0.f, 0.f);
+        Sched sc;           // the env's schedule record: loaded whole, stored whole at the end
+        bool act_nan = false;
         {
             // ---- issue every load of this env first.  No branch around them: a lane beyond the batch (the last tile
             // of a ragged batch) loads the last env's state and ignores it -- inside an `if (valid)` the loaded values
             // reach the code below through copies at the end of the block, and those copies made the wave wait for
-            // EVERY zone load before it could look at the pose (round 3: s_waitcnt vmcnt right behind the issue)
+            // EVERY zone load before it could look at the pose (round 3: s_waitcnt vmcnt right behind the issue).
+            // The per-env scalars are three 16-byte records (round 4; ten narrow arrays before), and the pose and the
+            // action are not loaded here at all: the physics wave has them and hands the pre-physics world position
+            // and the action's NaN-ness over through LDS (first barrier below).
             const int envl = valid ? env : N - 1;
-            was_done = p.done_state[envl];
-            act = reinterpret_cast<const float2 *>(actions)[envl];   // only its NaN-ness matters here (exception path)
-            {
-                const double2 qa = p.qa[envl], fa = p.fa[envl], fb = p.fb[envl];
-                e.q0 = qa.x; e.q1 = qa.y;
-                e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
-            }
-            e.steps = p.steps[envl];
+            sc = p.sched[envl];
+            const HotA ha = p.hota[envl];
+            was_done = (uint8_t)sc.done_state;
+            e.steps = ha.steps;
+            ep_ret = ha.ep_return;
             e.vis = 0u; e.colpack = 0ull; e.goal_dist = 0;
+            if (TASK == ZENV_TASK_COLOUR_MATCH) e.goal_dist = (int32_t)ha.vis;
+            else e.vis = ha.vis;
             if (TASK == ZENV_TASK_COLOUR_MATCH) {
-                e.colpack = p.colpack[envl];
-                e.goal_dist = p.goal_dist[envl];
-            } else {
-                e.vis = p.vis[envl];
+                const HotC hc = p.hotc[envl];
+                e.colpack = hc.colpack;
+                cdw[0] = hc.cd0;
             }
-            ep_ret = p.ep_return[envl];
             if (ZT > 0) {
-                // issue order = consumption order: pose first, then zone pairs 0, 1, ... so the
-                // in-order vmcnt waits of the zone pass release one pair at a time
+                // issue order = consumption order: zone pairs 0, 1, ... so the in-order vmcnt waits of the zone pass
+                // release one pair at a time
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int h = 0; h < ZH; ++h) zp[h] = p.zpf[(size_t)h * N + envl];   // 1 KiB per wave
@@ -1004,14 +1018,19 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 }
                 if (TASK == ZENV_TASK_COLOUR_MATCH) {
 #pragma unroll
-                    for (int w = 0; w < ZW; ++w) cdw[w] = *cd_word(p, w, envl);
+                    for (int w = 1; w < ZW; ++w) cdw[w] = *cd_word(p, w, envl);
                 }
                 // nothing below may be scheduled above this point, nor any load below it
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // only needed at the very end (reset / prefetch): requested behind the zone loads
-            nslot = p.next_slot[envl];         // the bank slot of a reset is known before it happens
-            epi_idx = p.episode_idx[envl];
+        }
+        const int nslot = sc.next_slot;   // bank slot of the env's NEXT episode (sequential / ring schedules)
+        __syncthreads();          // the physics wave has published the pre-physics pose
+        double rx, ry;            // what set_mocaps() sees
+        {
+            const double2 pz = xpose[lane];
+            rx = pz.x; ry = pz.y;
+            act_nan = xexc[lane] != 0;
         }
 
         float rew_out = 0.f;
@@ -1036,8 +1055,6 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = make_float2(0.f, 0.f);
             }
         } else if (valid) {
-            double rx, ry;               // pre-physics pose: what set_mocaps() sees
-            world_pos(e, rx, ry);
             ZSTAMP(1);
 
             // ---- zone pass: set_mocaps() of the first substep (TSP_env.py:54-69,
@@ -1136,10 +1153,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 timed_out = (expired & ~e.vis & full) != 0u;
                 ends_soon = (expiring & ~e.vis & full) != 0u;
             }
-            if (TASK == ZENV_TASK_COLOUR_MATCH && ZT > 0) {
-#pragma unroll
-                for (int w = 0; w < ZW; ++w) *cd_word(p, w, env) = cdw[w];
-            }
+            // (ZT > 0: the cooldown words go back with the env's records, below)
         }
 
         ZSTAMP(14);
@@ -1148,7 +1162,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             // Engine.step's MujocoException path: MuJoCo cannot simulate a NaN control (np.clip keeps it; mj_checkAcc
             // -> BADQACC -> mujoco-py raises): done, reward_exception, no reward() / goal test; the physics wave
             // leaves the joint state mj_resetData would (zeros).  set_mocaps() above already ran, as in the reference.
-            const bool exc = !(act.x == act.x && act.y == act.y);
+            const bool exc = act_nan;
             double r = 0.0;
             bool goal = false;
             bool done = false;
@@ -1187,7 +1201,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 p.episodes[env] += 1;
                 p.exception[env] = exc ? 1 : 0;
                 if (auto_reset) need_reset = true;
-                else p.done_state[env] = 1;
+                else sc.done_state = 1;
             }
             // next step ends the episode for sure (time limit / a deadline) or possibly (one zone
             // left; ColourMatch: one cycle from the goal)
@@ -1215,7 +1229,10 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         if (pending) {
             ZSTAMP(5);
             int my_slot = 0;
-            if (need_reset) my_slot = next_bank_slot(p, env, epi_idx, nslot);
+            if (need_reset) {
+                // (the schedule record goes back whole at the end of the wave: advance the local copy)
+                my_slot = next_bank_slot_rec(p, env, sc);
+            }
             while (pending) {
                 const int j = __ffsll((long long)pending) - 1;   // wave-uniform
                 pending &= pending - 1;
@@ -1236,7 +1253,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                         p.tmax[zi] = aux;
                     } else if (TASK == ZENV_TASK_COLOUR_MATCH) {
                         code = p.bank_aux[bi];
-                        *cd_byte(p, lane, env_j) = 0;
+                        if (ZT == 0) *cd_byte(p, lane, env_j) = 0;      // (ZT > 0: zeroed in lane j's registers below)
                     }
                     en = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
                     ents[j * Z + lane] = en;
@@ -1273,6 +1290,8 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 if (lane == j) {
                     e = fresh;
                     ep_ret = 0.0;
+#pragma unroll
+                    for (int w = 0; w < ZW; ++w) cdw[w] = 0ull;
                     mode = 2;   // superseded by the reset (the physics wave keeps the terminal position)
                     p.seed[env] = p.bank_seed[slot];
                     store_frame(p, env, e);
@@ -1292,35 +1311,53 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         // dozen store instructions that nothing waits for no longer sit between the zone pass and the start of the flush
         z_valid = valid; z_was_done = was_done != 0; z_need_reset = need_reset; z_hint = hint; z_first = first;
         z_ep_ret = ep_ret; z_rew = rew_out; z_done = done_out; z_goal = goal_out;
-#if !ZENV_STORES_AFTER_FLUSH
+        // ---- the env's records go back whole: one 16-byte store each
         if (z_valid) {
             if (!z_was_done || auto_reset) {
-                p.ep_return[env] = z_ep_ret;
-                store_counters(p, env, TASK, e);
-                if (z_was_done) p.done_state[env] = 0;      // revived by the reset
+                p.hota[env] = HotA{ z_ep_ret, e.steps, TASK == ZENV_TASK_COLOUR_MATCH ? (uint32_t)e.goal_dist : e.vis };
+                if (TASK == ZENV_TASK_COLOUR_MATCH) {
+                    if (ZT > 0) {
+                        p.hotc[env] = HotC{ e.colpack, cdw[0] };
+#pragma unroll
+                        for (int w = 1; w < ZW; ++w) *cd_word(p, w, env) = cdw[w];
+                    } else {
+                        p.hotc[env].colpack = e.colpack;       // (runtime zone count: the cooldown bytes went back one by one)
+                    }
+                }
+                if (z_was_done) sc.done_state = 0;      // revived by the reset
             }
-            p.reset_hint[env] = z_need_reset ? -1 : z_hint;
+            sc.reset_hint = z_need_reset ? -1 : z_hint;
+            p.sched[env] = sc;
             if (p.visit_zone) p.visit_zone[env] = z_first;
             p.reward[env] = z_rew;
             p.done_out[env] = z_done;
             p.goal_met[env] = z_goal;
         }
-#endif
         ZSTAMP(2);
     } else {
         // =================================================================== physics wave
         ZSTAMP(8);
+        // ---- loads (a lane beyond the batch reads the last env's state and ignores it), then the hand-over the zone
+        // wave waits for: the pre-physics world position -- what set_mocaps() sees -- and whether the action holds a NaN
+        const int envl = env < N ? env : N - 1;
+        float2 act;
+        int hint;
+        {
+            const double2 qa = p.qa[envl], fa = p.fa[envl], fb = p.fb[envl];      // the pose first
+            act = reinterpret_cast<const float2 *>(actions)[envl];
+            const double2 qb = p.qb[envl], qc = p.qc[envl];
+            hint = auto_reset ? p.sched[envl].reset_hint : -1;                     // the previous launch's reset hint
+            e.q0 = qa.x; e.q1 = qa.y; e.q2 = qb.x;
+            e.v0 = qb.y; e.v1 = qc.x; e.v2 = qc.y;
+            e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
+            double rx, ry;
+            world_pos(e, rx, ry);
+            xpose[lane] = make_double2(rx, ry);
+            xexc[lane] = !(act.x == act.x && act.y == act.y);
+        }
+        __syncthreads();
         if (env < N) {
-            {
-                const double2 qa = p.qa[env], qb = p.qb[env], qc = p.qc[env];
-                const double2 fa = p.fa[env], fb = p.fb[env];
-                e.q0 = qa.x; e.q1 = qa.y; e.q2 = qb.x;
-                e.v0 = qb.y; e.v1 = qc.x; e.v2 = qc.y;
-                e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
-            }
-            const float2 act = reinterpret_cast<const float2 *>(actions)[env];
-            // the previous launch's reset hint (see the zone wave): touch every cache line of that bank slot now
-            const int hint = auto_reset ? p.reset_hint[env] : -1;
+            // (see the zone wave: touch every cache line of the bank slot this env may reset into)
             if (hint >= 0 && hint < p.bank_size) {
                 const int *bz = reinterpret_cast<const int *>(p.bank_zone + 2 * (size_t)hint * Z);
                 pf[0] = bz[0];                                   // 128-B lines of the 16*Z-byte zone block
@@ -1366,20 +1403,6 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         const int n_blk = min(kWave, N - env0);
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 1)   // diagnostic builds only: ZENV_EXP bit 0 drops the flush
         flush_entries<TASK, StorePolicy<ZT * F>::kStep>(ents, stage, p.zone_obs + (size_t)env0 * Z * F, n_blk * Z, lane);
-#endif
-#if ZENV_STORES_AFTER_FLUSH
-        if (z_valid) {
-            if (!z_was_done || auto_reset) {
-                p.ep_return[env] = z_ep_ret;
-                store_counters(p, env, TASK, e);
-                if (z_was_done) p.done_state[env] = 0;      // revived by the reset
-            }
-            p.reset_hint[env] = z_need_reset ? -1 : z_hint;
-            if (p.visit_zone) p.visit_zone[env] = z_first;
-            p.reward[env] = z_rew;
-            p.done_out[env] = z_done;
-            p.goal_met[env] = z_goal;
-        }
 #endif
         ZSTAMP(3);
     } else if (env < N) {
@@ -1837,18 +1860,18 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
         act = EXT ? io.actions[env] : reinterpret_cast<const float2 *>(p.actions)[env];
         det_sincos_inl(0.5 * e.q2, hs, hc);
-        frozen = p.done_state[env] != 0;
-        e.steps = p.steps[env];
+        frozen = p.sched[env].done_state != 0;
+        e.steps = p.hota[env].steps;
         if (kColour) {
-            e.colpack = p.colpack[env];
-            e.goal_dist = p.goal_dist[env];
+            e.colpack = p.hotc[env].colpack;
+            e.goal_dist = p.hota[env].vis;
         } else {
-            e.vis = p.vis[env];
+            e.vis = p.hota[env].vis;
         }
-        ep_ret = p.ep_return[env];
+        ep_ret = p.hota[env].ep_return;
         vcount = p.visit_count[env];
-        epi_idx = p.episode_idx[env];
-        nslot = p.next_slot[env];
+        epi_idx = p.sched[env].episode_idx;
+        nslot = p.sched[env].next_slot;
 #pragma unroll
         for (int h = 0; h < ZH; ++h) zp[h] = p.zpf[(size_t)h * N + env];
 #pragma unroll
@@ -1878,7 +1901,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         store_dyn(pc, env, er);
         store_frame(pc, env, er);
         store_counters(pc, env, TASK, er);
-        pc.ep_return[env] = ret;
+        pc.hota[env].ep_return = ret;
         if (kColour) {
 #pragma unroll
             for (int w = 0; w < (ZT + 7) / 8; ++w) {
@@ -2050,7 +2073,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         if (live && done && !ar_t) {
             // finished, no auto-reset: frozen from the next step on.  Its registers go back to the state arrays NOW --
             // from here on the lane only idles through the steps on them (nothing of a frozen lane is written back).
-            pc.done_state[env] = 1;
+            pc.sched[env].done_state = 1;
             write_back(e, ep_ret);
             frozen = true;
         }
@@ -2142,7 +2165,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = of[i];      // the new episode's first obs is what this step returns
                     if (frozen) {
-                        pc.done_state[env] = 0;
+                        pc.sched[env].done_state = 0;
                         frozen = false;
                     }
                 }
@@ -2214,7 +2237,7 @@ __global__ __launch_bounds__(256) void k_goal_set(DevParams p, const int32_t *__
     if (g < 0) return;                                         // leave this env's goal alone
     // set_goal asserts the zone is unvisited (:86); ColourMatchNextCityEnv only checks the range
     // (zone-goals/envs/colour_match_next_city_env.py set_goal)
-    if (g >= p.Z || (p.task != ZENV_TASK_COLOUR_MATCH && ((p.vis[env] >> g) & 1u))) {
+    if (g >= p.Z || (p.task != ZENV_TASK_COLOUR_MATCH && ((p.hota[env].vis >> g) & 1u))) {
         atomicAdd(bad, 1);
         return;
     }
@@ -2257,7 +2280,7 @@ __global__ __launch_bounds__(256) void k_goal_step(DevParams p)
         const bool reached = p.visit_zone[env] == g;           // new_city_reached and zones[goal] == visited
         if (!reached) {
             double rx, ry;
-            if (done && !p.done_state[env]) {                  // auto-reset happened: the terminal position
+            if (done && !p.sched[env].done_state) {                  // auto-reset happened: the terminal position
                 const double2 t = p.term_xy[env];
                 rx = t.x; ry = t.y;
             } else {
@@ -2284,7 +2307,7 @@ __global__ __launch_bounds__(256) void k_goal_step(DevParams p)
     p.shaped[env] = sh;
     p.need_goal[env] = need;
     // get_available_goals, :92-100; every zone for ColourMatch
-    p.available[env] = p.task == ZENV_TASK_COLOUR_MATCH ? full : (~p.vis[env] & full);
+    p.available[env] = p.task == ZENV_TASK_COLOUR_MATCH ? full : (~p.hota[env].vis & full);
 }
 
 // ColourMatchSolverEnv.solver_get_next_goal (zone-goals/envs/colour_match_solver_env.py:57-97): among the zones whose
@@ -2294,7 +2317,7 @@ __global__ __launch_bounds__(256) void k_solver_goal(DevParams p, int32_t *__res
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= p.N) return;
-    const uint64_t cp = p.colpack[env];
+    const uint64_t cp = p.hotc[env].colpack;
     int n[3] = { 0, 0, 0 };                                    // Blue, Green, Red
     for (int z = 0; z < p.Z; ++z) n[(int)((cp >> (2 * z)) & 3ull) % 3] += 1;
     const int to[3] = { n[1] * 2 + n[2], n[2] * 2 + n[0], n[0] * 2 + n[1] };   // dist_to_blue / _green / _red
@@ -2324,7 +2347,7 @@ __global__ __launch_bounds__(256) void k_solver_goal(DevParams p, int32_t *__res
 // (:52-75).  Like K6 it runs after the step kernel, on the zone visited in the step and the terminal position.
 __device__ __forceinline__ int current_bank_slot(const DevParams &p, int env)
 {
-    if (p.sched_mode != SCHED_FIXED_SEEDS) return seq_slot(p, p.slot_first[env], p.episode_idx[env] - 1);
+    if (p.sched_mode != SCHED_FIXED_SEEDS) return seq_slot(p, p.slot_first[env], p.sched[env].episode_idx - 1);
     return (int)(p.seed[env] - p.seed_min);
 }
 __device__ __forceinline__ void env_world_pos(const DevParams &p, int env, double &rx, double &ry)
@@ -2387,7 +2410,7 @@ __global__ __launch_bounds__(256) void k_order_step(DevParams p)
     if (env >= p.N) return;
     int8_t *pos = p.order_pos + (size_t)env * p.Z;
     const bool done = p.done_out[env] != 0;
-    const bool was_reset = done && !p.done_state[env];
+    const bool was_reset = done && !p.sched[env].done_state;
     const int v = p.visit_zone[env];
     if (v >= 0) {
         // set_mocaps: self.route.remove(h_index) (:90)
@@ -2443,8 +2466,8 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
     const size_t zi = (size_t)lane * N + env;
     const GlobalRowSink sink{ p.zone_obs + (size_t)env * Z * F };
 
-    const bool revive = p.done_state[env] != 0 && auto_reset;   // frozen env at an auto-reset step: see k_step_lane
-    if (p.done_state[env] && !auto_reset) {
+    const bool revive = p.sched[env].done_state != 0 && auto_reset;   // frozen env at an auto-reset step: see k_step_lane
+    if (p.sched[env].done_state && !auto_reset) {
         // finished and not auto-reset: masked no-op (WaitWrapper, wrappers.py:34-45)
         if (zl) sink.put<TASK>(lane, make_float4(0.f, 0.f, -1.f, 0.f));
         if (lane == 0) {
@@ -2465,15 +2488,15 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
         e.v0 = qb.y; e.v1 = qc.x; e.v2 = qc.y;
         e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
     }
-    e.steps = p.steps[env];
+    e.steps = p.hota[env].steps;
     e.vis = 0u; e.colpack = 0ull; e.goal_dist = 0;
     if (TASK == ZENV_TASK_COLOUR_MATCH) {
-        e.colpack = p.colpack[env];
-        e.goal_dist = p.goal_dist[env];
+        e.colpack = p.hotc[env].colpack;
+        e.goal_dist = p.hota[env].vis;
     } else {
-        e.vis = p.vis[env];
+        e.vis = p.hota[env].vis;
     }
-    double ep_ret = p.ep_return[env];
+    double ep_ret = p.hota[env].ep_return;
     const float2 act = reinterpret_cast<const float2 *>(actions)[env];
     const int k = e.steps + 1;
     const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
@@ -2567,9 +2590,9 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
             p.last_len[env] = k;
             p.episodes[env] += 1;
             p.exception[env] = exc ? 1 : 0;
-            if (!auto_reset) p.done_state[env] = 1;
+            if (!auto_reset) p.sched[env].done_state = 1;
         }
-        if (revive) p.done_state[env] = 0;
+        if (revive) p.sched[env].done_state = 0;
     }
 
     if ((done || revive) && auto_reset) {
@@ -2636,7 +2659,7 @@ __global__ __launch_bounds__(4 * kWave) void k_step_wave(DevParams p, const floa
         store_obs8(p, env, o);
         store_dyn(p, env, e);
         store_counters(p, env, TASK, e);
-        p.ep_return[env] = ep_ret;
+        p.hota[env].ep_return = ep_ret;
     }
 }
 
@@ -2654,8 +2677,8 @@ __global__ __launch_bounds__(kWave) void k_reset_lane(DevParams p, const uint8_t
     store_dyn(p, env, e);
     store_frame(p, env, e);
     store_counters(p, env, TASK, e);
-    p.done_state[env] = 0;
-    p.ep_return[env] = 0.0;
+    p.sched[env].done_state = 0;
+    p.hota[env].ep_return = 0.0;
     p.visit_count[env] = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : __popc(e.vis);
     p.exception[env] = 0;
     float o[8];
@@ -2724,11 +2747,22 @@ __global__ __launch_bounds__(64) void k_bank_scatter(DevParams p, const int32_t 
 // =========================================================================== schedule sync
 // next_slot[env] = seq_slot(slot_first[env], episode_idx[env]): the invariant of slot_after(), re-established after the
 // host changed the schedule or swapped the bank for one of another size (the modulo lives here, off every step path).
-__global__ __launch_bounds__(256) void k_sched_sync(DevParams p)
+__global__ __launch_bounds__(256) void k_sched_sync(DevParams p, int restart)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= p.N) return;
-    p.next_slot[env] = p.sched_mode == SCHED_FIXED_SEEDS ? 0 : seq_slot(p, p.slot_first[env], p.episode_idx[env]);
+    if (restart) p.sched[env].episode_idx = 0;         // a new schedule starts at episode 0
+    p.sched[env].next_slot = p.sched_mode == SCHED_FIXED_SEEDS ? 0 : seq_slot(p, p.slot_first[env], p.sched[env].episode_idx);
+}
+
+// ZENV_F_EP_RETURN / ZENV_F_EP_LEN live inside the HotA records: unpacked into plain arrays when a caller asks for them
+__global__ __launch_bounds__(256) void k_unpack_hot(DevParams p, double *__restrict__ ep_return, int32_t *__restrict__ steps)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.N) return;
+    const HotA a = p.hota[env];
+    ep_return[env] = a.ep_return;
+    steps[env] = a.steps;
 }
 
 // =========================================================================== gather prep
@@ -2784,9 +2818,15 @@ hipError_t launch_bank_scatter(const DevParams &p, const int32_t *slots, const v
     return hipGetLastError();
 }
 
-hipError_t launch_sched_sync(const DevParams &p, hipStream_t s)
+hipError_t launch_sched_sync(const DevParams &p, int restart, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_sched_sync, dim3((p.N + 255) / 256), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_sched_sync, dim3((p.N + 255) / 256), dim3(256), 0, s, p, restart);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_hot(const DevParams &p, double *ep_return, int32_t *steps, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_unpack_hot, dim3((p.N + 255) / 256), dim3(256), 0, s, p, ep_return, steps);
     return hipGetLastError();
 }
 
@@ -2815,7 +2855,8 @@ static inline size_t full_tile_bytes(const DevParams &p) { return (size_t)kWave 
 static inline size_t step_lds_bytes(const DevParams &p)
 {
     const int G = p.F == 6 ? (ZENV_RPC6 * 6) / 4 : 7;
-    return (size_t)kWave * p.Z * sizeof(float4) + (size_t)kWave * G * sizeof(float4) + 2 * kWave * sizeof(int);
+    return (size_t)kWave * p.Z * sizeof(float4) + (size_t)kWave * G * sizeof(float4) + 2 * kWave * sizeof(int) +
+           kWave * sizeof(double2) + kWave * sizeof(int);       // + the pose / exception hand-over
 }
 
 template <int TASK>

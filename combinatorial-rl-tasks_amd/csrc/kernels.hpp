@@ -41,7 +41,10 @@ struct ChunkIO {
 hipError_t launch_rollout_actions(const DevParams &p, int n_steps, int reset_mode, const ChunkIO &io, hipStream_t s,
                                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int tile0 = 0, int n_tiles = -1);
 // next_slot[env] = seq_slot(slot_first[env], episode_idx[env]) after the host changed the schedule or the bank's size
-hipError_t launch_sched_sync(const DevParams &p, hipStream_t s);
+// restart != 0: the schedule also starts over at episode 0
+hipError_t launch_sched_sync(const DevParams &p, int restart, hipStream_t s);
+// HotA -> plain arrays (ZENV_F_EP_RETURN float64 [N], ZENV_F_EP_LEN int32 [N])
+hipError_t launch_unpack_hot(const DevParams &p, double *ep_return, int32_t *steps, hipStream_t s);
 hipError_t launch_reset(const DevParams &p, const uint8_t *mask, hipStream_t s);
 // goal-conditioned variant: set goals (new_goal[N], -1 = keep; *bad counts rejected ones) / per-step shaping
 hipError_t launch_goal_set(const DevParams &p, const int32_t *new_goal, int32_t *bad, hipStream_t s);

@@ -124,6 +124,9 @@ struct zenv {
     float *chunk_actions = nullptr, *chunk_reward = nullptr;
     uint8_t *chunk_done = nullptr;
     int chunk_steps = 0;            // steps of the last zenv_step_many (extent of ZENV_F_CHUNK_*)
+    // ZENV_F_EP_RETURN / ZENV_F_EP_LEN as plain arrays: the values live in the HotA records, unpacked by refresh_field()
+    double *pub_ep_return = nullptr;
+    int32_t *pub_steps = nullptr;
 };
 
 namespace {
@@ -248,8 +251,8 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_REWARD: return { p.reward, N * 4 };
     case ZENV_F_DONE: return { p.done_out, N };
     case ZENV_F_GOAL_MET: return { p.goal_met, N };
-    case ZENV_F_EP_RETURN: return { p.ep_return, N * 8 };
-    case ZENV_F_EP_LEN: return { p.steps, N * 4 };
+    case ZENV_F_EP_RETURN: return { h->pub_ep_return, N * 8 };      // (refresh_field() first)
+    case ZENV_F_EP_LEN: return { h->pub_steps, N * 4 };
     case ZENV_F_LAST_RETURN: return { p.last_return, N * 8 };
     case ZENV_F_LAST_LEN: return { p.last_len, N * 4 };
     case ZENV_F_EPISODES: return { p.episodes, N * 4 };
@@ -281,6 +284,15 @@ FieldInfo field_info(const zenv *h, int field)
     case ZENV_F_EXCEPTION: return { p.exception, N };
     default: return { nullptr, 0 };
     }
+}
+
+// ZENV_F_EP_RETURN / ZENV_F_EP_LEN are kept inside the step kernels' 16-byte records: bring the plain arrays a caller
+// sees up to date (stream-ordered, behind every step already enqueued)
+int refresh_field(zenv *h, int field)
+{
+    if (field != ZENV_F_EP_RETURN && field != ZENV_F_EP_LEN) return ZENV_OK;
+    HIP_TRY(launch_unpack_hot(h->p, h->pub_ep_return, h->pub_steps, h->stream));
+    return ZENV_OK;
 }
 
 }  // namespace
@@ -478,17 +490,13 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
     want(h, p.fa, N, true); want(h, p.fb, N, true);
     want(h, p.zxy, Z * N, true);
     want(h, p.zpf, ((Z + 1) / 2) * N, true);
-    want(h, p.vis, N, true);
+    want(h, p.hota, N, true); want(h, p.hotc, N, true); want(h, p.sched, N, true);   // the hot per-env scalars: 16-byte records
     want(h, p.tmax, Z * N, true);
-    want(h, p.colpack, N, true);
-    want(h, p.cooldown, ((Z + 7) / 8) * 8 * N, true);      // one byte per zone, eight zones of an env per 64-bit word
-    want(h, p.goal_dist, N, true);
-    want(h, p.steps, N, true);
-    want(h, p.done_state, N, true);
-    want(h, p.ep_return, N, true); want(h, p.last_return, N, true);
+    want(h, p.cooldown, std::max<size_t>(1, (Z + 7) / 8 - 1) * 8 * N, true);      // ColourMatch zones 8 and up (zones 0..7: HotC::cd0)
+    want(h, p.last_return, N, true);
     want(h, p.last_len, N, true); want(h, p.episodes, N, true); want(h, p.visit_count, N, true);
     want(h, p.seed, N, true);
-    want(h, p.slot_first, N, true); want(h, p.episode_idx, N, true); want(h, p.next_slot, N, true);
+    want(h, p.slot_first, N, true);
     want(h, p.pcg, 4 * N, true); want(h, p.pcg_buf, 2 * N, true);
     want(h, p.actions, 2 * N, true);
     {   // results slab, in ZENV_RESULT_* order
@@ -503,7 +511,7 @@ extern "C" int zenv_create(const zenv_config *cfg, int n_env, int device, zenv_t
         h->results_bytes = off;
     }
     want(h, p.dbg, 16 * ((N + 63) / 64), false);
-    want(h, p.reset_hint, N, false);       // zero-filled = "slot 0": a prefetch hint only, any value is harmless
+    want(h, h->pub_ep_return, N, false); want(h, h->pub_steps, N, false);   // ZENV_F_EP_RETURN / _EP_LEN, unpacked on request
 
     hipError_t err = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     h->stream = h->own_stream;
@@ -636,7 +644,7 @@ static int upload_bank(zenv *h, const std::vector<double> &robot4, const std::ve
     if (h->sched_ready && h->p.sched_mode == SCHED_SEQUENTIAL) {
         // a sequential schedule carries over to a bank of another size: (first + k stride) mod the NEW size
         h->p.sched_stride %= (int32_t)S;
-        HIP_TRY(launch_sched_sync(h->p, h->stream));
+        HIP_TRY(launch_sched_sync(h->p, 0, h->stream));
     } else if (h->sched_ready && h->p.sched_mode == SCHED_RING && (int32_t)S != S_old) {
         h->sched_ready = false;  // a ring's slots belong to the bank it was laid out over
     }
@@ -828,10 +836,9 @@ extern "C" int zenv_schedule_sequential(zenv_t *h, const int32_t *first, int32_t
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(h->p.slot_first, f.data(), f.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemsetAsync(h->p.episode_idx, 0, h->n_env * sizeof(int32_t), h->stream));   // on the handle's stream: the null stream does not order with it
     h->p.sched_mode = SCHED_SEQUENTIAL;
     h->p.sched_stride = stride % S;
-    HIP_TRY(launch_sched_sync(h->p, h->stream));      // next_slot = first (episode 0)
+    HIP_TRY(launch_sched_sync(h->p, 1, h->stream));   // episode 0, next_slot = first (on the handle's stream)
     h->sched_ready = true;
     return ZENV_OK;
 }
@@ -849,10 +856,9 @@ extern "C" int zenv_schedule_ring(zenv_t *h, const int32_t *first, int32_t depth
             return fail(ZENV_E_ARG, "ring of env %d, slots [%d, %d), leaves the bank [0,%d)", i, first[i], first[i] + depth, S);
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(h->p.slot_first, first, (size_t)h->n_env * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemsetAsync(h->p.episode_idx, 0, h->n_env * sizeof(int32_t), h->stream));   // on the handle's stream: the null stream does not order with it
     h->p.sched_mode = SCHED_RING;
     h->p.sched_stride = depth;
-    HIP_TRY(launch_sched_sync(h->p, h->stream));
+    HIP_TRY(launch_sched_sync(h->p, 1, h->stream));
     h->sched_ready = true;
     return ZENV_OK;
 }
@@ -876,11 +882,10 @@ extern "C" int zenv_schedule_fixed_seeds(zenv_t *h, const uint64_t *rng_seeds, i
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(h->p.pcg, st.data(), st.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(h->p.pcg_buf, 0, 2 * (size_t)h->n_env * sizeof(uint32_t), h->stream));
-    HIP_TRY(hipMemsetAsync(h->p.episode_idx, 0, h->n_env * sizeof(int32_t), h->stream));   // on the handle's stream: the null stream does not order with it
     h->p.sched_mode = SCHED_FIXED_SEEDS;
     h->p.seed_min = min_seed;
     h->p.seed_max = max_seed;
-    HIP_TRY(launch_sched_sync(h->p, h->stream));
+    HIP_TRY(launch_sched_sync(h->p, 1, h->stream));
     h->sched_ready = true;
     return ZENV_OK;
 }
@@ -1574,6 +1579,7 @@ extern "C" int zenv_get(zenv_t *h, int field, void *dst, int dst_on_device)
     if (!f.ptr) return fail(ZENV_E_ARG, "unknown field %d", field);
     int rc = use_device(h);
     if (rc) return rc;
+    if (int rf = refresh_field(h, field)) return rf;
     HIP_TRY(hipMemcpyAsync(dst, f.ptr, f.bytes, hipMemcpyDefault, h->stream));   // (a zenv_host_io field is host memory)
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (int rr = mlp_range_check(h)) return rr;
@@ -1591,6 +1597,7 @@ extern "C" int zenv_get_rows(zenv_t *h, int field, int first_env, int count, voi
     int rc = use_device(h);
     if (rc) return rc;
     const int64_t per_env = f.bytes / h->n_env;
+    if (int rf = refresh_field(h, field)) return rf;
     HIP_TRY(hipMemcpyAsync(dst, static_cast<const char *>(f.ptr) + per_env * first_env, (size_t)(per_env * count),
                            hipMemcpyDefault, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1622,6 +1629,7 @@ extern "C" int zenv_get_many(zenv_t *h, int n_fields, const int *fields, void *c
     for (int i = 0; i < n_fields; ++i) {
         const FieldInfo f = field_info(h, fields[i]);
         if (!f.ptr || !dst[i]) return fail(ZENV_E_ARG, "unknown field %d or null destination", fields[i]);
+        if (int rf = refresh_field(h, fields[i])) return rf;
         HIP_TRY(hipMemcpyAsync(dst[i], f.ptr, f.bytes, hipMemcpyDefault, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1716,6 +1724,13 @@ extern "C" int zenv_device_ptr(zenv_t *h, int field, void **ptr)
     if (!h || !ptr) return fail(ZENV_E_ARG, "null argument");
     const FieldInfo f = field_info(h, field);
     if (!f.ptr) return fail(ZENV_E_ARG, "unknown field %d", field);
+    if (field == ZENV_F_EP_RETURN || field == ZENV_F_EP_LEN) {
+        // these two live inside the step kernels' records: the pointer is to a plain copy brought up to date by THIS
+        // call (stream-ordered), not a live view
+        int rc = use_device(h);
+        if (rc) return rc;
+        if (int rf = refresh_field(h, field)) return rf;
+    }
     *ptr = f.ptr;
     return ZENV_OK;
 }
@@ -1874,6 +1889,7 @@ extern "C" int zenv_allgather(zenv_t *h, int field, void *dst, int dst_on_device
     int rc = use_device(h);
     if (rc) return rc;
     const bool is_f32 = as_f64 || as_f32;
+    if (int rf = refresh_field(h, field)) return rf;
     HIP_TRY(launch_gather_prep(f.ptr, (int)(f.bytes / N), h->comm_send, h->n_env, h->stream));
     RCCL_TRY(api, api->AllGather(h->comm_send, h->comm_recv, (size_t)N, is_f32 ? ncclFloat32 : ncclInt32, h->comm, h->stream));
     HIP_TRY(hipMemcpyAsync(dst, h->comm_recv, (size_t)N * 4 * (size_t)h->comm_world,
@@ -2085,26 +2101,25 @@ extern "C" int zenv_debug_state(zenv_t *h, double *qpos, double *qvel, int32_t *
             if (qvel) { qvel[3 * i] = qb[i].y; qvel[3 * i + 1] = qc[i].x; qvel[3 * i + 2] = qc[i].y; }
         }
     }
+    std::vector<HotA> ha(N);
+    std::vector<HotC> hc(N);
+    HIP_TRY(hipMemcpy(ha.data(), p.hota, N * sizeof(HotA), hipMemcpyDefault));
+    HIP_TRY(hipMemcpy(hc.data(), p.hotc, N * sizeof(HotC), hipMemcpyDefault));
     if (zone_state) {
-        if (h->cfg.task == ZENV_TASK_COLOUR_MATCH) {
-            std::vector<uint64_t> cp(N);
-            HIP_TRY(hipMemcpy(cp.data(), p.colpack, N * 8, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < N; ++i)
-                for (size_t z = 0; z < Z; ++z) zone_state[i * Z + z] = (int32_t)((cp[i] >> (2 * z)) & 3ull);
-        } else {
-            std::vector<uint32_t> v(N);
-            HIP_TRY(hipMemcpy(v.data(), p.vis, N * 4, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < N; ++i)
-                for (size_t z = 0; z < Z; ++z) zone_state[i * Z + z] = (int32_t)((v[i] >> z) & 1u);
-        }
+        for (size_t i = 0; i < N; ++i)
+            for (size_t z = 0; z < Z; ++z)
+                zone_state[i * Z + z] = h->cfg.task == ZENV_TASK_COLOUR_MATCH ? (int32_t)((hc[i].colpack >> (2 * z)) & 3ull)
+                                                                               : (int32_t)((ha[i].vis >> z) & 1u);
     }
     if (cooldown) {
         const size_t ZW = (Z + 7) / 8;
-        std::vector<uint8_t> cd(ZW * 8 * N);
+        std::vector<uint8_t> cd(std::max<size_t>(1, ZW - 1) * 8 * N);      // zones 8 and up
         HIP_TRY(hipMemcpy(cd.data(), p.cooldown, cd.size(), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < N; ++i)
-            for (size_t z = 0; z < Z; ++z) cooldown[i * Z + z] = cd[((z >> 3) * N + i) * 8 + (z & 7)];
+            for (size_t z = 0; z < Z; ++z)
+                cooldown[i * Z + z] = z < 8 ? (int32_t)((hc[i].cd0 >> (8 * z)) & 0xFFull) : cd[(((z >> 3) - 1) * N + i) * 8 + (z & 7)];
     }
-    if (steps) HIP_TRY(hipMemcpy(steps, p.steps, N * 4, hipMemcpyDeviceToHost));
+    if (steps)
+        for (size_t i = 0; i < N; ++i) steps[i] = ha[i].steps;
     return ZENV_OK;
 }
