@@ -2031,6 +2031,12 @@ extern "C" int zenv_get_state(zenv_t *h, void *dst, int64_t bytes)
     for (const Alloc &a : h->allocs) {
         if (!a.is_state) continue;
         HIP_TRY(hipMemcpy(out, *a.slot, a.bytes, hipMemcpyDefault));
+        if (a.slot == (void **)&h->p.sched) {
+            // the reset hint rides in the schedule record but is a prefetch hint, not state (the persistent kernel
+            // does not maintain it): snapshots of equal states are equal bytes
+            Sched *sc = reinterpret_cast<Sched *>(out);
+            for (int i = 0; i < h->n_env; ++i) sc[i].reset_hint = -1;
+        }
         out += a.bytes;
     }
     return ZENV_OK;
