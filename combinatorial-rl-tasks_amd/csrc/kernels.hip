@@ -21,8 +21,6 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
-#include <cstdlib>
-
 #include "det_math.hpp"
 #include "dev_params.hpp"
 #include "kernels.hpp"
@@ -1427,419 +1425,6 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                      "v"(pf[7]), "v"(pf[8]), "v"(pf[9]), "v"(pf[10]));
         ZSTAMP(13);
     }
-}
-
-// =========================================================================== K1 (round 4): rows first
-// k_step_lane above finishes the whole env logic before it starts to move the tile's rows: set_mocaps(), reward,
-// termination and auto-reset sit between the wave's loads (landed ~2 us into the launch) and the start of the row
-// stream (~5 us), and the stream -- 38 KB per tile, chip-wide 39 MB at the store path's ~10 TB/s -- is the launch's
-// longest phase.  But a step changes AT MOST ONE zone row of an env (the zone visited / cycled in this step; every
-// cooldown's decrement and every deadline's (tmax - k) are known before the pose is), so the rows can go out from the
-// PRE-step state at once and the one row a step changes is rewritten behind them.  Same two waves per tile, K1p's split:
-//   wave 0, "stream wave": loads the zone positions (+ deadlines), takes the env's state words from the env wave
-//       (barrier 1), builds the tile's entries in LDS (barrier 1b), streams the rows; after the env wave's verdicts
-//       (barrier 2) and once its own stores have landed (vmcnt(0): a rewrite never overtakes the stream) it rewrites the
-//       changed rows and performs the auto-resets (wave-cooperative, as before), whose rows it writes directly.
-//   wave 1, "env wave": pose, action, the env's three records; set_mocaps() on the LDS entries, reward / goal /
-//       termination, the ten substeps, obs, the fused action source, the records -- everything a step computes.
-// Results are bit-identical to k_step_lane (same device functions, same order of the float64 operations).
-// Compiled zone counts only; the runtime-Z fallback stays on k_step_lane<TASK, 0>.
-struct __attribute__((aligned(16))) StepWords {     // env wave -> stream wave (barrier 1)
-    uint64_t w0;          // TSP / TimedTSP: visited mask | (step index after this call) << 32; ColourMatch: packed colours
-    uint64_t cd[4];       // ColourMatch: cooldown bytes AFTER this step's decrement
-    int32_t zero_rows;    // the env's rows are all zero (finished and left alone) -- or about to be rewritten by a reset
-    int32_t pad;
-};
-struct __attribute__((aligned(16))) StepVerdict {   // env wave -> stream wave (barrier 2)
-    int32_t first;        // zone whose row changed in this step (its LDS entry holds the new row), -1: none
-    int32_t need_reset;
-    int32_t nslot, epi;   // the env's schedule position (for the reset)
-};
-
-template <int TASK, int ZT>
-__global__ __launch_bounds__(kStepThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_step_lane2(DevParams p, const float *__restrict__ actions, int auto_reset, StepPolicy pol)
-{
-    static_assert(ZT > 0 && ZT <= 32, "compiled zone counts only");
-    extern __shared__ __align__(16) float4 lds4[];
-    warm_kernarg<sizeof(DevParams) + 8 + 8 + sizeof(StepPolicy)>();
-    constexpr int F = TaskTraits<TASK>::F;
-    constexpr int G = TaskTraits<TASK>::G;
-    constexpr int Z = ZT;
-    constexpr int ZH = (ZT + 1) / 2;
-    constexpr int ZW = (ZT + 7) / 8;
-    constexpr bool kColour = TASK == ZENV_TASK_COLOUR_MATCH;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
-    const int env0 = blockIdx.x * kWave;
-    const int env = env0 + lane;
-    const int N = p.N;
-    const bool valid = env < N;
-    const int envl = valid ? env : N - 1;
-    float4 *ents = lds4;                                  // [64][Z] compact entries
-    float4 *stage = lds4 + kWave * Z;                     // [64*G]  flush staging slab
-    StepWords *xw = reinterpret_cast<StepWords *>(stage + kWave * G);
-    StepVerdict *xv = reinterpret_cast<StepVerdict *>(xw + kWave);
-    float4 *my_ents = ents + lane * Z;
-    const uint32_t full = (Z >= 32) ? 0xFFFFFFFFu : ((1u << Z) - 1u);
-
-    if (role == 0) {
-        // =================================================================== stream wave
-        float4 zp[ZH];
-        int tm[ZT];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int h = 0; h < ZH; ++h) zp[h] = p.zpf[(size_t)h * N + envl];   // 1 KiB per wave
-#pragma unroll
-        for (int z = 0; z < ZT; ++z) tm[z] = TASK == ZENV_TASK_TIMED_TSP ? p.tmax[(size_t)z * N + envl] : 0;
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                                  // 1: the env wave's state words
-        {
-            const StepWords st = xw[lane];
-            const uint32_t vis = (uint32_t)st.w0;
-            const int k = (int)(uint32_t)(st.w0 >> 32);
-#pragma unroll
-            for (int z = 0; z < ZT; ++z) {
-                const float4 pr = zp[z >> 1];
-                float4 en = make_float4((z & 1) ? pr.z : pr.x, (z & 1) ? pr.w : pr.y, 0.f, 0.f);
-                if (kColour) {
-                    const int cd = (int)((st.cd[z >> 3] >> (8 * (z & 7))) & 0xFFull);
-                    en.z = (float)(int)((st.w0 >> (2 * z)) & 3ull);
-                    en.w = (float)div_const((double)(float)cd, p.d_maxcd, p.inv_maxcd);
-                } else {
-                    const bool v = (vis >> z) & 1u;
-                    en.z = v ? 1.f : 0.f;
-                    if (TASK == ZENV_TASK_TIMED_TSP)
-                        en.w = v ? 1.f : (float)div_const((double)(tm[z] - k), p.d_steps, p.inv_steps);
-                }
-                if (st.zero_rows) en = make_float4(0.f, 0.f, -1.f, 0.f);
-                my_ents[z] = en;
-            }
-        }
-        __syncthreads();                                  // 1b: the tile's entries are in LDS
-        const int n_blk = min(kWave, N - env0);
-        flush_entries<TASK, StorePolicy<ZT * F>::kStep>(ents, stage, p.zone_obs + (size_t)env0 * Z * F, n_blk * Z, lane);
-        __syncthreads();                                  // 2: the env wave's verdicts
-        const StepVerdict v = xv[lane];
-        if (__ballot(valid && (v.first >= 0 || v.need_reset)) == 0ull) return;     // nothing of this tile changed
-        // no rewrite overtakes the stream: every store of this wave has landed before a row is written a second time
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (valid && v.first >= 0 && !v.need_reset) {
-            float row[7];
-            expand_entry<TASK>(my_ents[v.first], row);
-            float *dst = p.zone_obs + ((size_t)env * Z + v.first) * F;
-#pragma unroll
-            for (int f = 0; f < F; ++f) dst[f] = row[f];
-        }
-        // ---- auto-reset (penv.py:8-11), wave-cooperative: lane z fetches zone z of the finished env's next layout
-        const bool need_reset = valid && v.need_reset != 0;
-        unsigned long long pending = __ballot(need_reset);
-        if (pending) {
-            Sched sc{ v.nslot, v.epi, -1, 0u };
-            int my_slot = 0;
-            if (need_reset) my_slot = next_bank_slot_rec(p, env, sc);
-            while (pending) {
-                const int j = __ffsll((long long)pending) - 1;   // wave-uniform
-                pending &= pending - 1;
-                const int slot = __shfl(my_slot, j);
-                const int env_j = env0 + j;
-                const double *br = p.bank_robot + 4 * (size_t)slot;
-                const double b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];   // same address in every lane
-                int code = kColour ? 0 : (int)((p.vis0 >> (lane & 31)) & 1u);   // pre-visited zones
-                float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (lane < Z) {
-                    const size_t bi = (size_t)slot * Z + lane;
-                    const double2 zz = reinterpret_cast<const double2 *>(p.bank_zone)[bi];
-                    const size_t zi = (size_t)lane * N + env_j;
-                    p.zxy[zi] = zz;
-                    int aux = 0;
-                    if (TASK == ZENV_TASK_TIMED_TSP) {
-                        aux = p.bank_aux[bi];
-                        p.tmax[zi] = aux;
-                    } else if (kColour) {
-                        code = p.bank_aux[bi];
-                    }
-                    en = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
-                    GlobalRowSink{ p.zone_obs + (size_t)env_j * Z * F }.template put<TASK>(lane, en);
-                }
-                {
-                    const float nx = __shfl_down(en.x, 1), ny = __shfl_down(en.y, 1);
-                    if (lane < Z && !(lane & 1))
-                        p.zpf[(size_t)(lane >> 1) * N + env_j] =
-                            make_float4(en.x, en.y, lane + 1 < Z ? nx : 0.f, lane + 1 < Z ? ny : 0.f);
-                }
-                uint64_t colpack = 0ull;
-                if (kColour) {
-                    const unsigned long long m0 = __ballot(lane < Z && (code & 1));
-                    const unsigned long long m1 = __ballot(lane < Z && (code & 2));
-                    colpack = spread_even_bits((uint32_t)m0) | (spread_even_bits((uint32_t)m1) << 1);
-                }
-                float of[8];
-                const float4 f2 = load_bank_first(p, slot, of);
-                float2 next_act = make_float2(f2.x, f2.y);
-                if (pol.policy == ZENV_POLICY_UNIFORM)
-                    next_act = uniform_action(pol.env_index0 + (uint64_t)env_j, pol.step_index, pol.seed);
-                if (lane == j) {
-                    EnvRegs fresh;
-                    fresh.x0 = b0; fresh.y0 = b1; fresh.bq0 = b2; fresh.bq3 = b3;
-                    fresh.q0 = fresh.q1 = fresh.q2 = 0.0;
-                    fresh.v0 = fresh.v1 = fresh.v2 = 0.0;
-                    p.hota[env] = HotA{ 0.0, 0, kColour ? (uint32_t)hamming_to_goal(colpack, Z) : p.vis0 };
-                    if (kColour) {
-                        p.hotc[env] = HotC{ colpack, 0ull };
-#pragma unroll
-                        for (int w = 1; w < ZW; ++w) *cd_word(p, w, env) = 0ull;
-                    }
-                    p.sched[env] = sc;
-                    p.seed[env] = p.bank_seed[slot];
-                    store_frame(p, env, fresh);
-                    store_dyn(p, env, fresh);
-                    store_obs8(p, env, of);
-                    if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = next_act;
-                }
-            }
-        }
-        return;
-    }
-
-    // ======================================================================= env wave
-    EnvRegs e;
-    Sched sc;
-    HotA ha;
-    uint64_t cdw[ZW];
-    float2 act;
-    {
-        const double2 qa = p.qa[envl], fa = p.fa[envl], fb = p.fb[envl];      // the pose first
-        sc = p.sched[envl];
-        ha = p.hota[envl];
-        e.colpack = 0ull;
-        if (kColour) {
-            const HotC hc = p.hotc[envl];
-            e.colpack = hc.colpack;
-            cdw[0] = hc.cd0;
-#pragma unroll
-            for (int w = 1; w < ZW; ++w) cdw[w] = *cd_word(p, w, envl);
-        }
-        act = reinterpret_cast<const float2 *>(actions)[envl];
-        const double2 qb = p.qb[envl], qc = p.qc[envl];
-        e.q0 = qa.x; e.q1 = qa.y; e.q2 = qb.x;
-        e.v0 = qb.y; e.v1 = qc.x; e.v2 = qc.y;
-        e.x0 = fa.x; e.y0 = fa.y; e.bq0 = fb.x; e.bq3 = fb.y;
-    }
-    const bool was_done = sc.done_state != 0;
-    const bool live = valid && !was_done;
-    e.steps = ha.steps;
-    e.vis = kColour ? 0u : ha.vis;
-    e.goal_dist = kColour ? (int32_t)ha.vis : 0;
-    double ep_ret = ha.ep_return;
-    const int k = e.steps + 1;   // step index after this call
-    if (kColour) {
-#pragma unroll
-        for (int w = 0; w < ZW; ++w) cdw[w] = cd_decrement(cdw[w]);   // colour_match_env.py:98-100, all zones
-    }
-    {
-        StepWords st;
-        st.w0 = kColour ? e.colpack : ((uint64_t)e.vis | ((uint64_t)(uint32_t)k << 32));
-#pragma unroll
-        for (int w = 0; w < 4; ++w) st.cd[w] = (kColour && w < ZW) ? cdw[w] : 0ull;
-        st.zero_rows = (valid && was_done) ? 1 : 0;     // left alone: zero rows; revived by this step: the reset rewrites them
-        st.pad = 0;
-        xw[lane] = st;
-    }
-    __syncthreads();                                      // 1
-    // the previous launch's reset hint: touch every cache line of the bank slot this env may reset into
-    int pf[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    {
-        const int hint = (auto_reset && valid) ? sc.reset_hint : -1;
-        if (hint >= 0 && hint < p.bank_size) {
-            const int *bz = reinterpret_cast<const int *>(p.bank_zone + 2 * (size_t)hint * Z);
-            pf[0] = bz[0];
-            if (4 * Z > 32) pf[1] = bz[32];
-            if (4 * Z > 64) pf[2] = bz[64];
-            if (4 * Z > 96) pf[3] = bz[96];
-            pf[4] = bz[4 * Z - 1];
-            pf[5] = reinterpret_cast<const int *>(p.bank_robot + 4 * (size_t)hint)[0];
-            if (TASK != ZENV_TASK_TSP) {
-                const int *ba = p.bank_aux + (size_t)hint * Z;
-                pf[6] = ba[0];
-                pf[7] = ba[Z - 1];
-            }
-            pf[8] = (int)p.bank_seed[hint];
-            pf[9] = reinterpret_cast<const int *>(p.bank_first + 3 * (size_t)hint)[0];
-            pf[10] = reinterpret_cast<const int *>(p.bank_first + 3 * (size_t)hint)[11];
-        }
-    }
-    double rx, ry;               // pre-physics pose: what set_mocaps() sees
-    world_pos(e, rx, ry);
-    __syncthreads();                                      // 1b: the entries are in LDS
-
-    float rew_out = 0.f;
-    uint8_t done_out = 1, goal_out = 0;
-    bool need_reset = false, timed_out = false, ends_soon = false, exc = false;
-    int first = -1;
-    if (valid && was_done && auto_reset) need_reset = true;     // left finished: the worker's `if done: obs = env.reset()`
-    if (live) {
-        // ---- set_mocaps() of the first substep, on the LDS entries (see k_step_lane for the float32 prefilter)
-        const float rxf = (float)rx, ryf = (float)ry;
-        uint32_t in_mask = 0u, amb_mask = 0u, elig_mask = 0u, expired = 0u, expiring = 0u;
-        const float f_one_step = (float)div_const(1.0, p.d_steps, p.inv_steps);
-#pragma unroll
-        for (int z = 0; z < ZT; ++z) {
-            const float4 en = my_ents[z];
-            const float dxf = __builtin_fmaf(3.f, en.x, -rxf), dyf = __builtin_fmaf(3.f, en.y, -ryf);
-            const float d2f = __builtin_fmaf(dxf, dxf, dyf * dyf);
-            const bool in_sure = d2f < p.d2_lo, out_sure = d2f > p.d2_hi;
-            in_mask |= (in_sure ? 1u : 0u) << z;
-            amb_mask |= ((in_sure || out_sure) ? 0u : 1u) << z;
-            if (kColour) {
-                const int cd = (int)((cdw[z >> 3] >> (8 * (z & 7))) & 0xFFull);
-                elig_mask |= (cd == 0 ? 1u : 0u) << z;
-            } else if (TASK == ZENV_TASK_TIMED_TSP) {
-                // the row's time feature is RN((tmax - k) / num_steps), or 1 once visited: its sign is (tmax - k)'s
-                expired |= (en.w <= 0.f ? 1u : 0u) << z;                 // TTSP_env.py:67
-                expiring |= (en.w <= f_one_step ? 1u : 0u) << z;
-            }
-        }
-        if (amb_mask & full) {
-            uint32_t m = amb_mask & full;
-            while (m) {
-                const int z = __ffs((int)m) - 1;
-                m &= m - 1;
-                const double2 zz = p.zxy[(size_t)z * N + env];
-                const double dx = zz.x - rx, dy = zz.y - ry;
-                if (dx * dx + dy * dy <= p.hit_d2) in_mask |= 1u << z;
-            }
-        }
-        if (!kColour) elig_mask = ~e.vis;
-        const uint32_t hits = in_mask & elig_mask & full;
-        first = hits ? __ffs((int)hits) - 1 : -1;                // lowest index wins, one per step
-        if (first >= 0) {
-            float *slot = reinterpret_cast<float *>(my_ents + first);
-            if (kColour) {
-                int col = (int)((e.colpack >> (2 * first)) & 3ull);
-                col = (col == 2) ? 0 : col + 1;                  // Blue->Green->Red->Blue
-                e.colpack = (e.colpack & ~(3ull << (2 * first))) | ((uint64_t)col << (2 * first));
-#pragma unroll
-                for (int w = 0; w < ZW; ++w)
-                    if ((first >> 3) == w)
-                        cdw[w] = (cdw[w] & ~(0xFFull << (8 * (first & 7)))) | ((uint64_t)p.max_cd << (8 * (first & 7)));
-                slot[2] = (float)col;
-                slot[3] = (float)div_const((double)(float)p.max_cd, p.d_maxcd, p.inv_maxcd);
-            } else {
-                e.vis |= 1u << first;
-                slot[2] = 1.f;
-                if (TASK == ZENV_TASK_TIMED_TSP) slot[3] = 1.f;
-            }
-        }
-        if (TASK == ZENV_TASK_TIMED_TSP) {
-            timed_out = (expired & ~e.vis & full) != 0u;
-            ends_soon = (expiring & ~e.vis & full) != 0u;
-        }
-        // ---- reward / goal / termination (Engine.step order; none of it needs the physics)
-        exc = !(act.x == act.x && act.y == act.y);
-        double r = 0.0;
-        bool goal = false;
-        bool done = false;
-        if (exc) {
-            r = p.reward_exc;
-            done = true;
-        } else if (kColour) {
-            if (first >= 0) {
-                const int nd = hamming_to_goal(e.colpack, Z);
-                r = (double)(e.goal_dist - nd);
-                e.goal_dist = nd;
-            }
-            goal = e.goal_dist == 0;
-        } else {
-            r = first >= 0 ? 1.0 : 0.0;
-            goal = (e.vis & full) == full;
-        }
-        if (goal) {
-            r += (double)(p.num_steps - e.steps) * p.tsr;   // pre-increment steps
-            done = true;
-            goal_out = 1;
-        }
-        e.steps = k;
-        if (k >= p.num_steps) done = true;
-        if (TASK == ZENV_TASK_TIMED_TSP && !done && timed_out) done = true;
-        ep_ret = ep_ret + r;
-        rew_out = (float)r;
-        done_out = done ? 1 : 0;
-        p.visit_count[env] = kColour ? e.goal_dist : __popc(e.vis);
-        if (done) {
-            p.last_return[env] = ep_ret;
-            p.last_len[env] = k;
-            p.episodes[env] += 1;
-            p.exception[env] = exc ? 1 : 0;
-            if (auto_reset) need_reset = true;
-            else sc.done_state = 1;
-        }
-        const int open_zones = kColour ? e.goal_dist : Z - (int)__popc(e.vis);
-        ends_soon = !done && (ends_soon || k + 1 >= p.num_steps || open_zones <= (kColour ? 2 : 1));
-    }
-    if (valid) {
-        // the verdict first: the stream wave may be waiting for it
-        xv[lane] = StepVerdict{ first, need_reset ? 1 : 0, sc.next_slot, sc.episode_idx };
-        // ---- the env's records (an env about to be reset gets fresh ones from the stream wave)
-        if (!need_reset) {
-            if (live) {
-                p.hota[env] = HotA{ ep_ret, e.steps, kColour ? (uint32_t)e.goal_dist : e.vis };
-                if (kColour) {
-                    p.hotc[env] = HotC{ e.colpack, cdw[0] };
-#pragma unroll
-                    for (int w = 1; w < ZW; ++w) *cd_word(p, w, env) = cdw[w];
-                }
-            }
-            sc.reset_hint = (ends_soon && auto_reset && p.sched_mode != SCHED_FIXED_SEEDS) ? sc.next_slot : -1;
-            p.sched[env] = sc;
-        }
-        if (p.visit_zone) p.visit_zone[env] = first;
-        p.reward[env] = rew_out;
-        p.done_out[env] = done_out;
-        p.goal_met[env] = goal_out;
-    } else {
-        xv[lane] = StepVerdict{ -1, 0, 0, 0 };
-    }
-
-    // ---- Engine.step: ctrl = clip(action, ctrlrange); frameskip x mj_step
-    float o[8];
-    if (valid) {
-        const double c0 = det_clamp((double)act.x, -1.0, 1.0);
-        const double c1 = det_clamp((double)act.y, -1.0, 1.0);
-        {
-            double hs, hc;
-            det_sincos_inl(0.5 * e.q2, hs, hc);
-            physics_step(p, e, c0, c1, hs, hc, p.frameskip == ZENV_SUBSTEP_UNROLL);
-        }
-        if (!(c0 == c0 && c1 == c1)) {
-            // exception path: what mj_resetData leaves -- qpos = qpos0, qvel = 0
-            e.q0 = e.q1 = e.q2 = 0.0;
-            e.v0 = e.v1 = e.v2 = 0.0;
-        }
-        if (live && !need_reset) {
-            emit_obs8(p, e, o);
-            store_dyn(p, env, e);
-            store_obs8(p, env, o);
-            // fused K3: the action of the NEXT step, from this step's obs and the (updated) entries in LDS
-            if (pol.policy >= 0)
-                reinterpret_cast<float2 *>(pol.out)[env] = scripted_action<TASK, ZT>(pol, env, my_ents, Z, o);
-        } else if (need_reset) {
-            if (p.term_xy) {
-                double tx, ty;
-                world_pos(e, tx, ty);           // where the finished episode ended (TSP_next_city_env.py:63-66)
-                p.term_xy[env] = make_double2(tx, ty);
-            }
-        } else {
-            // finished earlier and left alone (step_no_reset): WaitWrapper.step's zero obs (wrappers.py:34-45)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = 0.f;
-            store_obs8(p, env, o);
-            if (pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = make_float2(0.f, 0.f);
-        }
-    }
-    asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]),
-                 "v"(pf[7]), "v"(pf[8]), "v"(pf[9]), "v"(pf[10]));
-    __syncthreads();                                      // 2: verdicts (and the updated entries) are in LDS
 }
 
 // =========================================================================== K1p: persistent rollout
@@ -3274,37 +2859,11 @@ static inline size_t step_lds_bytes(const DevParams &p)
            kWave * sizeof(double2) + kWave * sizeof(int);       // + the pose / exception hand-over
 }
 
-static inline size_t step2_lds_bytes(const DevParams &p)
-{
-    const int G = p.F == 6 ? (ZENV_RPC6 * 6) / 4 : 7;
-    return (size_t)kWave * p.Z * sizeof(float4) + (size_t)kWave * G * sizeof(float4) + kWave * sizeof(StepWords) +
-           kWave * sizeof(StepVerdict);
-}
-
-// (diagnostic: ZENV_K1_OLD=1 keeps the compiled zone counts on the round-3 kernel, for same-box A/Bs)
-static const bool kUseOldStepKernel = [] { const char *e = std::getenv("ZENV_K1_OLD"); return e && e[0] == '1'; }();
-
 template <int TASK>
 static void launch_step_task(const DevParams &p, const float *actions, int auto_reset, const StepPolicy &pol,
                              hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const dim3 grid(n_blocks(p.N)), block(kStepThreads);
-    if (!kUseOldStepKernel) {
-        const size_t lds2 = step2_lds_bytes(p);
-#define ZENV_LAUNCH2(ZT)                                                                                     \
-        hipExtLaunchKernelGGL((k_step_lane2<TASK, ZT>), grid, block, lds2, s, ev_start, ev_stop, 0, p, actions, \
-                              auto_reset, pol)
-        switch (p.Z) {
-        case 5: ZENV_LAUNCH2(5); return;
-        case 6: ZENV_LAUNCH2(6); return;
-        case 10: ZENV_LAUNCH2(10); return;
-        case 15: ZENV_LAUNCH2(15); return;
-        case 20: ZENV_LAUNCH2(20); return;
-        case 25: ZENV_LAUNCH2(25); return;
-        default: break;
-        }
-#undef ZENV_LAUNCH2
-    }
     const size_t lds = step_lds_bytes(p);
     // hipExtLaunchKernelGGL stamps ev_start/ev_stop with the dispatch's own begin/end
 #define ZENV_LAUNCH(ZT)                                                                                   \
