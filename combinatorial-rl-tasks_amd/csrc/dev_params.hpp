@@ -56,6 +56,7 @@ struct DevParams {
     int32_t order_fresh;  // solver-ordered variant: 1 = an episode's first observation shows its own route (opt-out, see K7)
     double hit_d2;        // largest d2 with sqrt(d2) <= zones_size
     float d2_lo, d2_hi;   // float32 prefilter shell around zones_size^2 (see kernels.hip)
+    float d2_near, pad_near;   // (zones_size + what the robot can travel in one env step)^2: "a zone could be hit at the NEXT step"
     double tsr;           // time_saved_reward
     double reward_exc;    // Engine 'reward_exception'
     double inv3, inv1_5;  // RN(1/3), RN(1/1.5)

@@ -1038,6 +1038,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         int mode = 1;
         bool need_reset = false;
         bool ends_soon = false;   // may terminate at the NEXT step: its bank rows get prefetched below
+        uint32_t near_mask = 0u;  // zones the robot could be inside at the next step (within radius + one step of travel)
         bool timed_out = false;
         int first = -1;
         const int k = e.steps + 1;   // step index after this call
@@ -1091,6 +1092,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 const bool in_sure = d2f < p.d2_lo, out_sure = d2f > p.d2_hi;
                 in_mask |= (in_sure ? 1u : 0u) << z;
                 amb_mask |= ((in_sure || out_sure) ? 0u : 1u) << z;
+                near_mask |= (d2f < p.d2_near ? 1u : 0u) << z;
                 float4 en = make_float4(x3, y3, 0.f, 0.f);
                 if (TASK == ZENV_TASK_COLOUR_MATCH) {
                     int cd = aux;
@@ -1205,9 +1207,13 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             }
             // next step ends the episode for sure (time limit / a deadline) or possibly (one zone
             // left; ColourMatch: one cycle from the goal)
+            // ... AND the robot is near a zone whose visit could do it: "one zone left" / "within one cycle of the goal"
+            // hold for tens to hundreds of steps, and every hinted env costs the next launch eleven cache lines of its
+            // bank slot (round 4 PMC: ColourMatch-6 fetched 24 MB per step against 12 MB of state, the rest was this)
             const int open_zones = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : Z - (int)__popc(e.vis);
+            const uint32_t could_hit = (TASK == ZENV_TASK_COLOUR_MATCH) ? (near_mask & full) : (near_mask & ~e.vis & full);
             ends_soon = !done && (ends_soon || k + 1 >= p.num_steps ||
-                                  open_zones <= (TASK == ZENV_TASK_COLOUR_MATCH ? 2 : 1));
+                                  (open_zones <= (TASK == ZENV_TASK_COLOUR_MATCH ? 2 : 1) && could_hit != 0u));
         }
 
         ZSTAMP(6);
@@ -1765,6 +1771,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
     // 8-float obs as the tile's [128] float4 (its 2 KiB of p.obs, in order) and one float4 (reward, flags, visit count, -)
     float4 *obs_pub = reinterpret_cast<float4 *>(kColour ? reinterpret_cast<char *>(cdtab + 256) : reinterpret_cast<char *>(ctr + 4));   // [2][128]
     float4 *misc_pub = obs_pub + 2 * 2 * kWave;                                                                                         // [2][64]
+    float *act_touch = reinterpret_cast<float *>(misc_pub + 2 * kWave);      // EXT: [64] landing pad of the action prefetch (never read)
     const RowTables rt{ coltab, cdtab };
     if (kColour) {                                                       // both waves fill, before the launch's barrier
         for (int i = threadIdx.x; i < 256; i += 2 * kWave)
@@ -1783,8 +1790,30 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         // =================================================================== stream wave
         if (kStreamFirst) __builtin_amdgcn_s_setprio(3);
         __syncthreads();   // static entries of the first step + cleared counters
+        // EXT: the caller's action rows are read ONCE, from memory, beside a store stream that saturates the memory system:
+        // a read issued one step ahead (the env wave's) comes back after more than a step (measured: the same kernel
+        // fetching a cache-resident row runs at the scripted kernel's speed, 6.3 vs 7.6 us per step on TimedTSP-25).
+        // This wave, which never waits for a load, pulls row t + kActAhead of the tile into the XCD's L2 kActAhead steps
+        // early -- an LDS-DMA into a pad nobody reads: no destination register, no wait -- and the env wave's own load
+        // hits L2.  Written as assembly on purpose: the compiler orders every later LDS read behind a DMA it knows about
+        // with s_waitcnt vmcnt(0), which here would drain this wave's whole store queue once per step.
+#if defined(ZENV_ACT_AHEAD)               // diagnostic builds: the prefetch distance (0 = no prefetch)
+        constexpr int kActAhead = ZENV_ACT_AHEAD;
+#else
+        constexpr int kActAhead = 8;
+#endif
+        const uint32_t touch_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)act_touch;
+        auto touch_row = [&](int row) {
+            const float *src = reinterpret_cast<const float *>(io.actions + (size_t)row * (size_t)N + min(env, N - 1));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(touch_lds) : "m0");
+        };
+        if (EXT && kActAhead > 0) {
+#pragma unroll 1
+            for (int r = 1; r < kActAhead && r < n_steps; ++r) touch_row(r);
+        }
         for (int t = 0; t < n_steps; ++t) {
             if (t == (n_steps >> 1)) ZSTAMP(8);
+            if (EXT && kActAhead > 0 && t + kActAhead < n_steps) touch_row(t + kActAhead);
             lds_ctr_wait(ctr + 0, t + 1);                 // published(t)
             if (t == (n_steps >> 1)) ZSTAMP(9);
             const int b = t & 1;
@@ -1823,6 +1852,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
             if (t == (n_steps >> 1) - 1) ZSTAMP(11);
             if (t == (n_steps >> 1)) ZSTAMP(10);
         }
+        if (EXT) asm volatile("s_waitcnt vmcnt(0)");   // no prefetch may land in LDS after the workgroup has left
         return;
     }
 
@@ -1937,11 +1967,11 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         float2 act_next = act;
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 32)      // diagnostic: bit 5 drops the action fetch (a_0 is held for the whole launch)
         if (EXT && t + 1 < n_steps) {
-            {   // read once, never again: non-temporal (a 2 048-step replay: 6.40 -> 6.19 us per step with the records' stores)
-                typedef float v2f_t __attribute__((ext_vector_type(2)));
-                const v2f_t v = __builtin_nontemporal_load(reinterpret_cast<const v2f_t *>(io.actions + (size_t)(t + 1) * (size_t)N + envl));
-                act_next = make_float2(v.x, v.y);
-            }
+#if defined(ZENV_EXP) && (ZENV_EXP & 64)      // diagnostic: bit 6 fetches row 0 every step (always cache-resident)
+            act_next = io.actions[envl];
+#else
+            act_next = (io.actions + (size_t)(t + 1) * (size_t)N)[envl];     // in L2 since the stream wave's touch
+#endif
             asm volatile("" ::: "memory");      // issued HERE: the scheduler may not sink the load towards its use
         }
 #endif
@@ -2918,7 +2948,8 @@ static inline size_t rollout_lds_bytes(const DevParams &p)
            + (p.task == ZENV_TASK_COLOUR_MATCH ? 2 * (size_t)kWave * ZB : 0)       // cooldown bytes
            + 4 * sizeof(int)                                                       // counters
            + (p.task == ZENV_TASK_COLOUR_MATCH ? 4 * sizeof(float4) + 256 * sizeof(float) : 0)    // row tables
-           + 2 * (2 * kWave + kWave) * sizeof(float4);                             // published obs + (reward, flags, count)
+           + 2 * (2 * kWave + kWave) * sizeof(float4)                              // published obs + (reward, flags, count)
+           + kWave * sizeof(float);                                                // action prefetch pad (EXT)
 }   // (allocated for every kernel; the ones whose env wave issues its own stores leave it unused)
 
 bool rollout_kernel_available(const DevParams &p)

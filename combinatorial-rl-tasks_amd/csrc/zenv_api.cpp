@@ -214,6 +214,15 @@ void derive_constants(const zenv_config &c, DevParams &p)
         p.d2_lo = std::nextafterf((float)lo, 0.f);
         p.d2_hi = std::nextafterf((float)hi, INFINITY);
     }
+    {
+        // reset-prefetch hint (k_step_lane): a zone can only be hit at the NEXT step if the robot is within its radius +
+        // one env step of travel NOW.  Terminal speed gear * forcerange / damping, 1.5x for transients; undamped: always near
+        const double b = std::min(c.damping[0], c.damping[1]);
+        const double v = b > 0 ? std::fabs(c.gear) * c.forcerange / b : INFINITY;
+        const double reach = c.zones_size + 1.5 * v * c.timestep * c.frameskip + 1e-3;
+        p.d2_near = std::isfinite(reach) && reach < 1e3 ? (float)(reach * reach) : INFINITY;
+        p.pad_near = 0.f;
+    }
     p.tsr = c.time_saved_reward;
     p.reward_exc = c.reward_exception;
     p.inv3 = 1.0 / 3.0;

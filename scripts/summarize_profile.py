@@ -14,7 +14,7 @@ import collections, csv, glob, json, os, sys
 
 out = sys.argv[1]
 tag = os.path.basename(os.path.normpath(out))
-KERNELS = ("k_rollout_lane", "k_step_lane", "k_policy_lane", "k_reset_lane", "k_mlp_zone1", "k_mlp_head")
+KERNELS = ("k_rollout_lane_ext", "k_rollout_lane", "k_step_lane", "k_policy_lane", "k_reset_lane", "k_mlp_zone1", "k_mlp_head")
 N_SIMD = 256 * 4
 CHUNK = 256
 SETTLE, WARMUP, STEPS = 6000 - 256, 256, 512      # bench.py --steps 512 --warmup 256 (profile_round.sh)
@@ -23,6 +23,9 @@ BIG_PS_WARMUP, BIG_PS_STEPS = 16, 64               # ... and its per-step passes
 
 
 def short(name):
+    # the action-chunk form of the persistent kernel is its own row (k_rollout_lane<TASK, ZT, true>)
+    if "k_rollout_lane" in name and ("ELb1E" in name or ", true>" in name or ",true>" in name):
+        return "k_rollout_lane_ext"
     for k in KERNELS:
         if k in name:
             return k
