@@ -1790,17 +1790,27 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         // =================================================================== stream wave
         if (kStreamFirst) __builtin_amdgcn_s_setprio(3);
         __syncthreads();   // static entries of the first step + cleared counters
-        // EXT: the caller's action rows are read ONCE, from memory, beside a store stream that saturates the memory system:
-        // a read issued one step ahead (the env wave's) comes back after more than a step (measured: the same kernel
-        // fetching a cache-resident row runs at the scripted kernel's speed, 6.3 vs 7.6 us per step on TimedTSP-25).
-        // This wave, which never waits for a load, pulls row t + kActAhead of the tile into the XCD's L2 kActAhead steps
-        // early -- an LDS-DMA into a pad nobody reads: no destination register, no wait -- and the env wave's own load
-        // hits L2.  Written as assembly on purpose: the compiler orders every later LDS read behind a DMA it knows about
-        // with s_waitcnt vmcnt(0), which here would drain this wave's whole store queue once per step.
-#if defined(ZENV_ACT_AHEAD)               // diagnostic builds: the prefetch distance (0 = no prefetch)
+        // EXT: the caller's action rows are read ONCE, from memory, beside a store stream that saturates the memory system.
+        // Left to the env wave alone (one 512 B row per tile and step, issued a step ahead) that read costs 0.6-1.3 us per
+        // step although it is 1.6 % of the bytes: the same kernel fetching a cache-resident row runs at the scripted
+        // kernel's speed, and a prefetch of ONE row per step, at any distance from 3 to 16 steps, recovers a quarter of
+        // it -- so it is not latency.  What recovers all of it is reading rarely and much: this wave, which never waits
+        // for a load, pulls kActBatch rows of the tile into the XCD's L2 every kActBatch steps (PointTSP-25, 2048 fresh
+        // rows: 6.37 us per step without, 6.16 one row per step, 5.37 eight rows every eighth step; scripted greedy
+        // 5.55 -- profiles/r04/action_prefetch_sweep.log), i.e. the memory controllers turn from writing to reading an
+        // eighth as often.  The touch is an LDS-DMA into a pad nobody reads: no destination register, no wait; the env
+        // wave's own load of the row then hits L2.  It is written as assembly on purpose: the compiler orders every later
+        // LDS read behind a DMA it knows about with s_waitcnt vmcnt(0), which here would drain this wave's whole store
+        // queue once per step.
+#if defined(ZENV_ACT_AHEAD)               // diagnostic builds: the prefetch distance (0 = no prefetch) and batch
         constexpr int kActAhead = ZENV_ACT_AHEAD;
 #else
         constexpr int kActAhead = 8;
+#endif
+#if defined(ZENV_ACT_BATCH)
+        constexpr int kActBatch = ZENV_ACT_BATCH;
+#else
+        constexpr int kActBatch = 8;
 #endif
         const uint32_t touch_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)act_touch;
         auto touch_row = [&](int row) {
@@ -1813,7 +1823,10 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         }
         for (int t = 0; t < n_steps; ++t) {
             if (t == (n_steps >> 1)) ZSTAMP(8);
-            if (EXT && kActAhead > 0 && t + kActAhead < n_steps) touch_row(t + kActAhead);
+            if (EXT && kActAhead > 0 && t % kActBatch == 0) {
+#pragma unroll 1
+                for (int r = t + kActAhead; r < t + kActAhead + kActBatch && r < n_steps; ++r) touch_row(r);
+            }
             lds_ctr_wait(ctr + 0, t + 1);                 // published(t)
             if (t == (n_steps >> 1)) ZSTAMP(9);
             const int b = t & 1;
