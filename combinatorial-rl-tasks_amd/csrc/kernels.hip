@@ -1039,6 +1039,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
         bool need_reset = false;
         bool ends_soon = false;   // may terminate at the NEXT step: its bank rows get prefetched below
         uint32_t near_mask = 0u;  // zones the robot could be inside at the next step (within radius + one step of travel)
+        uint32_t soon_elig = 0u;  // ColourMatch: zones whose cooldown will have run out by then
         bool timed_out = false;
         int first = -1;
         const int k = e.steps + 1;   // step index after this call
@@ -1101,6 +1102,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                         *cd_byte(p, z, env) = (uint8_t)cd;
                     }
                     elig_mask |= (cd == 0 ? 1u : 0u) << z;
+                    soon_elig |= (cd <= 1 ? 1u : 0u) << z;     // triggerable at the NEXT step (after its decrement)
                     en.z = (float)(int)((e.colpack >> (2 * z)) & 3ull);
                     en.w = (float)div_const((double)(float)cd, p.d_maxcd, p.inv_maxcd);
                 } else {
@@ -1133,6 +1135,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                     int col = (int)((e.colpack >> (2 * first)) & 3ull);
                     col = (col == 2) ? 0 : col + 1;                  // Blue->Green->Red->Blue
                     e.colpack = (e.colpack & ~(3ull << (2 * first))) | ((uint64_t)col << (2 * first));
+                    soon_elig &= ~(1u << first);                     // its cooldown starts over
                     if (ZT > 0) {
 #pragma unroll
                         for (int w = 0; w < ZW; ++w)
@@ -1211,9 +1214,9 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             // hold for tens to hundreds of steps, and every hinted env costs the next launch eleven cache lines of its
             // bank slot (round 4 PMC: ColourMatch-6 fetched 24 MB per step against 12 MB of state, the rest was this)
             const int open_zones = (TASK == ZENV_TASK_COLOUR_MATCH) ? e.goal_dist : Z - (int)__popc(e.vis);
-            const uint32_t could_hit = (TASK == ZENV_TASK_COLOUR_MATCH) ? (near_mask & full) : (near_mask & ~e.vis & full);
-            ends_soon = !done && (ends_soon || k + 1 >= p.num_steps ||
-                                  (open_zones <= (TASK == ZENV_TASK_COLOUR_MATCH ? 2 : 1) && could_hit != 0u));
+            // one visit per step moves ColourMatch's distance (cycle steps to the nearest uniform colouring) by one at most
+            const uint32_t could_hit = (TASK == ZENV_TASK_COLOUR_MATCH) ? (near_mask & soon_elig & full) : (near_mask & ~e.vis & full);
+            ends_soon = !done && (ends_soon || k + 1 >= p.num_steps || (open_zones <= 1 && could_hit != 0u));
         }
 
         ZSTAMP(6);

@@ -27,6 +27,10 @@ for w in $workloads; do
     echo "pmc $w $mode done"
   done
 done
+# the action-chunk form of the persistent kernel (zenv_step_many), PointTSP-25
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_chunk -- python scripts/chunk_pmc.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_chunk -- python scripts/chunk_pmc.py > /dev/null 2>&1
+echo "pmc action chunk done"
 # the batch-size sweep of aux.beyond_llc: HBM bytes of both kernels AT each size (per-step output 0.6x .. 7x the LLC)
 for n in ${SWEEP_SIZES:-262144 1048576 3145728}; do
   w="PointTSP-25@$n"

@@ -157,6 +157,23 @@ for w in workloads:                       # "PointTSP-25" (N = 65536) or "PointT
         ps["gpu_clock_ghz"] = pe["gpu_clock_ghz"]
         ps["gpu_cycles_per_step"] = ps["pmc_run_ns_per_step"] * pe["gpu_clock_ghz"]
         ps["clock_note"] = "clock of the persistent launches of the same workload (short dispatches read high)"
+# the action-chunk form (scripts/chunk_pmc.py: 256-step launches of k_rollout_lane<.., EXT> on PointTSP-25, fresh actions)
+ext = {}
+for name, key, scale in (("pmc_fetch_chunk", "FETCH_SIZE", 2048.0), ("pmc_write_chunk", "WRITE_SIZE", 1024.0)):
+    rows = [r for r in counter_rows(name) if short(r["Kernel_Name"]) == "k_rollout_lane_ext"]
+    vals = [v * scale / CHUNK for v in per_dispatch(rows, "k_rollout_lane", key)]
+    if vals:
+        ext[key.lower() + "_per_step"] = sum(vals) / len(vals)
+        ext[key.lower() + "_dispatches"] = len(vals)
+        with open(os.path.join(out, f"{name}_head.csv"), "w") as g:
+            wr = csv.DictWriter(g, fieldnames=list(rows[0].keys()))
+            wr.writeheader()
+            wr.writerows(rows[:4])
+if len(ext) == 4:
+    ext.update({"kernel": "k_rollout_lane<EXT>", "n_env": 65536, "source": f"profiles/{tag}/summary.json",
+                "hbm_bytes_per_step": ext["fetch_size_per_step"] + ext["write_size_per_step"],
+                "method": "scripts/chunk_pmc.py under rocprofv3 --pmc (one counter per run): every 256-step launch / 256"})
+    traffic.setdefault("PointTSP-25@65536", {})["action_chunk"] = ext
 names, sha = kernel_sources_sha()
 traffic["_meta"] = {"kernel_sources": names, "kernel_sources_sha256": sha, "measured_in": f"profiles/{tag}",
                     "note": "bench.py marks the record stale (aux.traffic_stale) and tests/test_bench_contract.py fails "
