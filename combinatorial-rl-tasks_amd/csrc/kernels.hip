@@ -1865,6 +1865,8 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
                 flush_static<TASK, ZT, false>(p, sent, dynw + b * kWave, cdb, stage, tile_dst, n_rows, lane, rt);
 #endif
             lds_ctr_set(ctr + 1, t + 1);                  // flushed(t)
+            if (t == 0) ZSTAMP(6);
+            if (t == n_steps - 1) ZSTAMP(7);
             if (t == (n_steps >> 1) - 1) ZSTAMP(11);
             if (t == (n_steps >> 1)) ZSTAMP(10);
         }
@@ -1873,6 +1875,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
     }
 
     // ======================================================================= env wave
+    ZSTAMP(12);
     if (!kStreamFirst) __builtin_amdgcn_s_setprio(3);
     // Everything the steady state of the loop does not touch -- the bank, the schedule, the state arrays, the episode
     // counters -- is read through the device copy of the parameter block, at the point of use inside the rare
@@ -1968,6 +1971,7 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
     // instructions' SADDR form; per-lane 64-bit pointers walking down the buffers cost the 25-zone kernels, which sit at
     // the 256-register limit, eight more registers and with them scratch spills inside the step loop)
     const int envl = min(env, N - 1);
+    ZSTAMP(13);
     for (int t = 0; t < n_steps; ++t) {
         StepPolicy polt = pol;
         polt.step_index = pol.step_index + (uint32_t)t;
@@ -1975,11 +1979,8 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
         const bool ar_t = auto_reset == 1 || (auto_reset == 2 && t == n_steps - 1);
         // EXT: a_{t+1} is requested now and taken at the END of the step -- the env wave's ONLY vector-memory instruction of
         // a step (everything it produces goes to the stream wave through LDS), so the wait is for this load alone, and it
-        // has the whole step to arrive.  Where the row stream saturates the store path that is still not enough: on
-        // TimedTSP-25 the fetch costs 1.0-1.8 us per step (the same kernel with a_0 held: 6.3 us, with the fetch 7.5-8.3;
-        // PointTSP-25, PointTSP-15, ColourMatch-6: within 5 % of the scripted kernel).  Tried and without effect there:
-        // LDS-DMA with a polled landing pad instead of a counted wait, the load at the stream wave's issue priority, the
-        // env wave first in priority (action chunks)
+        // has the whole step to arrive.  The row is in L2 by then: the stream wave pulled it in, eight rows at a time (see
+        // there -- fetched from memory one row per step beside the saturated row stream, this load cost 0.6-1.9 us per step).
         float2 act_next = act;
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 32)      // diagnostic: bit 5 drops the action fetch (a_0 is held for the whole launch)
         if (EXT && t + 1 < n_steps) {
@@ -2264,10 +2265,12 @@ void k_rollout_lane(DevParams p, int n_steps, int auto_reset, StepPolicy pol, in
     }
 
     // ---- the registers go back to the state arrays (a frozen env's did when it froze, or never left them)
+    ZSTAMP(14);
     if (valid) {
         if (!frozen) write_back(e, ep_ret);
         if (!EXT && pol.policy >= 0) reinterpret_cast<float2 *>(pol.out)[env] = act;
     }
+    ZSTAMP(15);
 }
 
 // =========================================================================== K6: goal shaping
