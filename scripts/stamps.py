@@ -26,8 +26,13 @@ mode = "per_step" if fused else "unfused"      # K1 either way: with its fused a
 env.rollout(warm, Z.POLICY_GREEDY, mode=mode)
 L = nat.lib(); L.zenv_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 acc, kus = [], []
+burst = int([a for a in sys.argv if a.startswith('burst=')][0][6:]) if any(a.startswith('burst=') for a in sys.argv) else 1
 for it in range(20):
-    _, k_ms = env.rollout(1, Z.POLICY_GREEDY, mode=mode, time_step_kernel=True)
+    if burst > 1:       # the LAST launch of a back-to-back burst (no launch ramp of an idle queue); its duration: the burst's mean
+        ms, _ = env.rollout(burst, Z.POLICY_GREEDY, mode=mode)
+        k_ms = ms / burst
+    else:
+        _, k_ms = env.rollout(1, Z.POLICY_GREEDY, mode=mode, time_step_kernel=True)
     kus.append(k_ms * 1e3)
     buf = np.zeros((n // 64, 16), np.uint64)
     nat.check(L.zenv_debug_stamps(env._h, buf.ctypes.data, buf.size))
