@@ -60,15 +60,35 @@ int main(void)
     for (int i = 0; i < 8 * N; ++i) so += obs[i];
     for (int i = 0; i < Z * F * N; ++i) sz += zone_obs[i];
     for (int i = 0; i < N; ++i) sr += reward[i];
+    /* a fixed-length skill as ONE launch (main/src/torch_ac/algos/_hier_policy_opt.py:68-71): 10 steps of pre-computed
+     * actions, skill_len - 1 x step_no_reset then one step; every step's reward and done flag comes back time-major */
+    enum { SKILL = 10 };
+    float *chunk = (float *)malloc(sizeof(float) * 2 * N * SKILL);
+    float *chunk_reward = (float *)malloc(sizeof(float) * N * SKILL);
+    uint8_t *chunk_done = (uint8_t *)malloc((size_t)N * SKILL);
+    for (int t = 0; t < SKILL; ++t)
+        for (int i = 0; i < N; ++i) { chunk[2 * (t * N + i)] = 1.0f; chunk[2 * (t * N + i) + 1] = ((i + t) % 3 - 1) * 0.5f; }
+    CHECK(zenv_step_many(h, chunk, 0, SKILL, ZENV_CHUNK_RESET_LAST));
+    CHECK(zenv_get(h, ZENV_F_CHUNK_REWARD, chunk_reward, 0));
+    CHECK(zenv_get(h, ZENV_F_CHUNK_DONE, chunk_done, 0));
+    double chunk_return = 0.0;
+    int chunk_dones = 0;
+    for (int i = 0; i < N * SKILL; ++i) { chunk_return += chunk_reward[i]; chunk_dones += chunk_done[i]; }
+    CHECK(zenv_get(h, ZENV_F_OBS, obs, 0));
+    CHECK(zenv_get(h, ZENV_F_ZONE_OBS, zone_obs, 0));
+    CHECK(zenv_get(h, ZENV_F_REWARD, reward, 0));
+    double co = 0;
+    for (int i = 0; i < 8 * N; ++i) co += obs[i];
     /* the slab downloaded without stepping holds the same bytes as the field-by-field downloads */
     CHECK(zenv_step_results(h, NULL, 1, slab));
     const int slab_ok = memcmp(slab + off[ZENV_RESULT_OBS], obs, sizeof(float) * 8 * N) == 0 &&
                         memcmp(slab + off[ZENV_RESULT_ZONE_OBS], zone_obs, sizeof(float) * Z * F * N) == 0 &&
                         memcmp(slab + off[ZENV_RESULT_REWARD], reward, sizeof(float) * N) == 0;
-    printf("steps %lld obs_sum %.9f zone_obs_sum %.9f reward_sum %.3f host_return %.3f host_dones %d slab_ok %d\n",
-           (long long)zenv_step_count(h), so, sz, sr, host_return, host_dones, slab_ok);
+    printf("steps %lld obs_sum %.9f zone_obs_sum %.9f reward_sum %.3f host_return %.3f host_dones %d slab_ok %d "
+           "chunk_return %.3f chunk_dones %d chunk_obs_sum %.9f\n",
+           (long long)zenv_step_count(h), so, sz, sr, host_return, host_dones, slab_ok, chunk_return, chunk_dones, co);
     CHECK(zenv_host_free(slab));
     CHECK(zenv_destroy(h));
-    free(actions); free(obs); free(zone_obs); free(reward);
+    free(actions); free(obs); free(zone_obs); free(reward); free(chunk); free(chunk_reward); free(chunk_done);
     return 0;
 }

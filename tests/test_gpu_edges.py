@@ -204,7 +204,17 @@ def test_c_abi_demo_matches_python_path(zenv_mod, tmp_path):
         host_dones += int(env.get(Z.F_DONE).sum())
     env.rollout(100, Z.POLICY_GREEDY, policy_seed=7)
     o, zo, r, _, _ = env.results()
-    assert got["steps"] == 140
+    # the demo's fixed-length skill: 10 pre-computed steps as one zenv_step_many(ZENV_CHUNK_RESET_LAST)
+    chunk = np.zeros((10, n, 2), np.float32)
+    chunk[:, :, 0] = 1.0
+    chunk[:, :, 1] = ((np.arange(n)[None, :] + np.arange(10)[:, None]) % 3 - 1) * 0.5
+    env.step_many(chunk, reset="last")
+    c_rew, c_done = env.chunk_results()
+    c_obs = env.get(Z.F_OBS)
+    assert got["steps"] == 150
+    assert abs(got["chunk_return"] - float(c_rew.astype(np.float64).sum())) < 1e-3
+    assert got["chunk_dones"] == int(c_done.sum())
+    assert abs(got["chunk_obs_sum"] - float(c_obs.astype(np.float64).sum())) < 1e-6
     assert abs(got["obs_sum"] - float(o.astype(np.float64).sum())) < 1e-6
     assert abs(got["zone_obs_sum"] - float(zo.astype(np.float64).sum())) < 1e-6
     assert abs(got["reward_sum"] - float(r.astype(np.float64).sum())) < 1e-6
