@@ -368,8 +368,12 @@ __device__ __forceinline__ float4 make_entry(const DevParams &p, double zx, doub
     return en;
 }
 
-template <int TASK>
-__device__ __forceinline__ void expand_entry(const float4 en, float *row)
+// DEFER (k_step_lane, ColourMatch): the entry's aux slot holds the cooldown COUNT and the division by max_cd (den, inv =
+// RN(1 / den)) happens here, in the flush, where the wave otherwise waits for its stores, instead of once per zone on
+// the zone wave's way to the flush (same-box A/B, ColourMatch-6: 9.32 -> 9.15 us per launch; the same move for
+// TimedTSP's (tmax - k) / num_steps changed nothing -- 25 divisions per lane either way -- and is not made).
+template <int TASK, bool DEFER = false>
+__device__ __forceinline__ void expand_entry(const float4 en, float *row, double den = 1.0, double inv = 1.0)
 {
     const bool zero = en.z < 0.f;
     if (TASK == ZENV_TASK_COLOUR_MATCH) {
@@ -379,7 +383,7 @@ __device__ __forceinline__ void expand_entry(const float4 en, float *row)
         row[3] = en.z == 1.f ? 1.f : 0.f;
         row[4] = en.z == 0.f ? 1.f : 0.f;
         row[5] = zero ? 0.f : 0.25f;
-        row[6] = en.w;
+        row[6] = DEFER ? (float)div_const((double)en.w, den, inv) : en.w;
     } else {
         row[0] = en.x;
         row[1] = en.y;
@@ -607,9 +611,9 @@ struct StorePolicy {
 };
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
-template <int TASK, int AUX>
+template <int TASK, int AUX, bool DEFER = false>
 __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage, float *dst, int n_rows,
-                                              int lane)
+                                              int lane, double den = 1.0, double inv = 1.0)
 {
     constexpr int F = TaskTraits<TASK>::F, RPC = TaskTraits<TASK>::RPC, G = TaskTraits<TASK>::G;
     const int n_chunks = n_rows / RPC;
@@ -625,7 +629,7 @@ __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage,
     float v[RPC * F];
     if (n_full > 0) {
 #pragma unroll
-        for (int j = 0; j < RPC; ++j) expand_entry<TASK>(ents[lane * RPC + j], v + j * F);
+        for (int j = 0; j < RPC; ++j) expand_entry<TASK, DEFER>(ents[lane * RPC + j], v + j * F, den, inv);
     }
     for (int it = 0; it < n_full; ++it, c0 += kWave) {
 #pragma unroll
@@ -639,7 +643,7 @@ __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage,
         if (it + 1 < n_full) {
             const int c = c0 + kWave + lane;
 #pragma unroll
-            for (int j = 0; j < RPC; ++j) expand_entry<TASK>(ents[c * RPC + j], v + j * F);
+            for (int j = 0; j < RPC; ++j) expand_entry<TASK, DEFER>(ents[c * RPC + j], v + j * F, den, inv);
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -653,7 +657,7 @@ __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage,
         if (c < n_chunks) {
             float v[RPC * F];
 #pragma unroll
-            for (int j = 0; j < RPC; ++j) expand_entry<TASK>(ents[c * RPC + j], v + j * F);
+            for (int j = 0; j < RPC; ++j) expand_entry<TASK, DEFER>(ents[c * RPC + j], v + j * F, den, inv);
 #pragma unroll
             for (int g = 0; g < G; ++g)
                 stage[lane * G + g] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
@@ -675,7 +679,7 @@ __device__ __forceinline__ void flush_entries(const float4 *ents, float4 *stage,
     const int r = n_chunks * RPC + lane;
     if (r < n_rows) {
         float v[F];
-        expand_entry<TASK>(ents[r], v);
+        expand_entry<TASK, DEFER>(ents[r], v, den, inv);
         for (int f = 0; f < F; ++f) dst[(size_t)r * F + f] = v[f];
     }
 }
@@ -958,6 +962,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
     double2 *xpose = reinterpret_cast<double2 *>(xstep + kWave);   // physics wave -> zone wave: pre-physics world position
     int *xexc = reinterpret_cast<int *>(xpose + kWave);            //                           and "the action holds a NaN"
     float4 *my_ents = ents + lane * Z;
+    constexpr bool kDefer = TASK == ZENV_TASK_COLOUR_MATCH;   // cooldown / max_cd is left to the flush (expand_entry)
 
     EnvRegs e;
     e.steps = 0;
@@ -1067,13 +1072,20 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
             // inside the shell (about once per 10^7 env-steps) the exact float64 test below
             // decides.  Everything is collected in bit masks; the lowest set bit wins.
             const float rxf = (float)rx, ryf = (float)ry;
-            uint32_t in_mask = 0u, amb_mask = 0u, elig_mask = 0u, expired = 0u, expiring = 0u;
+            uint32_t in_mask = 0u, out_mask = 0u, amb_mask = 0u, elig_mask = 0u, expired = 0u, expiring = 0u;
             if (TASK == ZENV_TASK_COLOUR_MATCH && ZT > 0) {
 #pragma unroll
                 for (int w = 0; w < ZW; ++w) cdw[w] = cd_decrement(cdw[w]);   // colour_match_env.py:98-100, all zones
             }
+            // The masks are built as in the persistent kernel: d2f >= +0, so its bit pattern orders like its value and
+            // "d2f < bound" is the borrow of an integer subtraction; small integers compare the same way; the borrow is
+            // shifted into the mask with one v_alignbit.  The zones are visited from the top so that zone z ends up in bit z.
+            const uint32_t lo_bits = __float_as_uint(p.d2_lo), hi_bits = __float_as_uint(p.d2_hi);
+            const uint32_t near_bits = __float_as_uint(p.d2_near);
+            const int zn = ZT > 0 ? ZT : Z;
 #pragma unroll
-            for (int z = 0; z < (ZT > 0 ? ZT : Z); ++z) {
+            for (int zr = 0; zr < zn; ++zr) {
+                const int z = zn - 1 - zr;
                 const size_t zi = (size_t)z * N + env;
                 int aux = 0;
                 float4 pr;
@@ -1089,11 +1101,10 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                 }
                 const float x3 = (z & 1) ? pr.z : pr.x, y3 = (z & 1) ? pr.w : pr.y;
                 const float dxf = __builtin_fmaf(3.f, x3, -rxf), dyf = __builtin_fmaf(3.f, y3, -ryf);
-                const float d2f = __builtin_fmaf(dxf, dxf, dyf * dyf);
-                const bool in_sure = d2f < p.d2_lo, out_sure = d2f > p.d2_hi;
-                in_mask |= (in_sure ? 1u : 0u) << z;
-                amb_mask |= ((in_sure || out_sure) ? 0u : 1u) << z;
-                near_mask |= (d2f < p.d2_near ? 1u : 0u) << z;
+                const uint32_t d2b = __float_as_uint(__builtin_fmaf(dxf, dxf, dyf * dyf));
+                in_mask = __builtin_amdgcn_alignbit(in_mask, d2b - lo_bits, 31);         // d2f <  d2_lo: inside for sure
+                out_mask = __builtin_amdgcn_alignbit(out_mask, hi_bits - d2b, 31);       // d2f >  d2_hi: outside for sure
+                near_mask = __builtin_amdgcn_alignbit(near_mask, d2b - near_bits, 31);   // d2f <  d2_near
                 float4 en = make_float4(x3, y3, 0.f, 0.f);
                 if (TASK == ZENV_TASK_COLOUR_MATCH) {
                     int cd = aux;
@@ -1101,21 +1112,22 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                         if (cd > 0) cd -= 1;                    // colour_match_env.py:98-100
                         *cd_byte(p, z, env) = (uint8_t)cd;
                     }
-                    elig_mask |= (cd == 0 ? 1u : 0u) << z;
-                    soon_elig |= (cd <= 1 ? 1u : 0u) << z;     // triggerable at the NEXT step (after its decrement)
+                    elig_mask = __builtin_amdgcn_alignbit(elig_mask, (uint32_t)(cd - 1), 31);   // cd == 0 (cd in 0..255)
+                    soon_elig = __builtin_amdgcn_alignbit(soon_elig, (uint32_t)(cd - 2), 31);   // cd <= 1: triggerable at the NEXT step
                     en.z = (float)(int)((e.colpack >> (2 * z)) & 3ull);
-                    en.w = (float)div_const((double)(float)cd, p.d_maxcd, p.inv_maxcd);
+                    en.w = kDefer ? (float)cd : (float)div_const((double)(float)cd, p.d_maxcd, p.inv_maxcd);
                 } else {
                     const bool vis = (e.vis >> z) & 1u;
                     en.z = vis ? 1.f : 0.f;
                     if (TASK == ZENV_TASK_TIMED_TSP) {
-                        expired |= ((aux - k) <= 0 ? 1u : 0u) << z;     // TTSP_env.py:67
-                        expiring |= ((aux - k) <= 1 ? 1u : 0u) << z;
+                        expired = __builtin_amdgcn_alignbit(expired, (uint32_t)(aux - k - 1), 31);     // tmax - k <= 0, TTSP_env.py:67
+                        expiring = __builtin_amdgcn_alignbit(expiring, (uint32_t)(aux - k - 2), 31);   // tmax - k <= 1
                         en.w = vis ? 1.f : (float)div_const((double)(aux - k), p.d_steps, p.inv_steps);
                     }
                 }
                 my_ents[z] = en;
             }
+            amb_mask = ~(in_mask | out_mask);
             if (amb_mask & full) {
                 // the rim: exact float64 test on the float64 zone centres (rare, divergent)
                 uint32_t m = amb_mask & full;
@@ -1146,7 +1158,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                     }
                     float *slot = reinterpret_cast<float *>(my_ents + first);
                     slot[2] = (float)col;
-                    slot[3] = (float)div_const((double)(float)p.max_cd, p.d_maxcd, p.inv_maxcd);
+                    slot[3] = kDefer ? (float)p.max_cd : (float)div_const((double)(float)p.max_cd, p.d_maxcd, p.inv_maxcd);
                 } else {
                     e.vis |= 1u << first;
                     float *slot = reinterpret_cast<float *>(my_ents + first);
@@ -1265,6 +1277,7 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
                         if (ZT == 0) *cd_byte(p, lane, env_j) = 0;      // (ZT > 0: zeroed in lane j's registers below)
                     }
                     en = make_entry<TASK>(p, zz.x, zz.y, code, aux, 0);
+                    if (kDefer) en.w = 0.f;                   // cooldown count 0
                     ents[j * Z + lane] = en;
                 }
                 {
@@ -1411,7 +1424,8 @@ void k_step_lane(DevParams p, const float *__restrict__ actions, int auto_reset,
     if (role == 0) {
         const int n_blk = min(kWave, N - env0);
 #if !defined(ZENV_EXP) || !(ZENV_EXP & 1)   // diagnostic builds only: ZENV_EXP bit 0 drops the flush
-        flush_entries<TASK, StorePolicy<ZT * F>::kStep>(ents, stage, p.zone_obs + (size_t)env0 * Z * F, n_blk * Z, lane);
+        flush_entries<TASK, StorePolicy<ZT * F>::kStep, kDefer>(ents, stage, p.zone_obs + (size_t)env0 * Z * F, n_blk * Z, lane,
+                                                               p.d_maxcd, p.inv_maxcd);
 #endif
         ZSTAMP(3);
     } else if (env < N) {
