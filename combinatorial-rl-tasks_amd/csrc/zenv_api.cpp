@@ -1379,10 +1379,16 @@ static int ring_guard(const zenv *h, int steps, int auto_reset_every_step)
 // K steps of caller-supplied actions.  With the persistent kernel available (lane layout, a compiled zone count, no
 // goal / order post-kernels) a chunk is one launch per ZENV_ROLLOUT_CHUNK steps and slice; otherwise it is the plain
 // sequence of single-step launches -- same results either way (tests/test_gpu_chunk.py).
-static int chunk_reserve(zenv *h, int steps, bool need_action_copy)
+static int chunk_reserve(zenv *h, int steps, const float *device_actions)
 {
     const size_t N = (size_t)h->n_env, cells = (size_t)steps * N;
     if (cells > h->chunk_cap) {
+        // growing frees the old allocation: a caller that replays ZENV_F_CHUNK_ACTIONS (zenv_device_ptr) must not do it
+        // with more steps than the buffer was sized for
+        const char *a = reinterpret_cast<const char *>(device_actions), *m = static_cast<const char *>(h->chunk_mem);
+        if (a && m && a >= m && a < m + h->chunk_cap * (8 + 4 + 1) + 256)
+            return fail(ZENV_E_ARG, "the actions lie inside the handle's own chunk buffer, which %d steps would outgrow "
+                                    "(size it with one zenv_step_many of host actions first)", steps);
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->chunk_mem) (void)hipFree(h->chunk_mem);
         h->chunk_mem = nullptr;
@@ -1400,7 +1406,6 @@ static int chunk_reserve(zenv *h, int steps, bool need_action_copy)
         h->chunk_reward = h->chunk_actions + 2 * cap;
         h->chunk_done = reinterpret_cast<uint8_t *>(h->chunk_reward + cap);
     }
-    (void)need_action_copy;
     return ZENV_OK;
 }
 
@@ -1417,7 +1422,7 @@ extern "C" int zenv_step_many(zenv_t *h, const float *actions, int actions_on_de
     int rc = use_device(h);
     if (rc) return rc;
     h->act_tag.valid = false;
-    rc = chunk_reserve(h, n_steps, !actions_on_device);
+    rc = chunk_reserve(h, n_steps, actions_on_device ? actions : nullptr);
     if (rc) return rc;
     const size_t N = (size_t)h->n_env;
     const float *d_act = actions;

@@ -179,3 +179,25 @@ def test_parallel_env_step_chunk_is_the_skill_loop(zenv_mod):
             assert np.array_equal(u, v)
         assert x[4] == y[4]
     assert any(l[3].any() for l in outs[0])
+
+
+@pytest.mark.gpu
+def test_replaying_the_chunk_buffer_beyond_its_size_is_refused(zenv_mod):
+    """ZENV_F_CHUNK_ACTIONS may be replayed in place (device pointer), but not with more steps than the buffer was sized
+    for: growing it would free the memory the actions lie in."""
+    Z = zenv_mod
+    from combinatorial_rl_tasks_amd import _native as nat
+    n = 192
+    env = Z.ZoneVecEnv(Z.default_config(0, 5), n)
+    env.build_bank(1, 4 * n)
+    env.schedule_sequential(stride=n)
+    env.reset()
+    a = np.random.RandomState(3).uniform(-1, 1, (4, n, 2)).astype(np.float32)
+    env.step_many(a, reset="every")
+    ptr = env.device_ptr(nat.F_CHUNK_ACTIONS)
+    env.step_many(None, reset="every", actions_ptr=(ptr, 4))          # in place, same size: fine
+    with pytest.raises(Z.ZenvError) as ei:
+        env.step_many(None, reset="every", actions_ptr=(ptr, 8))
+    assert ei.value.code == nat.E_ARG
+    env.step_many(a, reset="every")                                    # the handle is still usable
+    env.close()
