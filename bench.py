@@ -297,13 +297,31 @@ def main():
     if args.rollout_slice is not None:
         env.set_rollout_slice(args.rollout_slice)
     rdzv = None
+    rccl_error = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         rdzv = sharding.FileRendezvous(rank, world)
         if rehearsal:
             shard.host_comm = rdzv
         else:
-            shard.comm_init(env, rdzv)          # ncclCommInitRank on this rank's device (collective)
+            # ncclCommInitRank on this rank's device (collective).  The collective is NOT on the timed path (one gather of
+            # returns after the rollout, one barrier on either side of the region): when RCCL cannot be brought up -- a
+            # library that does not load, a fabric the ranks cannot agree on -- the ranks agree on that through the
+            # rendezvous and the job still measures its shards, with the gather / barrier / max over the host, and says
+            # so in the line (`collective`, `aux.rccl_ranks` = 0, `aux.rccl_error`).
+            try:
+                shard.comm_init(env, rdzv)
+            except Exception as ex:
+                rccl_error = f"rank {rank}: {ex}"
+            oks = rdzv.all_gather("rccl_ok", (rccl_error or "").encode())
+            failed = [b.decode() for b in oks if b]
+            if failed:
+                rccl_error = failed[0]
+                if getattr(env, "comm_world", 0):
+                    native.lib().zenv_comm_destroy(env._h)
+                    env.comm_world = 0
+                shard.host_comm = rdzv
+                rehearsal = True
     t_bank = time.perf_counter()
     if args.bank_maps > 0:
         spot_seeds, spot_stride, spot_period = replay_bank(env, n_env, args.bank_maps, shard.env_index0)
@@ -360,6 +378,7 @@ def main():
             elapsed = env.comm_max(elapsed)
     rccl_ranks = int(getattr(env, "comm_world", 0)) if distributed and not rehearsal else 0
     collective = ("none (single process)" if not distributed else
+                  "host rendezvous (RCCL could not be initialised)" if rccl_error else
                   "host rendezvous (rehearsal: ranks share a GPU)" if rehearsal else
                   f"rccl ncclAllGather (native), {env.comm_library}")
 
@@ -459,7 +478,7 @@ def main():
                        "parallelism": f"env-shard x{world}, all-gather(ep_return) after rollout"},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "aux": {"collective": collective, "rccl_ranks": rccl_ranks, "host_side": "python + ctypes over the C ABI (no PyTorch imported)"
+            "aux": {"collective": collective, "rccl_ranks": rccl_ranks, "rccl_error": rccl_error, "host_side": "python + ctypes over the C ABI (no PyTorch imported)"
                     if sys.modules.get("torch") is None else "python + ctypes over the C ABI (torch present in the process)",
                     "env_overrides": exp, "traffic_stale": traffic_is_stale(),
                     "settle_steps_untimed": args.settle, "hip_event_ms_total": round(ms_total, 3),

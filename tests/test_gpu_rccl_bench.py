@@ -48,6 +48,31 @@ def test_one_rank_native_rccl_gather_matches_the_plain_run(zenv_mod):
     assert dist["aux"]["parity_spot_check"] == "bit-identical" == plain["aux"]["parity_spot_check"]
 
 
+def test_rccl_that_cannot_be_initialised_is_agreed_on_and_reported(zenv_mod):
+    """The collective is not on the timed path: when ncclCommInitRank fails (here: made to raise), the ranks agree on it
+    through the rendezvous and the job still measures its shard -- gather / barrier / max over the host -- and the line
+    says so (collective, rccl_ranks 0, rccl_error)."""
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29647", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+                "HSA_ENABLE_IPC_MODE_LEGACY": "0", "ZENV_BENCH_FORCE_DIST": "1"})
+    boot = ("import sys, runpy; sys.argv = sys.argv[1:]; sys.path.insert(0, %r); "
+            "import combinatorial_rl_tasks_amd.sharding as S\n"
+            "def broken(self, env, rdzv): raise RuntimeError('librccl.so: cannot open shared object file (simulated)')\n"
+            "S.EnvShard.comm_init = broken; runpy.run_path(sys.argv[0], run_name='__main__')") % ROOT
+    cmd = [sys.executable, "-c", boot, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "512", "--warmup", "8",
+           "--workload", "ColourMatch-6", "--no-cpu-baseline", "--no-mlp", "--no-steady", "--no-settle", "--no-sweep",
+           "--envs-per-gpu", "8192"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"rc {r.returncode}\nstdout: {r.stdout[-2000:]}\nstderr: {r.stderr[-4000:]}"
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    plain = _bench({})
+    assert line["aux"]["collective"] == "host rendezvous (RCCL could not be initialised)"
+    assert line["aux"]["rccl_ranks"] == 0 and "simulated" in line["aux"]["rccl_error"]
+    assert line["aux"]["mean_last_return_all_ranks"] == plain["aux"]["mean_last_return_all_ranks"] != 0.0
+    assert line["aux"]["parity_spot_check"] == "bit-identical" and line["value"] > 0
+    assert plain["aux"]["rccl_error"] is None
+
+
 def test_two_rank_launch_line_on_one_gpu(zenv_mod):
     """The driver's N > 1 command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2`
     -- on this box's one GPU (ZENV_BENCH_REHEARSAL=host: both ranks on device 0, gather / barrier / max over the host
